@@ -1,0 +1,154 @@
+"""
+oracle.rdf — CPU restatement of the radial-histogram / RDF path.
+
+TEST INFRASTRUCTURE (see ``oracle/__init__.py``): never imported by the
+product package.
+
+Follows, line by line:
+
+* ``radial_histogram``            reference ``src/mdhelper/analysis/structure.py:32-104``
+* ``RadialDistributionFunction``  ``_prepare :734-748``, ``_single_frame :750-791``,
+                                  ``_conclude :837-862`` (``rdf_normalise`` below)
+
+The pair search of the reference is ``MDAnalysis.lib.distances.capped_distance``
+(third party, absent here, version unpinned ``mdanalysis >= 2.2.0``).  Its
+published brute-force / orthorhombic algorithm
+(``MDAnalysis/lib/src/calc_distances.h``: ``_calc_distance_array_ortho`` +
+``minimum_image``; ``MDAnalysis/lib/distances.py``: ``_bruteforce_capped``) is
+restated in ``pair_distances`` — **parity unpinned at the ULP level** for this
+one step; everything after it (exclusion mask, ``numpy.histogram``) is the
+reference's literal code path.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+_EPS = np.finfo(np.float64).eps
+
+
+def _c_round(s: np.ndarray) -> np.ndarray:
+    """C99 ``round``: nearest integer, halfway cases away from zero."""
+    t = np.trunc(s)
+    return np.where(np.abs(s - t) == 0.5, t + np.sign(s), np.rint(s))
+
+
+def check_box(dims):
+    """float32 box[6] as MDAnalysis stores it; orthorhombic only."""
+    if dims is None:
+        return None
+    box = np.asarray(dims, dtype=np.float32).reshape(-1)
+    if box.shape[0] != 6:
+        raise ValueError("dims must have six entries (lx, ly, lz, alpha, beta, gamma).")
+    if not np.all(box[3:] == 90.0):
+        raise NotImplementedError("Only orthorhombic boxes are supported.")
+    return box
+
+
+def pair_distances(pos1: np.ndarray, pos2: np.ndarray, box) -> np.ndarray:
+    """
+    float64 minimum-image distances d[i, j] between float32 coordinates.
+
+    Arithmetic contract, per component k::
+
+        dx  = (double)(conf[j][k] - ref[i][k])        # float32 subtract, widened
+        inv = (float)(1.0 / box[k])                    # float32 inverse box
+        s   = inv * dx                                 # double
+        dx  = box[k] * (s - round(s))                  # double, C round()
+        rsq = (dx*dx + dy*dy) + dz*dz                  # double, no FMA
+        d   = sqrt(rsq)
+    """
+    ref = np.ascontiguousarray(pos1, dtype=np.float32).reshape(-1, 3)
+    conf = np.ascontiguousarray(pos2, dtype=np.float32).reshape(-1, 3)
+    d32 = conf[None, :, :] - ref[:, None, :]            # float32 arithmetic
+    dx = d32.astype(np.float64)
+    if box is not None:
+        b = box[:3].astype(np.float64)
+        inv = (1.0 / b).astype(np.float32).astype(np.float64)
+        s = inv * dx
+        dx = b * (s - _c_round(s))
+    sq = dx * dx
+    rsq = (sq[..., 0] + sq[..., 1]) + sq[..., 2]
+    return np.sqrt(rsq)
+
+
+def radial_histogram_ref(pos1, pos2, n_bins, range, dims, *, exclusion=None,
+                         chunk_pairs: int = 4_000_000) -> np.ndarray:
+    """
+    int64[n_bins] histogram of in-range ordered pair distances.
+
+    Mirrors ``structure.py:92-104``: capped pairs with
+    ``range[0] - eps < d <= range[1]``, optional exclusion
+    ``i // e0 != j // e1``, then ``numpy.histogram(dist, n_bins, range)``.
+    """
+    box = check_box(dims)
+    ref = np.ascontiguousarray(pos1, dtype=np.float32).reshape(-1, 3)
+    conf = np.ascontiguousarray(pos2, dtype=np.float32).reshape(-1, 3)
+    n1, n2 = ref.shape[0], conf.shape[0]
+    counts = np.zeros(n_bins, dtype=np.int64)
+    if n1 == 0 or n2 == 0:
+        return counts
+    max_cut = np.float64(range[1])
+    min_cut = np.float64(range[0]) - _EPS
+    rows = max(1, int(chunk_pairs // max(n2, 1)))
+    j_idx = np.arange(n2)
+    for lo in np.arange(0, n1, rows):
+        hi = min(n1, lo + rows)
+        d = pair_distances(ref[lo:hi], conf, box)
+        keep = (d <= max_cut) & (d > min_cut)
+        if exclusion is not None:
+            i_idx = np.arange(lo, hi)
+            keep &= (i_idx[:, None] // exclusion[0]) != (j_idx[None, :] // exclusion[1])
+        counts += np.histogram(d[keep], bins=n_bins, range=range)[0]
+    return counts
+
+
+def rdf_edges(n_bins, range):
+    """``_prepare`` (structure.py:737-739)."""
+    edges = np.linspace(*range, n_bins + 1)
+    bins = (edges[:-1] + edges[1:]) / 2
+    return edges, bins
+
+
+def rdf_normalise(counts, edges, n_frames, n1, n2, volume_sum, *, norm="rdf",
+                  exclusion=None, drop_axis=None):
+    """``_conclude`` (structure.py:846-862)."""
+    nrm = n_frames
+    if norm is not None:
+        if drop_axis is None:
+            nrm = nrm * (4 * np.pi * np.diff(edges ** 3) / 3)
+        else:
+            nrm = nrm * (np.pi * np.diff(edges ** 2))
+        if norm == "rdf":
+            _n2 = n2
+            if exclusion:
+                _n2 -= exclusion[1]
+            nrm = nrm * (n1 * _n2 * n_frames / volume_sum)
+    return counts / nrm
+
+
+def rdf_run_ref(frames, boxes, n_bins=201, range=(0.0, 15.0), *, sel1=None,
+                sel2=None, exclusion=None, norm="rdf"):
+    """
+    Serial driver restating ``_prepare/_single_frame/_conclude`` for
+    ``groupings="atoms"``, no ``drop_axis``, no ``n_batches``.
+
+    frames : float32[F, N, 3];  boxes : float32[F, 6] (or [6]).
+    """
+    frames = np.asarray(frames, dtype=np.float32)
+    boxes = np.broadcast_to(np.asarray(boxes, dtype=np.float32), (frames.shape[0], 6))
+    edges, bins = rdf_edges(n_bins, range)
+    counts = np.zeros(n_bins, dtype=np.int64)
+    vol = 0.0
+    sel1 = slice(None) if sel1 is None else sel1
+    sel2 = sel1 if sel2 is None else sel2
+    for f in np.arange(frames.shape[0]):
+        dims = boxes[f]
+        vol += float(np.prod(dims[:3].astype(np.float64)))
+        counts += radial_histogram_ref(frames[f][sel1], frames[f][sel2], n_bins, range,
+                                       dims, exclusion=exclusion)
+    n1 = frames[0][sel1].shape[0]
+    n2 = frames[0][sel2].shape[0]
+    rdf = rdf_normalise(counts, edges, frames.shape[0], n1, n2, vol, norm=norm,
+                        exclusion=exclusion)
+    return {"edges": edges, "bins": bins, "counts": counts, "rdf": rdf, "volume": vol}

@@ -1,0 +1,97 @@
+"""
+Oracle pinning for the radial histogram: the numpy restatement, the C
+restatement and numpy.histogram's binning semantics; the reference's own
+radial_histogram test geometry (tests/test_analysis_structure.py:21-40).
+"""
+import ctypes
+import pathlib
+
+import numpy as np
+import pytest
+
+from oracle import rdf as orf
+from oracle.cbind import c_radial_histogram
+
+
+def test_reference_test_geometry():
+    """Points at known radii around one origin; exact counts vs numpy.histogram."""
+    rng = np.random.default_rng(11)
+    L = 20
+    half_L = L // 2
+    dims = np.array((L, L, L, 90, 90, 90), dtype=int)
+    origin = half_L * np.ones(3)
+    N = 1_000
+    norm = L // 2 * rng.random(N)
+    neighbors = rng.random((N, 3))
+    neighbors *= norm[:, None] / np.linalg.norm(neighbors, axis=1, keepdims=True)
+    neighbors += dims[:3] / 2
+    got = orf.radial_histogram_ref(origin, neighbors, n_bins=half_L, range=(0, half_L + 1), dims=dims)
+    # expected counts from the float32 coordinates the pair search actually sees
+    d = np.linalg.norm(neighbors.astype(np.float32).astype(np.float64)
+                       - origin.astype(np.float32).astype(np.float64), axis=1)
+    want = np.histogram(d, bins=half_L, range=(0, half_L + 1))[0]
+    assert got.sum() == N
+    assert np.abs(got - want).sum() <= 2      # only sub-ulp edge cases may move
+    got_c = c_radial_histogram(origin, neighbors, half_L, (0, half_L + 1), dims)
+    assert np.array_equal(got, got_c)
+
+
+@pytest.mark.parametrize("rng_range", [(0.0, 15.0), (2.0, 9.5), (0.0, 34.47)])
+@pytest.mark.parametrize("exclusion", [None, (1, 1), (3, 3)])
+def test_numpy_and_c_oracles_agree(rng_range, exclusion):
+    rng = np.random.default_rng(5)
+    L = np.float32(68.94)
+    n = 900
+    pos = (rng.random((n, 3)) * L).astype(np.float32)
+    dims = np.array([L, L, L, 90, 90, 90], dtype=np.float32)
+    a = orf.radial_histogram_ref(pos, pos, 201, rng_range, dims, exclusion=exclusion)
+    b = c_radial_histogram(pos, pos, 201, rng_range, dims, exclusion=exclusion)
+    assert np.array_equal(a, b)
+    assert a.sum() > 0
+
+
+def test_two_groups_and_non_cubic():
+    rng = np.random.default_rng(6)
+    dims = np.array([30.0, 41.5, 27.25, 90, 90, 90], dtype=np.float32)
+    p1 = (rng.random((300, 3)) * dims[:3]).astype(np.float32)
+    p2 = (rng.random((500, 3)) * dims[:3] * 3 - dims[:3]).astype(np.float32)   # outside the box too
+    a = orf.radial_histogram_ref(p1, p2, 64, (0.5, 12.0), dims)
+    b = c_radial_histogram(p1, p2, 64, (0.5, 12.0), dims)
+    assert np.array_equal(a, b)
+
+
+def test_binning_is_searchsorted_right():
+    """numpy.histogram uniform bins == searchsorted(edges, d, 'right') - 1, last bin closed."""
+    edges = np.linspace(0.0, 15.0, 202)
+    probes = np.concatenate([edges, np.nextafter(edges, -np.inf), np.nextafter(edges, np.inf)])
+    probes = probes[(probes >= 0) & (probes <= 15.0)]
+    h = np.histogram(probes, bins=201, range=(0.0, 15.0))[0]
+    idx = np.searchsorted(edges, probes, "right") - 1
+    idx[idx == 201] = 200
+    assert np.array_equal(h, np.bincount(idx, minlength=201))
+
+
+def test_self_pairs_and_exclusion_semantics():
+    pos = np.array([[1, 1, 1], [1, 1, 2.5], [4, 4, 4]], dtype=np.float32)
+    dims = np.array([10, 10, 10, 90, 90, 90], dtype=np.float32)
+    # no exclusion: the three self pairs (d = 0) land in bin 0 because 0 > -eps
+    h = orf.radial_histogram_ref(pos, pos, 10, (0.0, 5.0), dims)
+    assert h[0] == 3 and h[3] == 2           # (0,1) and (1,0) at d = 1.5
+    h = orf.radial_histogram_ref(pos, pos, 10, (0.0, 5.0), dims, exclusion=(1, 1))
+    assert h[0] == 0 and h[3] == 2
+    # ordered pairs: both (i, j) and (j, i); (1,2)/(2,1) sit at d = 4.5
+    assert h[9] == 2 and h.sum() == 4
+
+
+def test_triclinic_rejected():
+    pos = np.zeros((2, 3), dtype=np.float32)
+    with pytest.raises(NotImplementedError):
+        orf.radial_histogram_ref(pos, pos, 4, (0, 1), [10, 10, 10, 90, 80, 90])
+
+
+def test_ideal_gas_rdf_is_one():
+    rng = np.random.default_rng(3)
+    L = 30.0
+    frames = (rng.random((4, 1500, 3)) * L).astype(np.float32)
+    res = orf.rdf_run_ref(frames, [L, L, L, 90, 90, 90], n_bins=30, range=(0.0, 12.0), exclusion=(1, 1))
+    assert np.allclose(res["rdf"][8:], 1.0, atol=0.06)
