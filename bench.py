@@ -1,0 +1,330 @@
+#!/usr/bin/env python3
+"""
+bench.py — headline benchmark of the MI355X-native mdhelper hot path.
+
+    python bench.py --gpus N --steps K --warmup W [--workload rdf|sq|msd]
+
+Default workload (BASELINE.json configs[1], "C2"): RDF on 32 768 atoms, cubic
+box L = 68.94 A (rho = 0.1 A^-3), n_bins = 201, range = (0, 15) A, self RDF with
+exclusion = (1, 1); synthetic wrapped Gaussian random walk generated in HBM.
+One *step* = one pass of the hot path (mdx_rdf_accumulate_device) over one batch
+of `--frames` frames already resident in HBM.  For N > 1 (launched by
+torch.distributed.run, one rank per GPU) every rank owns its own batch of
+frames (weak scaling, frames shard with no data-path collective) and the
+per-rank histograms meet in ONE RCCL all-reduce at the end of the timed region.
+
+Prints one JSON line on rank 0:
+  value        = pair distances binned per second, whole job (sum of all counts / time)
+  roofline     = dominant kernel (rdf_tile_kernel) algorithmic HBM bytes / its HIP-event time
+  cpu_baseline = the C restatement of the reference path (oracle/c/rdf_oracle.c,
+                 OpenMP on the host cores) on a bounded sample of the same frames;
+                 its counts are also checked bit-for-bit against the GPU's.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+FP64_VALU_PEAK_TFLOPS = 78.6   # vector fp64 spec
+FP32_VALU_PEAK_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="rdf", choices=["rdf", "rdf_wide", "sq", "msd"])
+    ap.add_argument("--frames", type=int, default=None, help="frames per step per GPU")
+    ap.add_argument("--atoms", type=int, default=None)
+    ap.add_argument("--algo", default="auto", choices=["auto", "exact", "filter", "cell"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time")
+    return ap.parse_args()
+
+
+class World:
+    """Control plane: env from torch.distributed.run; data plane: RCCL inside libmdx."""
+
+    def __init__(self, n_gpus):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != n_gpus:
+            if self.world == 1 and n_gpus > 1:
+                raise SystemExit(
+                    f"--gpus {n_gpus} needs one process per GPU: launch with\n  python -m "
+                    f"torch.distributed.run --nnodes=1 --nproc-per-node {n_gpus} --master-addr "
+                    f"127.0.0.1 --master-port 29500 bench.py --gpus {n_gpus} ...")
+            raise SystemExit(f"WORLD_SIZE={self.world} does not match --gpus {n_gpus}")
+        self.comm = None
+        if self.world > 1:
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            from mdhelper_amd.comm import rccl_comm_from_env
+            self.comm = rccl_comm_from_env(self.local_rank)
+
+    def barrier(self):
+        if self.comm is not None:
+            self.comm.barrier()
+
+    def max(self, x):
+        if self.comm is None:
+            return x
+        return float(self.comm.allreduce(np.array([x], dtype=np.float64), op="max")[0])
+
+    def sum(self, x):
+        if self.comm is None:
+            return x
+        return float(self.comm.allreduce(np.array([x], dtype=np.float64), op="sum")[0])
+
+
+def timed_region(world, dev, steps, body, finish):
+    from mdhelper_amd import _core
+    world.barrier()
+    _core.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        body()
+    finish()
+    _core.synchronize(dev)
+    world.barrier()
+    return world.max(time.perf_counter() - t0)
+
+
+def bench_rdf(args, world, wide=False):
+    from mdhelper_amd import _core
+    dev = world.local_rank
+    N = args.atoms or 32768
+    F = args.frames or 10000
+    L = 68.94 * (N / 32768.0) ** (1.0 / 3.0)
+    n_bins = 201
+    rng = (0.0, float(np.float32(L)) / 2) if wide else (0.0, 15.0)
+    edges = np.linspace(rng[0], rng[1], n_bins + 1)
+    box = np.array([L, L, L, 90, 90, 90], dtype=np.float32)
+
+    traj = _core.synth_random_walk(F, N, box[:3], 0.3, seed=2 + world.rank, dev=dev)
+    d_boxes = _core.DeviceArray.from_host(np.tile(box, (F, 1)), dev)
+    eng = _core.RdfEngine(edges, (1, 1), algo=args.algo, dev=dev, timing=True)
+
+    def step():
+        eng.accumulate_device(traj.ptr, N, None, N, d_boxes.ptr, F)
+
+    for _ in range(args.warmup):
+        step()
+    eng.synchronize()
+    eng.reset()
+
+    def finish():
+        if world.comm is not None:
+            eng.allreduce(world.comm)
+        eng.synchronize()
+
+    dt = timed_region(world, dev, args.steps, step, finish)
+    counts = eng.counts()          # global sum after the all-reduce
+    st = eng.stats()
+    binned = int(counts.sum())
+    frames_total = args.steps * F * world.world
+    launches = max(st["launches"], 1)
+    kernel_s = st["kernel_ms"] * 1e-3
+    alg_bytes_per_launch = F * (12 * N + 24)
+    achieved = alg_bytes_per_launch * launches / kernel_s / 1e9 if kernel_s > 0 else 0.0
+    pairs_eval_rate = st["pairs_evaluated"] / kernel_s if kernel_s > 0 else 0.0
+    out = {
+        "metric": "pair-distances binned/sec",
+        "value": binned / dt,
+        "unit": "pairs/s",
+        "n_gpus": world.world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 filter + f64 contract arithmetic, u64 counts",
+        "data": "synthetic",
+        "config": {"workload": ("C2(ii)" if wide else "C2(i)") + f" RDF {N} atoms x {F} frames/GPU/step, "
+                   f"L={L:.2f} A, n_bins={n_bins}, range=({rng[0]:g},{rng[1]:.4g}), exclusion=(1,1), "
+                   f"algo={args.algo}",
+                   "atoms": N, "frames_per_step_per_gpu": F, "n_bins": n_bins},
+        "frames_per_sec": frames_total / dt,
+        "pair_distances_covered_per_sec": frames_total * float(N) * N / dt,
+        "pairs_binned_per_frame": binned / max(frames_total, 1),
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "kernel": "rdf_tile_kernel", "kernel_ms_per_launch": st["kernel_ms"] / launches,
+            "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+            "note": "O(N^2) arithmetic on O(N) bytes: the kernel is VALU/LDS-atomic bound, see 'valu'",
+            "valu": {
+                "ordered_pairs_per_sec_kernel": pairs_eval_rate,
+                "exact_path_fraction": st["pairs_exact"] / max(st["pairs_evaluated"], 1),
+            },
+        },
+    }
+    if world.rank == 0 and world.world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_rdf(args, traj, box, edges, rng, n_bins, N, eng)
+    eng.close()
+    traj.free()
+    d_boxes.free()
+    return out
+
+
+def cpu_baseline_rdf(args, traj, box, edges, rng, n_bins, N, eng):
+    """C oracle (OpenMP, all host cores) on a bounded sample of the same frames + parity check."""
+    from mdhelper_amd import _core
+    from oracle import cbind
+    threads = max(1, len(os.sched_getaffinity(0)))
+    frames = traj.to_host(0, 1)
+    t0 = time.perf_counter()
+    c0 = cbind.c_radial_histogram(frames[0], frames[0], n_bins, rng, box, exclusion=(1, 1),
+                                  n_threads=threads)
+    t_one = time.perf_counter() - t0
+    n_sample = int(max(1, min(64, args.cpu_seconds // max(t_one, 1e-3))))
+    sample = traj.to_host(0, n_sample)
+    counts = np.zeros(n_bins, dtype=np.int64)
+    t0 = time.perf_counter()
+    for f in range(n_sample):
+        cbind.c_radial_histogram(sample[f], sample[f], n_bins, rng, box, exclusion=(1, 1),
+                                 n_threads=threads, counts=counts)
+    t_cpu = time.perf_counter() - t0
+    # parity of the very same frames on the GPU
+    chk = _core.RdfEngine(edges, (1, 1), algo=args.algo, dev=eng.dev)
+    chk.accumulate(sample, None, box)
+    same = bool(np.array_equal(chk.counts(), counts))
+    chk.close()
+    return {"value": float(counts.sum()) / t_cpu, "unit": "pairs/s", "cores": threads,
+            "kind": "port",
+            "sample": f"{n_sample} of the bench frames, brute-force C restatement "
+                      f"(oracle/c/rdf_oracle.c, OpenMP x{threads}); {t_cpu:.1f} s",
+            "frames_per_sec": n_sample / t_cpu, "gpu_counts_bit_exact_on_sample": same}
+
+
+def bench_sq(args, world):
+    from mdhelper_amd import _core
+    from oracle import fourier as of
+    dev = world.local_rank
+    N = args.atoms or 32768
+    F = args.frames or 1000
+    L = 68.94
+    q = of.grid_wavevectors([L, L, L], 8)          # 512 wavevectors (structure.py:1379-1381)
+    sizes = [N // 2, N - N // 2]
+    pairs = of.ssf_pairs(2, "partial")
+    traj = _core.synth_random_walk(F, N, [L, L, L], 0.3, seed=2 + world.rank, dev=dev)
+    eng = _core.SqEngine(q, sizes, pairs, dev=dev, timing=True)
+
+    def step():
+        eng.accumulate_device(traj.ptr, N, F)
+
+    for _ in range(args.warmup):
+        step()
+    eng.result()
+    eng.reset()
+
+    def finish():
+        if world.comm is not None:
+            eng.allreduce(world.comm)
+
+    dt = timed_region(world, dev, args.steps, step, finish)
+    st = eng.stats()
+    ssf = eng.result()
+    evals = args.steps * F * world.world * float(N) * len(q)
+    kernel_s = st["kernel_ms"] * 1e-3
+    alg = F * (12 * N) + 24 * len(q)
+    achieved = alg * max(st["launches"], 1) / kernel_s / 1e9 if kernel_s > 0 else 0.0
+    out = {
+        "metric": "exp(iq.r) evaluations/sec", "value": evals / dt, "unit": "evals/s",
+        "n_gpus": world.world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"C3 partial S(q) {N} atoms, {len(q)} wavevectors, 2 groups, {F} frames/GPU/step"},
+        "frames_per_sec": args.steps * F * world.world / dt,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "sq_rho_kernel",
+                     "note": "fp64 sincos bound (~40 fp64 instr per evaluation)",
+                     "valu": {"fp64_instr_tflops_est": evals / max(kernel_s, 1e-9) / args.steps * args.steps * 40 / 1e12}},
+        "checksum": float(ssf.sum()),
+    }
+    if world.rank == 0 and world.world == 1 and not args.no_cpu_baseline:
+        sample = traj.to_host(0, 2).astype(np.float64)
+        t0 = time.perf_counter()
+        for f in range(2):
+            of.fourier_sum_ref(q, sample[f])
+        t_cpu = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": 2 * float(N) * len(q) / t_cpu, "unit": "evals/s", "cores": 1,
+                               "kind": "port", "sample": f"2 frames, numpy exp(1j q.r) ({t_cpu:.1f} s)"}
+    eng.close()
+    traj.free()
+    return out
+
+
+def bench_msd(args, world):
+    from mdhelper_amd import _core
+    dev = world.local_rank
+    N = args.atoms or 10000
+    T = args.frames or 100000
+    # particles shard across ranks (transport.py:1036-1039: per-particle MSDs are independent)
+    traj = _core.synth_random_walk(T, N, [1.0, 1.0, 1.0], 0.1, seed=4 + world.rank, dev=dev,
+                                   dtype=np.float64)
+    eng = _core.MsdEngine(T, 1, 2, dev=dev, timing=True)
+
+    def step():
+        eng.reset()
+        eng.push_device(0, traj.ptr, N, 0, N // 2)
+        eng.push_device(1, traj.ptr, N, N // 2, N - N // 2)
+
+    for _ in range(args.warmup):
+        step()
+    box = {}
+
+    def finish():
+        if world.comm is not None:
+            eng.allreduce(world.comm)
+        box["msd"], box["traj"] = eng.result()
+
+    dt = timed_region(world, dev, args.steps, step, finish)
+    st = eng.stats()
+    atom_frames = args.steps * float(N) * T * world.world
+    alg_bytes = 24.0 * N * T
+    kernel_s = st["kernel_ms"] * 1e-3
+    achieved = alg_bytes / max(kernel_s, 1e-9) / 1e9
+    msd = box["msd"][0, 0] / (N // 2)
+    out = {
+        "metric": "MSD atom-frames/sec", "value": atom_frames / dt, "unit": "atom-frames/s",
+        "n_gpus": world.world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"C4 self-MSD {N} atoms x {T} frames, 2 groups, rocFFT n_fft={eng.n_fft}"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "msd pipeline (gather + rocFFT R2C + power) of the last step",
+                     "pipeline_bytes_model": st["bytes_moved"]},
+        "physics_check_msd_over_3sigma2m": float(msd[10] / (3 * 0.01 * 10)),
+    }
+    eng.close()
+    traj.free()
+    return out
+
+
+def main():
+    args = parse()
+    world = World(args.gpus)
+    from mdhelper_amd import _lib
+    _lib.require_device(world.local_rank)
+    if args.workload in ("rdf", "rdf_wide"):
+        out = bench_rdf(args, world, wide=args.workload == "rdf_wide")
+    elif args.workload == "sq":
+        out = bench_sq(args, world)
+    else:
+        out = bench_msd(args, world)
+    if world.rank == 0:
+        print(json.dumps(out))
+    if world.comm is not None:
+        world.comm.close()
+
+
+if __name__ == "__main__":
+    main()

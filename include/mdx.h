@@ -1,0 +1,203 @@
+/*
+ * mdx.h — C-ABI of libmdx.so, the MI355X-native trajectory-analysis core.
+ *
+ * The reference (bbye98/mdhelper) has no FFI on this path: its hot loops sit
+ * behind Python functions.  Each entry point below therefore cites the Python
+ * function (reference file:line) whose work it carries; INTEGRATION.md shows
+ * the ctypes stub a maintainer adds at that call site.
+ *
+ * Conventions
+ *   - every function returns MDX_OK (0) or a negative error class;
+ *     mdx_last_error() returns the thread-local message of the last failure;
+ *   - plain pointers and sizes only; the caller owns every host buffer and the
+ *     library never keeps a host pointer past return;
+ *   - "_device" variants take pointers obtained from mdx_malloc() (HBM-resident
+ *     input, no PCIe traffic inside the call);
+ *   - a handle owns its device memory and stream, is bound to one device and
+ *     is not thread-safe (one handle per device per host thread);
+ *   - positions are float32[n_frames][n][3] (MDAnalysis' native layout),
+ *     boxes float32[n_frames][6] = (lx, ly, lz, alpha, beta, gamma), or NULL
+ *     for no periodic boundaries.  Non-orthorhombic boxes are rejected with
+ *     MDX_ERR_UNSUPPORTED rather than silently mis-binned.
+ */
+#ifndef MDX_H
+#define MDX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDX_VERSION 100 /* 0.1.0 */
+
+#define MDX_OK 0
+#define MDX_ERR_INVALID_VALUE (-1) /* -> ValueError          */
+#define MDX_ERR_UNSUPPORTED (-2)   /* -> NotImplementedError */
+#define MDX_ERR_NO_DEVICE (-3)     /* -> RuntimeError        */
+#define MDX_ERR_HIP (-4)           /* -> RuntimeError        */
+#define MDX_ERR_ROCFFT (-5)        /* -> RuntimeError        */
+#define MDX_ERR_RCCL (-6)          /* -> RuntimeError        */
+#define MDX_ERR_OUT_OF_MEMORY (-7) /* -> MemoryError         */
+#define MDX_ERR_STATE (-8)         /* -> RuntimeError        */
+
+/* ------------------------------------------------------------------ runtime */
+
+const char *mdx_last_error(void);
+int mdx_version(void);
+int mdx_device_count(int *count);
+/* name: caller buffer of name_len bytes; any out pointer may be NULL. */
+int mdx_device_info(int dev, char *name, size_t name_len, int *compute_units,
+                    size_t *hbm_bytes, size_t *hbm_free_bytes);
+int mdx_malloc(int dev, size_t bytes, void **dptr);
+int mdx_free(int dev, void *dptr);
+int mdx_memcpy_h2d(int dev, void *dst, const void *src, size_t bytes);
+int mdx_memcpy_d2h(int dev, void *dst, const void *src, size_t bytes);
+int mdx_memset(int dev, void *dst, int value, size_t bytes);
+int mdx_device_synchronize(int dev);
+
+/* Synthetic wrapped Gaussian random walk, generated in HBM (bench / tests):
+ * frame 0 uniform in [0, L)^3, then x += sigma * N(0,1) wrapped into the box;
+ * counter-based Philox-4x32-10 keyed by (seed, atom, frame) so any frame can
+ * be regenerated anywhere.  out: float32[n_frames][n_atoms][3] on the device. */
+int mdx_synth_random_walk(int dev, float *d_out, int64_t n_frames, int64_t n_atoms,
+                          const float box_lengths[3], float sigma, uint64_t seed,
+                          int wrap);
+/* Unwrapped walk in float64[n_frames][n_atoms][3] (the Onsager position store,
+ * transport.py:932), same generator. */
+int mdx_synth_random_walk_f64(int dev, double *d_out, int64_t n_frames, int64_t n_atoms,
+                              const float box_lengths[3], float sigma, uint64_t seed);
+
+/* ---------------------------------------------------------------- collectives
+ * One process per GPU; the communicator is RCCL over xGMI.  Rank 0 calls
+ * mdx_comm_unique_id() and ships the 128-byte id to the other ranks through
+ * whatever rendezvous the launcher offers (bench.py: the torch.distributed
+ * TCPStore); then every rank calls mdx_comm_init_rank(). */
+typedef struct mdx_comm *mdx_comm_t;
+#define MDX_COMM_ID_BYTES 128
+int mdx_comm_unique_id(unsigned char id[MDX_COMM_ID_BYTES]);
+int mdx_comm_init_rank(mdx_comm_t *comm, int dev, const unsigned char id[MDX_COMM_ID_BYTES],
+                       int rank, int world_size);
+int mdx_comm_destroy(mdx_comm_t comm);
+int mdx_comm_barrier(mdx_comm_t comm);
+/* in-place sum / max all-reduce of small host vectors (staged through HBM) */
+int mdx_comm_allreduce_f64(mdx_comm_t comm, double *host_inout, int64_t n, int op_max);
+int mdx_comm_allreduce_i64(mdx_comm_t comm, int64_t *host_inout, int64_t n);
+
+/* ------------------------------------------------------------------------ RDF
+ * Replaces the per-frame body of RadialDistributionFunction._single_frame
+ * (reference src/mdhelper/analysis/structure.py:750-791), i.e. the call
+ *     counts += radial_histogram(pos1, pos2, n_bins, range, dims, exclusion)
+ * (structure.py:32-104, :788-791) for a batch of frames at once. */
+typedef struct mdx_rdf *mdx_rdf_t;
+
+#define MDX_RDF_ALGO_AUTO 0
+#define MDX_RDF_ALGO_EXACT_F64 1 /* contract arithmetic on every pair            */
+#define MDX_RDF_ALGO_FILTER_F32 2 /* f32 filter + exact f64 re-evaluation near edges */
+#define MDX_RDF_ALGO_CELL 3      /* cell-sorted tiles, culled tile pairs, f32 filter */
+
+/* edges: the n_bins+1 float64 bin edges exactly as numpy.linspace(r_min, r_max,
+ * n_bins+1) yields them (structure.py:737; numpy.histogram builds the same
+ * array).  excl1/excl2: the reference's `exclusion` tuple, 0/0 for None. */
+int mdx_rdf_create(mdx_rdf_t *out, int dev, int n_bins, const double *edges,
+                   int64_t excl1, int64_t excl2, int algo);
+int mdx_rdf_destroy(mdx_rdf_t h);
+int mdx_rdf_reset(mdx_rdf_t h);
+/* Host buffers.  pos2 == NULL (or == pos1 with n2 == n1) means ag2 is ag1: the
+ * kernel then evaluates each unordered pair once and counts it twice, which is
+ * bit-identical because the contract arithmetic is exactly antisymmetric. */
+int mdx_rdf_accumulate(mdx_rdf_t h, const float *pos1, int64_t n1, const float *pos2,
+                       int64_t n2, const float *boxes, int64_t n_frames);
+/* Same, all pointers in HBM (from mdx_malloc); asynchronous on the handle's stream. */
+int mdx_rdf_accumulate_device(mdx_rdf_t h, const float *d_pos1, int64_t n1,
+                              const float *d_pos2, int64_t n2, const float *d_boxes,
+                              int64_t n_frames);
+/* Waits for the stream, then copies int64[n_bins] counts (np.intp, structure.py:740). */
+int mdx_rdf_counts(mdx_rdf_t h, int64_t *counts);
+int mdx_rdf_synchronize(mdx_rdf_t h);
+/* Sum the counts of every rank's handle (one RCCL all-reduce, uint64 sum). */
+int mdx_rdf_allreduce(mdx_rdf_t h, mdx_comm_t comm);
+/* Timing / statistics of the pair kernel, measured with HIP events on the
+ * handle's stream: launches since reset, total milliseconds, pair distances
+ * evaluated, pairs re-evaluated by the exact path.  Any pointer may be NULL. */
+int mdx_rdf_stats(mdx_rdf_t h, int64_t *launches, double *kernel_ms,
+                  int64_t *pairs_evaluated, int64_t *pairs_exact);
+int mdx_rdf_enable_timing(mdx_rdf_t h, int on);
+
+/* Function-level drop-in for structure.radial_histogram (structure.py:32-104):
+ * one frame, host buffers, counts overwritten. */
+int mdx_radial_histogram(int dev, const float *pos1, int64_t n1, const float *pos2,
+                         int64_t n2, int n_bins, const double *edges, const float dims[6],
+                         int64_t excl1, int64_t excl2, int64_t *counts);
+
+/* --------------------------------------------------------------- structure factor
+ * Replaces StructureFactor._single_frame (structure.py:1481-1527) with its
+ * Numba kernels delta_fourier_transform_sum_2d_2d / inner_2d_2d /
+ * pythagorean_trigonometric_identity_* (src/mdhelper/algorithm/accelerated.py:81-321):
+ *   rho_g(q) = sum_{j in group g} exp(i q.r_j)  (fp64), then per pair (j,k)
+ *   ssf += |rho_j|^2  (j == k)   or   2 Re(rho_j rho_k*)  (j != k).
+ * Both `form`s of the reference map onto this one fused kernel. */
+typedef struct mdx_sq *mdx_sq_t;
+
+/* wavevectors: float64[n_q][3].  group_offsets: int64[n_groups+1] into the
+ * concatenated position array (structure.py:1427-1431).  pairs: int32[n_pairs][2]
+ * group indices; (-1,-1) = all particles as one group (mode=None). */
+int mdx_sq_create(mdx_sq_t *out, int dev, const double *wavevectors, int64_t n_q,
+                  const int64_t *group_offsets, int n_groups, const int32_t *pairs,
+                  int n_pairs);
+int mdx_sq_destroy(mdx_sq_t h);
+int mdx_sq_reset(mdx_sq_t h);
+int mdx_sq_accumulate(mdx_sq_t h, const float *pos, int64_t n, int64_t n_frames);
+int mdx_sq_accumulate_device(mdx_sq_t h, const float *d_pos, int64_t n, int64_t n_frames);
+/* float64[n_pairs][n_q] un-normalised sums over frames (structure.py:1494-1508). */
+int mdx_sq_result(mdx_sq_t h, double *ssf);
+int mdx_sq_allreduce(mdx_sq_t h, mdx_comm_t comm);
+int mdx_sq_stats(mdx_sq_t h, int64_t *launches, double *kernel_ms);
+int mdx_sq_enable_timing(mdx_sq_t h, int on);
+/* Function-level drop-in for accelerated.delta_fourier_transform_sum_2d_2d
+ * (accelerated.py:81-122): out = complex128[n_q] as (re, im) pairs; float64 positions. */
+int mdx_fourier_sum(int dev, const double *wavevectors, int64_t n_q, const double *positions,
+                    int64_t n, double *out_re_im);
+
+/* ------------------------------------------------------------- time correlation
+ * Replaces algorithm.correlation.correlation_fft / msd_fft
+ * (src/mdhelper/algorithm/correlation.py:17-226, :461-668) as called from
+ * Onsager._conclude (src/mdhelper/analysis/transport.py:1016-1059). */
+typedef struct mdx_msd *mdx_msd_t;
+
+/* One engine per (n_frames_block, n_blocks): plans a batched rocFFT R2C/C2R of
+ * length n_fft = 2*next_fast_len(n_frames_block) (correlation.py:176-178). */
+int mdx_msd_create(mdx_msd_t *out, int dev, int64_t n_frames_block, int n_blocks,
+                   int n_groups);
+int mdx_msd_destroy(mdx_msd_t h);
+int mdx_msd_reset(mdx_msd_t h);
+int mdx_msd_n_fft(mdx_msd_t h, int64_t *n_fft);
+/* Feed particles of one group: pos float64[n_blocks*n_frames_block][n_total][3]
+ * (transport.py:932 layout), of which particles [first, first+count) belong to
+ * `group`.  Accumulates sum_particles of the per-particle self MSD numerators
+ * and sum_particles r(t) for the collective terms.  zero_dims: bit k set ->
+ * dimension k is zeroed (transport.py:1025,1033). */
+int mdx_msd_push(mdx_msd_t h, int group, const double *pos, int64_t n_total, int64_t first,
+                 int64_t count, int zero_dims);
+int mdx_msd_push_device(mdx_msd_t h, int group, const double *d_pos, int64_t n_total,
+                        int64_t first, int64_t count, int zero_dims);
+/* msd_self[g][b][t] = sum_particles MSD_particle / N_g  (transport.py:1036-1039, before /2D)
+ * sum_traj[g][b][t][3] = sum_particles r(t)            (input of :1034 and :1044-1052) */
+int mdx_msd_result(mdx_msd_t h, double *msd_self_sum, double *sum_traj);
+int mdx_msd_allreduce(mdx_msd_t h, mdx_comm_t comm);
+int mdx_msd_stats(mdx_msd_t h, int64_t *launches, double *kernel_ms, int64_t *bytes_moved);
+int mdx_msd_enable_timing(mdx_msd_t h, int on);
+
+/* Function-level drop-in for correlation.correlation_fft on real input
+ * (correlation.py:17-226): n_series independent series of length n_t, laid out
+ * [n_series][n_t] contiguous; b == NULL -> ACF.  out[n_series][n_t] =
+ * sum_k a[k] b[k+m] (un-normalised, lags m = 0..n_t-1); with neg_out != NULL the
+ * negative lags sum_k a[k+m] b[k] are written there too. */
+int mdx_correlate(int dev, const double *a, const double *b, int64_t n_series, int64_t n_t,
+                  double *out, double *neg_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDX_H */

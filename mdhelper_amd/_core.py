@@ -1,0 +1,349 @@
+"""
+Thin object wrappers over the C-ABI handles of ``libmdx.so``: device arrays,
+the RCCL communicator and the three analysis engines.  Host-side glue only —
+all arithmetic happens in the HIP library.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from ctypes import byref, c_double, c_int, c_int64, c_size_t, c_void_p
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(c_void_p)
+
+
+class DeviceArray:
+    """A typed HBM allocation (``mdx_malloc``); inputs of the ``*_device`` entry points."""
+
+    def __init__(self, shape, dtype, dev: int = 0):
+        self.shape = tuple(int(s) for s in np.atleast_1d(shape))
+        self.dtype = np.dtype(dtype)
+        self.dev = dev
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        p = c_void_p()
+        check(lib().mdx_malloc(dev, self.nbytes, byref(p)))
+        self.ptr = p
+
+    @classmethod
+    def from_host(cls, arr, dev: int = 0):
+        arr = np.ascontiguousarray(arr)
+        out = cls(arr.shape, arr.dtype, dev)
+        check(lib().mdx_memcpy_h2d(dev, out.ptr, _ptr(arr), arr.nbytes))
+        return out
+
+    def to_host(self, first: int = 0, count: int | None = None):
+        """Copy rows [first, first+count) of the leading axis back to the host."""
+        n0 = self.shape[0]
+        count = n0 - first if count is None else count
+        row = self.nbytes // max(n0, 1)
+        out = np.empty((count,) + self.shape[1:], dtype=self.dtype)
+        src = c_void_p(self.ptr.value + first * row)
+        check(lib().mdx_memcpy_d2h(self.dev, _ptr(out), src, count * row))
+        return out
+
+    def offset(self, first: int):
+        """Raw pointer to row ``first`` of the leading axis."""
+        row = self.nbytes // max(self.shape[0], 1)
+        return c_void_p(self.ptr.value + first * row)
+
+    def free(self):
+        if getattr(self, "ptr", None) is not None and self.ptr.value:
+            lib().mdx_free(self.dev, self.ptr)
+            self.ptr = c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def device_info(dev: int = 0):
+    name = ctypes.create_string_buffer(256)
+    cus = c_int()
+    total = c_size_t()
+    free = c_size_t()
+    check(lib().mdx_device_info(dev, name, 256, byref(cus), byref(total), byref(free)))
+    return {"name": name.value.decode(), "compute_units": cus.value, "hbm_bytes": total.value,
+            "hbm_free_bytes": free.value}
+
+
+def synchronize(dev: int = 0):
+    check(lib().mdx_device_synchronize(dev))
+
+
+def synth_random_walk(n_frames, n_atoms, box_lengths, sigma, seed, *, wrap=True, dev=0,
+                      dtype=np.float32):
+    """Synthetic trajectory generated in HBM (``mdx_synth_random_walk``)."""
+    out = DeviceArray((n_frames, n_atoms, 3), dtype, dev)
+    L = (ctypes.c_float * 3)(*[float(x) for x in box_lengths])
+    if np.dtype(dtype) == np.float32:
+        check(lib().mdx_synth_random_walk(dev, out.ptr, n_frames, n_atoms, L, float(sigma),
+                                          int(seed), int(bool(wrap))))
+    else:
+        check(lib().mdx_synth_random_walk_f64(dev, out.ptr, n_frames, n_atoms, L, float(sigma),
+                                              int(seed)))
+    return out
+
+
+class RcclComm:
+    """One rank of an RCCL communicator (``mdx_comm_*``)."""
+
+    device_collectives = True
+
+    def __init__(self, rank: int, world_size: int, unique_id: bytes, dev: int = 0):
+        assert len(unique_id) == 128
+        self.rank, self.world_size, self.dev = rank, world_size, dev
+        buf = ctypes.create_string_buffer(unique_id, 128)
+        h = c_void_p()
+        check(lib().mdx_comm_init_rank(byref(h), dev, buf, rank, world_size))
+        self.handle = h
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(128)
+        check(lib().mdx_comm_unique_id(buf))
+        return buf.raw
+
+    def barrier(self):
+        check(lib().mdx_comm_barrier(self.handle))
+
+    def allreduce(self, arr, op="sum"):
+        arr = np.ascontiguousarray(arr)
+        if arr.dtype == np.int64 and op == "sum":
+            check(lib().mdx_comm_allreduce_i64(self.handle, _ptr(arr), arr.size))
+        else:
+            arr = arr.astype(np.float64)
+            check(lib().mdx_comm_allreduce_f64(self.handle, _ptr(arr), arr.size, int(op == "max")))
+        return arr
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            lib().mdx_comm_destroy(self.handle)
+            self.handle = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _Engine:
+    _destroy = None
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            getattr(lib(), self._destroy)(self.handle)
+            self.handle = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class RdfEngine(_Engine):
+    """``mdx_rdf_*``: pair-distance histogram accumulated over batches of frames."""
+
+    _destroy = "mdx_rdf_destroy"
+
+    def __init__(self, edges, exclusion=None, *, algo="auto", dev=0, timing=False):
+        self.edges = np.ascontiguousarray(edges, dtype=np.float64)
+        self.n_bins = self.edges.size - 1
+        e1, e2 = (0, 0) if exclusion is None else (int(exclusion[0]), int(exclusion[1]))
+        h = c_void_p()
+        check(lib().mdx_rdf_create(byref(h), dev, self.n_bins, _ptr(self.edges), e1, e2,
+                                   _lib.RDF_ALGO[algo]))
+        self.handle = h
+        self.dev = dev
+        if timing:
+            check(lib().mdx_rdf_enable_timing(h, 1))
+
+    def accumulate(self, pos1, pos2=None, boxes=None):
+        """pos: float32[F, N, 3] (host); boxes float32[F, 6] or None."""
+        p1 = np.ascontiguousarray(pos1, dtype=np.float32)
+        if p1.ndim == 2:
+            p1 = p1[None]
+        F, n1 = p1.shape[0], p1.shape[1]
+        if pos2 is None or pos2 is pos1:
+            p2, n2 = None, n1
+        else:
+            p2 = np.ascontiguousarray(pos2, dtype=np.float32)
+            if p2.ndim == 2:
+                p2 = p2[None]
+            n2 = p2.shape[1]
+            if p2.shape[0] != F:
+                raise ValueError("pos1 and pos2 must hold the same number of frames.")
+        b = None
+        if boxes is not None:
+            b = np.ascontiguousarray(np.broadcast_to(np.asarray(boxes, dtype=np.float32), (F, 6)))
+        check(lib().mdx_rdf_accumulate(self.handle, _ptr(p1), n1, _ptr(p2), n2, _ptr(b), F))
+
+    def accumulate_device(self, d_pos1, n1, d_pos2, n2, d_boxes, n_frames):
+        check(lib().mdx_rdf_accumulate_device(self.handle, d_pos1, n1, d_pos2, n2, d_boxes, n_frames))
+
+    def counts(self):
+        out = np.zeros(self.n_bins, dtype=np.int64)
+        check(lib().mdx_rdf_counts(self.handle, _ptr(out)))
+        return out
+
+    def synchronize(self):
+        check(lib().mdx_rdf_synchronize(self.handle))
+
+    def reset(self):
+        check(lib().mdx_rdf_reset(self.handle))
+
+    def allreduce(self, comm: RcclComm):
+        check(lib().mdx_rdf_allreduce(self.handle, comm.handle))
+
+    def stats(self):
+        n, ms, pe, px = c_int64(), c_double(), c_int64(), c_int64()
+        check(lib().mdx_rdf_stats(self.handle, byref(n), byref(ms), byref(pe), byref(px)))
+        return {"launches": n.value, "kernel_ms": ms.value, "pairs_evaluated": pe.value,
+                "pairs_exact": px.value}
+
+
+def radial_histogram_device(pos1, pos2, n_bins, edges, dims, exclusion=None, dev=0):
+    """``mdx_radial_histogram``: one frame, host buffers."""
+    p1 = np.ascontiguousarray(pos1, dtype=np.float32).reshape(-1, 3)
+    p2 = np.ascontiguousarray(pos2, dtype=np.float32).reshape(-1, 3)
+    box = None if dims is None else np.ascontiguousarray(dims, dtype=np.float32).reshape(6)
+    edges = np.ascontiguousarray(edges, dtype=np.float64)
+    e1, e2 = (0, 0) if exclusion is None else (int(exclusion[0]), int(exclusion[1]))
+    counts = np.zeros(n_bins, dtype=np.int64)
+    same = pos2 is pos1
+    check(lib().mdx_radial_histogram(dev, _ptr(p1), p1.shape[0], _ptr(p1 if same else p2),
+                                     p2.shape[0], n_bins, _ptr(edges), _ptr(box), e1, e2,
+                                     _ptr(counts)))
+    return counts
+
+
+class SqEngine(_Engine):
+    """``mdx_sq_*``: fused exp(i q.r) accumulation and pair products."""
+
+    _destroy = "mdx_sq_destroy"
+
+    def __init__(self, wavevectors, group_sizes, pairs, *, dev=0, timing=False):
+        self.q = np.ascontiguousarray(wavevectors, dtype=np.float64).reshape(-1, 3)
+        self.offsets = np.concatenate(([0], np.cumsum(group_sizes))).astype(np.int64)
+        self.pairs = np.ascontiguousarray(
+            [(-1, -1) if p[0] is None else (int(p[0]), int(p[1])) for p in pairs], dtype=np.int32)
+        h = c_void_p()
+        check(lib().mdx_sq_create(byref(h), dev, _ptr(self.q), self.q.shape[0], _ptr(self.offsets),
+                                  len(group_sizes), _ptr(self.pairs), self.pairs.shape[0]))
+        self.handle = h
+        self.dev = dev
+        if timing:
+            check(lib().mdx_sq_enable_timing(h, 1))
+
+    def accumulate(self, pos):
+        p = np.ascontiguousarray(pos, dtype=np.float32)
+        if p.ndim == 2:
+            p = p[None]
+        check(lib().mdx_sq_accumulate(self.handle, _ptr(p), p.shape[1], p.shape[0]))
+
+    def accumulate_device(self, d_pos, n, n_frames):
+        check(lib().mdx_sq_accumulate_device(self.handle, d_pos, n, n_frames))
+
+    def result(self):
+        out = np.zeros((self.pairs.shape[0], self.q.shape[0]), dtype=np.float64)
+        check(lib().mdx_sq_result(self.handle, _ptr(out)))
+        return out
+
+    def reset(self):
+        check(lib().mdx_sq_reset(self.handle))
+
+    def allreduce(self, comm: RcclComm):
+        check(lib().mdx_sq_allreduce(self.handle, comm.handle))
+
+    def stats(self):
+        n, ms = c_int64(), c_double()
+        check(lib().mdx_sq_stats(self.handle, byref(n), byref(ms)))
+        return {"launches": n.value, "kernel_ms": ms.value}
+
+
+def fourier_sum_device(wavevectors, positions, dev=0):
+    """``mdx_fourier_sum``: complex128[N_q] = sum_j exp(i q.r_j), float64 positions."""
+    q = np.ascontiguousarray(wavevectors, dtype=np.float64).reshape(-1, 3)
+    r = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, 3)
+    out = np.zeros(q.shape[0], dtype=np.complex128)
+    check(lib().mdx_fourier_sum(dev, _ptr(q), q.shape[0], _ptr(r), r.shape[0], _ptr(out)))
+    return out
+
+
+class MsdEngine(_Engine):
+    """``mdx_msd_*``: per-group sums of per-particle MSDs through rocFFT."""
+
+    _destroy = "mdx_msd_destroy"
+
+    def __init__(self, n_frames_block, n_blocks, n_groups, *, dev=0, timing=False):
+        h = c_void_p()
+        check(lib().mdx_msd_create(byref(h), dev, int(n_frames_block), int(n_blocks), int(n_groups)))
+        self.handle = h
+        self.dev = dev
+        self.t_block, self.n_blocks, self.n_groups = int(n_frames_block), int(n_blocks), int(n_groups)
+        if timing:
+            check(lib().mdx_msd_enable_timing(h, 1))
+
+    @property
+    def n_fft(self):
+        n = c_int64()
+        check(lib().mdx_msd_n_fft(self.handle, byref(n)))
+        return n.value
+
+    def push(self, group, positions, first, count, zero_dims=0):
+        """positions: float64[T, N_total, 3] on the host."""
+        p = np.ascontiguousarray(positions, dtype=np.float64)
+        if p.shape[0] < self.t_block * self.n_blocks:
+            raise ValueError("positions hold fewer frames than n_blocks * n_frames_block.")
+        check(lib().mdx_msd_push(self.handle, group, _ptr(p), p.shape[1], first, count, zero_dims))
+
+    def push_device(self, group, d_pos, n_total, first, count, zero_dims=0):
+        check(lib().mdx_msd_push_device(self.handle, group, d_pos, n_total, first, count, zero_dims))
+
+    def result(self, want_msd=True):
+        msd = np.zeros((self.n_groups, self.n_blocks, self.t_block)) if want_msd else None
+        traj = np.zeros((self.n_groups, self.n_blocks, self.t_block, 3))
+        check(lib().mdx_msd_result(self.handle, _ptr(msd), _ptr(traj)))
+        return msd, traj
+
+    def reset(self):
+        check(lib().mdx_msd_reset(self.handle))
+
+    def allreduce(self, comm: RcclComm):
+        check(lib().mdx_msd_allreduce(self.handle, comm.handle))
+
+    def stats(self):
+        n, ms, nb = c_int64(), c_double(), c_int64()
+        check(lib().mdx_msd_stats(self.handle, byref(n), byref(ms), byref(nb)))
+        return {"launches": n.value, "kernel_ms": ms.value, "bytes_moved": nb.value}
+
+
+def correlate_device(a, b=None, *, negative=False, dev=0):
+    """
+    ``mdx_correlate``: un-normalised linear correlations of real series.
+
+    a, b : float64[n_series, n_t].  Returns ``pos[n_series, n_t]`` with
+    ``pos[s, m] = sum_k a[s, k] b[s, k+m]`` and, when ``negative``, also
+    ``neg[s, m] = sum_k a[s, k+m] b[s, k]``.
+    """
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    n_series, n_t = a.shape
+    bb = None
+    if b is not None:
+        bb = np.ascontiguousarray(b, dtype=np.float64)
+        if bb.shape != a.shape:
+            raise ValueError("The arrays must have the same dimensions.")
+    out = np.zeros_like(a)
+    neg = np.zeros_like(a) if negative else None
+    check(lib().mdx_correlate(dev, _ptr(a), _ptr(bb), n_series, n_t, _ptr(out), _ptr(neg)))
+    return (out, neg) if negative else out

@@ -1,0 +1,131 @@
+"""
+ctypes binding of ``libmdx.so`` (C-ABI declared in ``include/mdx.h``).
+
+There is no CPU fallback: if the shared library is missing, or no HIP device is
+visible when a compute entry point is called, an exception is raised.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import pathlib
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
+
+_PKG = pathlib.Path(__file__).resolve().parent
+LIB_PATH = pathlib.Path(os.environ.get("MDX_LIBRARY", _PKG / "libmdx.so"))
+
+MDX_OK = 0
+_EXC = {
+    -1: ValueError,            # MDX_ERR_INVALID_VALUE
+    -2: NotImplementedError,   # MDX_ERR_UNSUPPORTED
+    -3: RuntimeError,          # MDX_ERR_NO_DEVICE
+    -4: RuntimeError,          # MDX_ERR_HIP
+    -5: RuntimeError,          # MDX_ERR_ROCFFT
+    -6: RuntimeError,          # MDX_ERR_RCCL
+    -7: MemoryError,           # MDX_ERR_OUT_OF_MEMORY
+    -8: RuntimeError,          # MDX_ERR_STATE
+}
+
+RDF_ALGO = {"auto": 0, "exact": 1, "filter": 2, "cell": 3}
+
+_vp = c_void_p
+_SIGNATURES = {
+    # runtime
+    "mdx_last_error": (c_char_p, []),
+    "mdx_version": (c_int, []),
+    "mdx_device_count": (c_int, [POINTER(c_int)]),
+    "mdx_device_info": (c_int, [c_int, c_char_p, c_size_t, POINTER(c_int), POINTER(c_size_t), POINTER(c_size_t)]),
+    "mdx_malloc": (c_int, [c_int, c_size_t, POINTER(_vp)]),
+    "mdx_free": (c_int, [c_int, _vp]),
+    "mdx_memcpy_h2d": (c_int, [c_int, _vp, _vp, c_size_t]),
+    "mdx_memcpy_d2h": (c_int, [c_int, _vp, _vp, c_size_t]),
+    "mdx_memset": (c_int, [c_int, _vp, c_int, c_size_t]),
+    "mdx_device_synchronize": (c_int, [c_int]),
+    "mdx_synth_random_walk": (c_int, [c_int, _vp, c_int64, c_int64, POINTER(c_float), c_float, c_uint64, c_int]),
+    "mdx_synth_random_walk_f64": (c_int, [c_int, _vp, c_int64, c_int64, POINTER(c_float), c_float, c_uint64]),
+    # collectives
+    "mdx_comm_unique_id": (c_int, [_vp]),
+    "mdx_comm_init_rank": (c_int, [POINTER(_vp), c_int, _vp, c_int, c_int]),
+    "mdx_comm_destroy": (c_int, [_vp]),
+    "mdx_comm_barrier": (c_int, [_vp]),
+    "mdx_comm_allreduce_f64": (c_int, [_vp, _vp, c_int64, c_int]),
+    "mdx_comm_allreduce_i64": (c_int, [_vp, _vp, c_int64]),
+    # RDF
+    "mdx_rdf_create": (c_int, [POINTER(_vp), c_int, c_int, _vp, c_int64, c_int64, c_int]),
+    "mdx_rdf_destroy": (c_int, [_vp]),
+    "mdx_rdf_reset": (c_int, [_vp]),
+    "mdx_rdf_accumulate": (c_int, [_vp, _vp, c_int64, _vp, c_int64, _vp, c_int64]),
+    "mdx_rdf_accumulate_device": (c_int, [_vp, _vp, c_int64, _vp, c_int64, _vp, c_int64]),
+    "mdx_rdf_counts": (c_int, [_vp, _vp]),
+    "mdx_rdf_synchronize": (c_int, [_vp]),
+    "mdx_rdf_allreduce": (c_int, [_vp, _vp]),
+    "mdx_rdf_stats": (c_int, [_vp, POINTER(c_int64), POINTER(c_double), POINTER(c_int64), POINTER(c_int64)]),
+    "mdx_rdf_enable_timing": (c_int, [_vp, c_int]),
+    "mdx_radial_histogram": (c_int, [c_int, _vp, c_int64, _vp, c_int64, c_int, _vp, _vp, c_int64, c_int64, _vp]),
+    # structure factor
+    "mdx_sq_create": (c_int, [POINTER(_vp), c_int, _vp, c_int64, _vp, c_int, _vp, c_int]),
+    "mdx_sq_destroy": (c_int, [_vp]),
+    "mdx_sq_reset": (c_int, [_vp]),
+    "mdx_sq_accumulate": (c_int, [_vp, _vp, c_int64, c_int64]),
+    "mdx_sq_accumulate_device": (c_int, [_vp, _vp, c_int64, c_int64]),
+    "mdx_sq_result": (c_int, [_vp, _vp]),
+    "mdx_sq_allreduce": (c_int, [_vp, _vp]),
+    "mdx_sq_stats": (c_int, [_vp, POINTER(c_int64), POINTER(c_double)]),
+    "mdx_sq_enable_timing": (c_int, [_vp, c_int]),
+    "mdx_fourier_sum": (c_int, [c_int, _vp, c_int64, _vp, c_int64, _vp]),
+    # time correlation
+    "mdx_msd_create": (c_int, [POINTER(_vp), c_int, c_int64, c_int, c_int]),
+    "mdx_msd_destroy": (c_int, [_vp]),
+    "mdx_msd_reset": (c_int, [_vp]),
+    "mdx_msd_n_fft": (c_int, [_vp, POINTER(c_int64)]),
+    "mdx_msd_push": (c_int, [_vp, c_int, _vp, c_int64, c_int64, c_int64, c_int]),
+    "mdx_msd_push_device": (c_int, [_vp, c_int, _vp, c_int64, c_int64, c_int64, c_int]),
+    "mdx_msd_result": (c_int, [_vp, _vp, _vp]),
+    "mdx_msd_allreduce": (c_int, [_vp, _vp]),
+    "mdx_msd_stats": (c_int, [_vp, POINTER(c_int64), POINTER(c_double), POINTER(c_int64)]),
+    "mdx_msd_enable_timing": (c_int, [_vp, c_int]),
+    "mdx_correlate": (c_int, [c_int, _vp, _vp, c_int64, c_int64, _vp, _vp]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def lib():
+    """The loaded ``libmdx.so``; raises ImportError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise ImportError(
+                f"{LIB_PATH} not found: build the HIP library first "
+                "(`make -C mdhelper_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "mdhelper_amd has no CPU fallback.")
+        handle = ctypes.CDLL(str(LIB_PATH))
+        for name, (restype, argtypes) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != MDX_OK:
+        msg = lib().mdx_last_error()
+        msg = msg.decode("utf-8", "replace") if msg else f"libmdx error {rc}"
+        raise _EXC.get(rc, RuntimeError)(msg)
+
+
+def device_count() -> int:
+    n = c_int(0)
+    check(lib().mdx_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def require_device(dev: int = 0) -> None:
+    if device_count() <= dev:
+        raise RuntimeError(
+            f"HIP device {dev} is not available; mdhelper_amd runs its analysis kernels on an "
+            "AMD GPU only (no CPU fallback).")

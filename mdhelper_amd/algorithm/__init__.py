@@ -1,0 +1,3 @@
+"""Algorithms of the hot path (mirrors ``mdhelper.algorithm``)."""
+
+from . import correlation, molecule, topology, unit, utility  # noqa: F401

@@ -1,0 +1,91 @@
+"""
+Communicators for frame- / particle-sharded runs (one process per GPU).
+
+* ``SerialComm``     — world of one (default).
+* ``RcclComm``       — RCCL over xGMI through ``libmdx.so`` (``mdx_comm_*``); the
+                       accumulators are all-reduced in HBM (``engine.allreduce``).
+* ``TorchDistComm``  — any initialised ``torch.distributed`` process group
+                       (``gloo`` on CPU, ``nccl`` = RCCL on GPUs); the host copies
+                       of the accumulators are all-reduced.  Used by the
+                       world_size-2 CPU tests and wherever a process group exists.
+
+The reference's counterpart is the per-frame gather-and-sum of
+``ParallelAnalysisBase.run`` (reference src/mdhelper/analysis/base.py:396-501,
+``np.vstack(...).sum(axis=0)`` at analysis/structure.py:842).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_range(n: int, rank: int, world_size: int) -> tuple[int, int]:
+    """Contiguous, balanced share [lo, hi) of ``n`` items for ``rank``."""
+    base, extra = divmod(n, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+class SerialComm:
+    rank = 0
+    world_size = 1
+    device_collectives = False
+
+    def allreduce(self, arr, op="sum"):
+        return np.asarray(arr)
+
+    def barrier(self):
+        pass
+
+
+class TorchDistComm:
+    """Host-side all-reduce over an existing ``torch.distributed`` process group."""
+
+    device_collectives = False
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised.")
+        self._dist = dist
+        self._group = group
+        self.rank = dist.get_rank(group)
+        self.world_size = dist.get_world_size(group)
+
+    def allreduce(self, arr, op="sum"):
+        import torch
+        a = np.ascontiguousarray(arr)
+        t = torch.from_numpy(a.copy())
+        if self._dist.get_backend(self._group) == "nccl":
+            t = t.cuda()
+        red = self._dist.ReduceOp.SUM if op == "sum" else self._dist.ReduceOp.MAX
+        self._dist.all_reduce(t, op=red, group=self._group)
+        return t.cpu().numpy().astype(a.dtype, copy=False)
+
+    def barrier(self):
+        self._dist.barrier(group=self._group)
+
+
+def rccl_comm_from_env(device: int | None = None):
+    """
+    Build an ``RcclComm`` for a process launched by ``torch.distributed.run``:
+    rank 0 creates the RCCL unique id and ships it through a gloo broadcast
+    (control plane only); the data plane is RCCL inside ``libmdx.so``.
+    """
+    import os
+
+    from ._core import RcclComm
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1:
+        return RcclComm(0, 1, RcclComm.unique_id(), device)
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        dist.init_process_group(backend="gloo")
+    box = [RcclComm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    comm = RcclComm(rank, world, box[0], device)
+    comm.device_collectives = True
+    return comm

@@ -1,0 +1,593 @@
+// mdx_msd.hip — FFT time correlation / MSD on gfx950 (MI355X) with rocFFT.
+//
+// Carries reference src/mdhelper/algorithm/correlation.py:
+//   correlation_fft :17-226   f = rfft(x, n=N_fft); corr = irfft(f f*)[:N_t]
+//                             with N_fft = 2 * next_fast_len(N_t, real=True)
+//   msd_fft         :461-668  MSD_m = S_m - 2 A_m, S_m by the cumsum recurrence
+// as Onsager._conclude calls them (src/mdhelper/analysis/transport.py:1016-1059):
+// per-particle self MSDs summed over the particles of a group (:1036-1039) and the
+// summed trajectories of each group for the collective / cross terms (:1034, :1044-1052).
+//
+// Engine (mdx_msd_*): HBM-bound.  The reference materialises a spectrum, a product
+// and an inverse per particle (3 x 48 GB at 10k particles x 100k frames); by linearity
+//     sum_p irfft(|F_p|^2) = irfft(sum_p |F_p|^2)
+// so the engine keeps ONE power spectrum per (group, block), accumulated over
+// particles and xyz, and does one inverse transform per (group, block) at the end.
+// Per pushed chunk of particles:
+//   1. msd_gather_kernel   [T][N][3] -> zero-padded series [b][a][k][N_fft]  (LDS transpose)
+//   2. msd_sums_kernel     D_t = sum_{a,k} x^2  and  sum_a r_a(t)          (fixed order)
+//   3. rocFFT R2C, batch = 3 * particles * blocks, double precision
+//   4. msd_power_kernel    P[b][f] += sum_{a,k} |F|^2                      (fixed order)
+// Everything is fp64: S_m - 2 A_m cancels catastrophically at small lags.
+#include "mdx_common.hpp"
+#include "mdx_internal.hpp"
+
+#include <rocfft/rocfft.h>
+
+#include <map>
+
+using namespace mdx;
+
+namespace {
+
+#define MDX_FFT(expr)                                                             \
+    do {                                                                          \
+        rocfft_status _s = (expr);                                                \
+        if (_s != rocfft_status_success)                                          \
+            return fail(MDX_ERR_ROCFFT, "%s failed with rocfft_status %d", #expr, (int)_s); \
+    } while (0)
+
+int rocfft_ready()
+{
+    static bool done = false;
+    if (!done) {
+        MDX_FFT(rocfft_setup());
+        done = true;
+    }
+    return MDX_OK;
+}
+
+// scipy.fft.next_fast_len(n, real=True): smallest 2^a 3^b 5^c >= n
+int64_t next_fast_len_real(int64_t n)
+{
+    if (n <= 6)
+        return std::max<int64_t>(n, 1);
+    int64_t best = INT64_MAX;
+    for (int64_t p5 = 1; p5 < 2 * n; p5 *= 5)
+        for (int64_t p35 = p5; p35 < 2 * n; p35 *= 3) {
+            int64_t v = p35;
+            while (v < n)
+                v *= 2;
+            best = std::min(best, v);
+        }
+    return best;
+}
+
+struct FftPlan {
+    rocfft_plan plan = nullptr;
+    size_t work_bytes = 0;
+};
+
+struct FftCache {
+    std::map<std::pair<int, int64_t>, FftPlan> plans;   // (direction, batch)
+    rocfft_execution_info info = nullptr;
+    DeviceBuffer work;
+    int64_t n_fft = 0;
+
+    int get(int inverse, int64_t batch, FftPlan **out)
+    {
+        auto key = std::make_pair(inverse, batch);
+        auto it = plans.find(key);
+        if (it == plans.end()) {
+            FftPlan p;
+            size_t len = (size_t)n_fft;
+            rocfft_plan_description desc = nullptr;
+            MDX_FFT(rocfft_plan_description_create(&desc));
+            const size_t nc = (size_t)(n_fft / 2 + 1);
+            rocfft_status s;
+            if (!inverse)
+                s = rocfft_plan_description_set_data_layout(
+                    desc, rocfft_array_type_real, rocfft_array_type_hermitian_interleaved, nullptr,
+                    nullptr, 1, nullptr, len, 1, nullptr, nc);
+            else
+                s = rocfft_plan_description_set_data_layout(
+                    desc, rocfft_array_type_hermitian_interleaved, rocfft_array_type_real, nullptr,
+                    nullptr, 1, nullptr, nc, 1, nullptr, len);
+            if (s == rocfft_status_success)
+                s = rocfft_plan_create(&p.plan, rocfft_placement_notinplace,
+                                       inverse ? rocfft_transform_type_real_inverse
+                                               : rocfft_transform_type_real_forward,
+                                       rocfft_precision_double, 1, &len, (size_t)batch, desc);
+            rocfft_plan_description_destroy(desc);
+            if (s != rocfft_status_success)
+                return fail(MDX_ERR_ROCFFT, "rocfft_plan_create(n=%lld, batch=%lld) failed (%d)",
+                            (long long)n_fft, (long long)batch, (int)s);
+            MDX_FFT(rocfft_plan_get_work_buffer_size(p.plan, &p.work_bytes));
+            it = plans.emplace(key, p).first;
+        }
+        *out = &it->second;
+        return MDX_OK;
+    }
+
+    int exec(int inverse, int64_t batch, void *in, void *out, hipStream_t stream)
+    {
+        FftPlan *p = nullptr;
+        MDX_TRY(get(inverse, batch, &p));
+        if (!info)
+            MDX_FFT(rocfft_execution_info_create(&info));
+        MDX_FFT(rocfft_execution_info_set_stream(info, stream));
+        if (p->work_bytes) {
+            if (p->work_bytes > work.bytes) {
+                // the previous work buffer may still be in use on the stream
+                MDX_HIP(hipStreamSynchronize(stream));
+                MDX_TRY(work.ensure(p->work_bytes));
+            }
+            MDX_FFT(rocfft_execution_info_set_work_buffer(info, work.ptr, p->work_bytes));
+        }
+        void *ib[1] = {in}, *ob[1] = {out};
+        MDX_FFT(rocfft_execute(p->plan, ib, ob, info));
+        return MDX_OK;
+    }
+
+    void destroy()
+    {
+        for (auto &kv : plans)
+            if (kv.second.plan)
+                rocfft_plan_destroy(kv.second.plan);
+        plans.clear();
+        if (info)
+            rocfft_execution_info_destroy(info);
+        info = nullptr;
+        work.release();
+    }
+};
+
+// ------------------------------------------------------------------- kernels
+
+constexpr int GT = 64;   // gather tile: 64 timesteps x 64 (particle, xyz) elements
+
+// X[((b*count + a)*3 + k)][t] = pos[(b*T_b + t)][first + a][k]  (t < T_b), 0 for t >= T_b
+__global__ __launch_bounds__(256) void msd_gather_kernel(const double *__restrict__ pos,
+                                                         int64_t n_total, int64_t first,
+                                                         int64_t count, int64_t t_block,
+                                                         int64_t n_fft, int zero_dims,
+                                                         double *__restrict__ X)
+{
+    __shared__ double tile[GT][GT + 1];
+    const int b = blockIdx.z;
+    const int64_t e0 = int64_t(blockIdx.y) * GT;   // element = a*3 + k within the chunk
+    const int64_t t0 = int64_t(blockIdx.x) * GT;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t n_elem = count * 3;
+    if (t0 < t_block) {
+        for (int r = ty; r < GT; r += 4) {
+            int64_t t = t0 + r, e = e0 + tx;
+            double v = 0.0;
+            if (t < t_block && e < n_elem) {
+                v = pos[((int64_t(b) * t_block + t) * n_total + first) * 3 + e];
+                if ((zero_dims >> int(e % 3)) & 1)
+                    v = 0.0;
+            }
+            tile[r][tx] = v;
+        }
+        __syncthreads();
+        for (int r = ty; r < GT; r += 4) {
+            int64_t e = e0 + r, t = t0 + tx;
+            if (e < n_elem && t < n_fft)
+                X[(int64_t(b) * n_elem + e) * n_fft + t] = tile[tx][r];
+        }
+    } else {
+        for (int r = ty; r < GT; r += 4) {
+            int64_t e = e0 + r, t = t0 + tx;
+            if (e < n_elem && t < n_fft)
+                X[(int64_t(b) * n_elem + e) * n_fft + t] = 0.0;
+        }
+    }
+}
+
+// per frame row: traj[row][k] += sum_a x_{a,k};  D[row] += sum_{a,k} x^2   (192 threads, k = tid % 3)
+__global__ __launch_bounds__(192) void msd_sums_kernel(const double *__restrict__ pos,
+                                                       int64_t n_total, int64_t first, int64_t count,
+                                                       int zero_dims, double *__restrict__ traj,
+                                                       double *__restrict__ D)
+{
+    __shared__ double s_sum[192], s_sq[192];
+    const int64_t row = blockIdx.x;
+    const int tid = threadIdx.x;
+    const double *p = pos + (row * n_total + first) * 3;
+    const int64_t n_elem = count * 3;
+    const bool dead = (zero_dims >> (tid % 3)) & 1;
+    double a = 0.0, q = 0.0;
+    for (int64_t e = tid; e < n_elem; e += 192) {
+        double v = dead ? 0.0 : p[e];
+        a += v;
+        q = fma(v, v, q);
+    }
+    s_sum[tid] = a;
+    s_sq[tid] = q;
+    __syncthreads();
+    if (tid < 3) {
+        double sa = 0.0, sq = 0.0;
+        for (int i = tid; i < 192; i += 3) {
+            sa += s_sum[i];
+            sq += s_sq[i];
+        }
+        traj[row * 3 + tid] += sa;
+        s_sq[tid] = sq;
+    }
+    __syncthreads();
+    if (tid == 0)
+        D[row] += (s_sq[0] + s_sq[1]) + s_sq[2];
+}
+
+// P[b][f] += sum over the chunk's series of |F[b][series][f]|^2
+__global__ __launch_bounds__(256) void msd_power_kernel(const double2 *__restrict__ F,
+                                                        int64_t n_series, int64_t nc,
+                                                        double *__restrict__ P)
+{
+    const int64_t f = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (f >= nc)
+        return;
+    const double2 *p = F + int64_t(b) * n_series * nc + f;
+    double acc = 0.0;
+    for (int64_t s = 0; s < n_series; ++s) {
+        double2 v = p[s * nc];
+        acc = fma(v.x, v.x, fma(v.y, v.y, acc));
+    }
+    P[int64_t(b) * nc + f] += acc;
+}
+
+__global__ void msd_real_to_complex_kernel(const double *__restrict__ P, int64_t n,
+                                           double2 *__restrict__ C)
+{
+    int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n)
+        C[i] = make_double2(P[i], 0.0);
+}
+
+// [n_series][n_t] -> zero-padded [n_series][n_fft]
+__global__ void corr_pad_kernel(const double *__restrict__ in, int64_t n_series, int64_t n_t,
+                                int64_t n_fft, double *__restrict__ out)
+{
+    int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n_series * n_fft)
+        return;
+    int64_t s = i / n_fft, t = i - s * n_fft;
+    out[i] = t < n_t ? in[s * n_t + t] : 0.0;
+}
+
+// C = conj(A) * B   (B == nullptr: |A|^2)
+__global__ void corr_product_kernel(const double2 *__restrict__ A, const double2 *__restrict__ B,
+                                    int64_t n, double2 *__restrict__ C)
+{
+    int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    double2 a = A[i];
+    if (B) {
+        double2 b = B[i];
+        C[i] = make_double2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x);
+    } else {
+        C[i] = make_double2(a.x * a.x + a.y * a.y, 0.0);
+    }
+}
+
+}  // namespace
+
+struct mdx_msd {
+    int dev = 0;
+    hipStream_t stream = nullptr;
+    int64_t t_block = 0, n_fft = 0, nc = 0;
+    int n_blocks = 0, n_groups = 0;
+    FftCache fft;
+    // accumulators: power [G][B][nc] + D [G][B*T_b] contiguous (one all-reduce), traj [G][B*T_b][3]
+    DeviceBuffer d_acc, d_traj, d_series, d_spec, d_stage, d_inv_in, d_inv_out;
+    StreamTimer timer;
+    int64_t bytes_moved = 0;
+    double *power(int g) { return d_acc.as<double>() + int64_t(g) * n_blocks * nc; }
+    double *dsq(int g)
+    {
+        return d_acc.as<double>() + int64_t(n_groups) * n_blocks * nc + int64_t(g) * n_blocks * t_block;
+    }
+    double *traj(int g) { return d_traj.as<double>() + int64_t(g) * n_blocks * t_block * 3; }
+    int64_t acc_len() const { return int64_t(n_groups) * n_blocks * (nc + t_block); }
+    int64_t traj_len() const { return int64_t(n_groups) * n_blocks * t_block * 3; }
+};
+
+static int msd_push_device(mdx_msd *h, int group, const double *d_pos, int64_t n_total, int64_t first,
+                           int64_t count, int zero_dims)
+{
+    if (count == 0)
+        return MDX_OK;
+    const int B = h->n_blocks;
+    // chunk the particles so that series + spectrum stay within ~40% of free HBM
+    size_t free_b = 0, total_b = 0;
+    MDX_HIP(hipMemGetInfo(&free_b, &total_b));
+    free_b += h->d_series.bytes + h->d_spec.bytes;
+    const int64_t per_atom = 3 * B * (h->n_fft * 8 + h->nc * 16);
+    int64_t chunk = std::max<int64_t>(1, int64_t(double(free_b) * 0.4) / per_atom);
+    chunk = std::min<int64_t>(chunk, count);
+    // a handful of equal chunks keeps the rocFFT plan cache small
+    const int64_t n_chunks = ceil_div(count, chunk);
+    chunk = ceil_div(count, n_chunks);
+    MDX_TRY(h->d_series.ensure(size_t(chunk) * 3 * B * h->n_fft * 8));
+    MDX_TRY(h->d_spec.ensure(size_t(chunk) * 3 * B * h->nc * 16));
+    hipEvent_t ev = h->timer.begin();
+    for (int64_t a0 = 0; a0 < count; a0 += chunk) {
+        const int64_t c = std::min(chunk, count - a0);
+        const int64_t n_elem = c * 3;
+        dim3 g1((unsigned)ceil_div(h->n_fft, GT), (unsigned)ceil_div(n_elem, GT), (unsigned)B);
+        hipLaunchKernelGGL(msd_gather_kernel, g1, dim3(256), 0, h->stream, d_pos, n_total,
+                           first + a0, c, h->t_block, h->n_fft, zero_dims, h->d_series.as<double>());
+        hipLaunchKernelGGL(msd_sums_kernel, dim3((unsigned)(B * h->t_block)), dim3(192), 0, h->stream,
+                           d_pos, n_total, first + a0, c, zero_dims, h->traj(group), h->dsq(group));
+        MDX_TRY(h->fft.exec(0, n_elem * B, h->d_series.ptr, h->d_spec.ptr, h->stream));
+        hipLaunchKernelGGL(msd_power_kernel, dim3((unsigned)ceil_div(h->nc, 256), (unsigned)B),
+                           dim3(256), 0, h->stream, h->d_spec.as<double2>(), n_elem, h->nc,
+                           h->power(group));
+        // algorithmic traffic of this chunk: positions read twice, series written + read,
+        // spectrum written + read
+        h->bytes_moved += c * 3 * B * (2 * h->t_block * 8 + 2 * h->n_fft * 8 + 2 * h->nc * 16);
+    }
+    h->timer.end(ev);
+    MDX_HIP(hipGetLastError());
+    return MDX_OK;
+}
+
+extern "C" {
+
+int mdx_msd_create(mdx_msd_t *out, int dev, int64_t n_frames_block, int n_blocks, int n_groups)
+{
+    MDX_REQUIRE(out, "NULL argument");
+    MDX_REQUIRE(n_frames_block >= 1 && n_frames_block < (int64_t(1) << 30), "n_frames_block out of range");
+    MDX_REQUIRE(n_blocks >= 1 && n_blocks <= 65535, "n_blocks out of range");
+    MDX_REQUIRE(n_groups >= 1 && n_groups <= 4096, "n_groups out of range");
+    MDX_TRY(set_device(dev));
+    MDX_TRY(rocfft_ready());
+    mdx_msd *h = new mdx_msd();
+    h->dev = dev;
+    h->t_block = n_frames_block;
+    h->n_blocks = n_blocks;
+    h->n_groups = n_groups;
+    h->n_fft = 2 * next_fast_len_real(n_frames_block);
+    h->nc = h->n_fft / 2 + 1;
+    h->fft.n_fft = h->n_fft;
+    int rc = MDX_OK;
+    do {
+        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+            rc = fail(MDX_ERR_HIP, "hipStreamCreate failed");
+            break;
+        }
+        h->timer.stream = h->stream;
+        if ((rc = h->d_acc.ensure(size_t(8) * h->acc_len())) != MDX_OK) break;
+        if ((rc = h->d_traj.ensure(size_t(8) * h->traj_len())) != MDX_OK) break;
+    } while (0);
+    if (rc != MDX_OK) {
+        mdx_msd_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return mdx_msd_reset(h);
+}
+
+int mdx_msd_destroy(mdx_msd_t h)
+{
+    if (!h)
+        return MDX_OK;
+    (void)hipSetDevice(h->dev);
+    if (h->stream)
+        (void)hipStreamSynchronize(h->stream);
+    h->timer.destroy();
+    h->fft.destroy();
+    for (DeviceBuffer *b : {&h->d_acc, &h->d_traj, &h->d_series, &h->d_spec, &h->d_stage,
+                            &h->d_inv_in, &h->d_inv_out})
+        b->release();
+    if (h->stream)
+        (void)hipStreamDestroy(h->stream);
+    delete h;
+    return MDX_OK;
+}
+
+int mdx_msd_reset(mdx_msd_t h)
+{
+    MDX_REQUIRE(h, "NULL handle");
+    MDX_TRY(set_device(h->dev));
+    MDX_HIP(hipMemsetAsync(h->d_acc.ptr, 0, size_t(8) * h->acc_len(), h->stream));
+    MDX_HIP(hipMemsetAsync(h->d_traj.ptr, 0, size_t(8) * h->traj_len(), h->stream));
+    MDX_HIP(hipStreamSynchronize(h->stream));
+    h->timer.reset();
+    h->bytes_moved = 0;
+    return MDX_OK;
+}
+
+int mdx_msd_n_fft(mdx_msd_t h, int64_t *n_fft)
+{
+    MDX_REQUIRE(h && n_fft, "NULL argument");
+    *n_fft = h->n_fft;
+    return MDX_OK;
+}
+
+int mdx_msd_push_device(mdx_msd_t h, int group, const double *d_pos, int64_t n_total, int64_t first,
+                        int64_t count, int zero_dims)
+{
+    MDX_REQUIRE(h && d_pos, "NULL argument");
+    MDX_REQUIRE(group >= 0 && group < h->n_groups, "group %d out of range", group);
+    MDX_REQUIRE(first >= 0 && count >= 0 && first + count <= n_total, "particle range out of bounds");
+    MDX_REQUIRE(zero_dims >= 0 && zero_dims < 8, "zero_dims is a 3-bit mask");
+    MDX_TRY(set_device(h->dev));
+    return msd_push_device(h, group, d_pos, n_total, first, count, zero_dims);
+}
+
+int mdx_msd_push(mdx_msd_t h, int group, const double *pos, int64_t n_total, int64_t first,
+                 int64_t count, int zero_dims)
+{
+    MDX_REQUIRE(h && pos, "NULL argument");
+    MDX_REQUIRE(group >= 0 && group < h->n_groups, "group %d out of range", group);
+    MDX_REQUIRE(first >= 0 && count >= 0 && first + count <= n_total, "particle range out of bounds");
+    MDX_REQUIRE(zero_dims >= 0 && zero_dims < 8, "zero_dims is a 3-bit mask");
+    MDX_TRY(set_device(h->dev));
+    // stage [T][count_chunk][3] slabs: rows are strided on the host (n_total particles per frame)
+    const int64_t T = int64_t(h->n_blocks) * h->t_block;
+    const int64_t budget = int64_t(2) << 30;
+    int64_t chunk = std::max<int64_t>(1, budget / (T * 24));
+    chunk = std::min(chunk, count);
+    for (int64_t a0 = 0; a0 < count; a0 += chunk) {
+        const int64_t c = std::min(chunk, count - a0);
+        MDX_TRY(h->d_stage.ensure(size_t(T) * c * 24));
+        MDX_HIP(hipMemcpy2DAsync(h->d_stage.ptr, size_t(c) * 24, pos + (first + a0) * 3,
+                                 size_t(n_total) * 24, size_t(c) * 24, (size_t)T,
+                                 hipMemcpyHostToDevice, h->stream));
+        MDX_TRY(msd_push_device(h, group, h->d_stage.as<double>(), c, 0, c, zero_dims));
+        MDX_HIP(hipStreamSynchronize(h->stream));
+    }
+    return MDX_OK;
+}
+
+int mdx_msd_result(mdx_msd_t h, double *msd_self_sum, double *sum_traj)
+{
+    MDX_REQUIRE(h, "NULL handle");
+    MDX_TRY(set_device(h->dev));
+    const int64_t GB = int64_t(h->n_groups) * h->n_blocks;
+    const int64_t Tb = h->t_block;
+    if (sum_traj) {
+        MDX_HIP(hipStreamSynchronize(h->stream));
+        MDX_HIP(hipMemcpy(sum_traj, h->d_traj.ptr, size_t(8) * h->traj_len(), hipMemcpyDeviceToHost));
+    }
+    if (!msd_self_sum) {
+        h->timer.collect();
+        return MDX_OK;
+    }
+    MDX_TRY(h->d_inv_in.ensure(size_t(16) * GB * h->nc));
+    MDX_TRY(h->d_inv_out.ensure(size_t(8) * GB * h->n_fft));
+    hipEvent_t ev = h->timer.begin();
+    hipLaunchKernelGGL(msd_real_to_complex_kernel, dim3((unsigned)ceil_div(GB * h->nc, 256)),
+                       dim3(256), 0, h->stream, h->d_acc.as<double>(), GB * h->nc,
+                       h->d_inv_in.as<double2>());
+    MDX_TRY(h->fft.exec(1, GB, h->d_inv_in.ptr, h->d_inv_out.ptr, h->stream));
+    h->timer.end(ev);
+    std::vector<double> acf(size_t(GB) * Tb), D(size_t(GB) * Tb);
+    MDX_HIP(hipMemcpy2DAsync(acf.data(), size_t(Tb) * 8, h->d_inv_out.ptr, size_t(h->n_fft) * 8,
+                             size_t(Tb) * 8, (size_t)GB, hipMemcpyDeviceToHost, h->stream));
+    MDX_HIP(hipMemcpyAsync(D.data(), h->dsq(0), size_t(8) * GB * Tb, hipMemcpyDeviceToHost, h->stream));
+    MDX_HIP(hipStreamSynchronize(h->stream));
+    h->timer.collect();
+    // MSD_m = S_m - 2 A_m   (correlation.py:621-648, summed over the particles)
+    const double inv_n = 1.0 / double(h->n_fft);
+    for (int64_t gb = 0; gb < GB; ++gb) {
+        const double *d = D.data() + gb * Tb;
+        const double *a = acf.data() + gb * Tb;
+        double *o = msd_self_sum + gb * Tb;
+        double total = 0.0;
+        for (int64_t t = 0; t < Tb; ++t)
+            total += d[t];
+        double run = 0.0;
+        for (int64_t m = 0; m < Tb; ++m) {
+            if (m > 0)
+                run += d[m - 1] + d[Tb - m];
+            const double w = double(Tb - m);
+            o[m] = (2.0 * total - run) / w - 2.0 * (a[m] * inv_n) / w;
+        }
+    }
+    return MDX_OK;
+}
+
+int mdx_msd_stats(mdx_msd_t h, int64_t *launches, double *kernel_ms, int64_t *bytes_moved)
+{
+    MDX_REQUIRE(h, "NULL handle");
+    MDX_TRY(set_device(h->dev));
+    MDX_HIP(hipStreamSynchronize(h->stream));
+    h->timer.collect();
+    if (launches) *launches = h->timer.launches;
+    if (kernel_ms) *kernel_ms = h->timer.total_ms;
+    if (bytes_moved) *bytes_moved = h->bytes_moved;
+    return MDX_OK;
+}
+
+int mdx_msd_enable_timing(mdx_msd_t h, int on)
+{
+    MDX_REQUIRE(h, "NULL handle");
+    h->timer.enabled = on != 0;
+    return MDX_OK;
+}
+
+int mdx_msd_internal_buffers(mdx_msd_t h, double **d_a, int64_t *na, double **d_b, int64_t *nb,
+                             hipStream_t *stream)
+{
+    MDX_TRY(set_device(h->dev));
+    *d_a = h->d_acc.as<double>();
+    *na = h->acc_len();
+    *d_b = h->d_traj.as<double>();
+    *nb = h->traj_len();
+    *stream = h->stream;
+    return MDX_OK;
+}
+
+int mdx_correlate(int dev, const double *a, const double *b, int64_t n_series, int64_t n_t,
+                  double *out, double *neg_out)
+{
+    MDX_REQUIRE(a && out, "NULL argument");
+    MDX_REQUIRE(n_series >= 1 && n_t >= 1 && n_t < (int64_t(1) << 30), "bad size");
+    MDX_TRY(set_device(dev));
+    MDX_TRY(rocfft_ready());
+    const int64_t n_fft = 2 * next_fast_len_real(n_t);
+    const int64_t nc = n_fft / 2 + 1;
+    const int64_t per_series = n_fft * 8 * 2 + nc * 16 * 2 + n_t * 8 * 2;
+    int64_t chunk = std::max<int64_t>(1, (int64_t(3) << 30) / per_series);
+    chunk = std::min(chunk, n_series);
+    FftCache fft;
+    fft.n_fft = n_fft;
+    DeviceBuffer d_in, d_pad, d_fa, d_fb;
+    std::vector<double> host(size_t(chunk) * n_fft);
+    int rc = MDX_OK;
+    auto run = [&]() -> int {
+        MDX_TRY(d_in.ensure(size_t(chunk) * n_t * 8));
+        MDX_TRY(d_pad.ensure(size_t(chunk) * n_fft * 8));
+        MDX_TRY(d_fa.ensure(size_t(chunk) * nc * 16));
+        if (b)
+            MDX_TRY(d_fb.ensure(size_t(chunk) * nc * 16));
+        for (int64_t s0 = 0; s0 < n_series; s0 += chunk) {
+            const int64_t c = std::min(chunk, n_series - s0);
+            const unsigned gp = (unsigned)ceil_div(c * n_fft, 256);
+            MDX_HIP(hipMemcpy(d_in.ptr, a + s0 * n_t, size_t(c) * n_t * 8, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(corr_pad_kernel, dim3(gp), dim3(256), 0, 0, d_in.as<double>(), c, n_t,
+                               n_fft, d_pad.as<double>());
+            MDX_TRY(fft.exec(0, c, d_pad.ptr, d_fa.ptr, nullptr));
+            if (b) {
+                MDX_HIP(hipMemcpy(d_in.ptr, b + s0 * n_t, size_t(c) * n_t * 8, hipMemcpyHostToDevice));
+                hipLaunchKernelGGL(corr_pad_kernel, dim3(gp), dim3(256), 0, 0, d_in.as<double>(), c,
+                                   n_t, n_fft, d_pad.as<double>());
+                MDX_TRY(fft.exec(0, c, d_pad.ptr, d_fb.ptr, nullptr));
+            }
+            hipLaunchKernelGGL(corr_product_kernel, dim3((unsigned)ceil_div(c * nc, 256)), dim3(256),
+                               0, 0, d_fa.as<double2>(), b ? d_fb.as<double2>() : nullptr, c * nc,
+                               d_fa.as<double2>());
+            MDX_TRY(fft.exec(1, c, d_fa.ptr, d_pad.ptr, nullptr));
+            MDX_HIP(hipDeviceSynchronize());
+            MDX_HIP(hipMemcpy(host.data(), d_pad.ptr, size_t(c) * n_fft * 8, hipMemcpyDeviceToHost));
+            const double inv_n = 1.0 / double(n_fft);
+            for (int64_t s = 0; s < c; ++s) {
+                const double *r = host.data() + s * n_fft;
+                double *o = out + (s0 + s) * n_t;
+                for (int64_t m = 0; m < n_t; ++m)
+                    o[m] = r[m] * inv_n;
+                if (neg_out) {
+                    double *q = neg_out + (s0 + s) * n_t;
+                    q[0] = r[0] * inv_n;
+                    for (int64_t m = 1; m < n_t; ++m)
+                        q[m] = r[n_fft - m] * inv_n;
+                }
+            }
+        }
+        return MDX_OK;
+    };
+    rc = run();
+    fft.destroy();
+    d_in.release();
+    d_pad.release();
+    d_fa.release();
+    d_fb.release();
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,597 @@
+// mdx_rdf.hip — radial pair-distance histogram on gfx950 (MI355X).
+//
+// Carries reference src/mdhelper/analysis/structure.py:32-104 (radial_histogram:
+// capped pair search + exclusion + numpy.histogram) for a batch of frames, i.e.
+// the `counts +=` body of RadialDistributionFunction._single_frame (:750-791).
+//
+// Result contract: for every ordered pair (i, j)
+//     fd  = (float)(x_j - x_i)                       float32 subtract
+//     s   = (double)(float)(1.0 / L) * (double)fd     exact in double
+//     w   = (double)L * (s - round(s))                one rounding
+//     rsq = (w_x*w_x + w_y*w_y) + w_z*w_z             no FMA contraction
+//     d   = sqrt(rsq);   kept when  r0 - eps < d <= r1  and  i/e0 != j/e1
+//     bin = numpy.histogram(d, n_bins, (r0, r1))
+// Bin *decisions* are bit-exact with that contract.  Nothing here computes a
+// double sqrt: sqrt is monotone, so every comparison `d >= edge` is replaced by
+// `rsq >= T(edge)` with T(edge) = the smallest double whose correctly rounded
+// sqrt is >= edge (computed on the host, see make_thresholds()).
+//
+// Three pair kernels share one skeleton (LDS-staged j tile read by broadcast,
+// i atoms in registers, per-wave LDS histograms, one uint64 flush per block):
+//   EXACT   the contract arithmetic on every pair (fp64 VALU bound);
+//   FILTER  float32 distance with a proven error bound; only pairs whose
+//           float32 distance falls within that bound of a bin edge (or of the
+//           range ends) are re-evaluated with the contract arithmetic;
+//   CELL    (mdx_rdf_cell.hip) cell-sorted tiles with culled tile pairs on
+//           top of FILTER.
+//
+// This translation unit is compiled with -ffp-contract=off.
+
+#include "mdx_common.hpp"
+#include "mdx_internal.hpp"
+#include "mdx_rdf_device.hpp"
+
+#include <cmath>
+
+namespace mdx {
+
+// ---------------------------------------------------------------- host helpers
+
+// smallest double t >= 0 with sqrt(t) >= e   (e >= 0; IEEE sqrt is correctly rounded)
+static double thresh_ge(double e)
+{
+    if (!(e > 0.0))
+        return 0.0;
+    double t = e * e;
+    while (std::sqrt(t) >= e && t > 0.0)
+        t = std::nextafter(t, 0.0);
+    while (std::sqrt(t) < e)
+        t = std::nextafter(t, INFINITY);
+    return t;
+}
+
+// smallest double t with sqrt(t) > e
+static double thresh_gt(double e)
+{
+    if (e < 0.0)
+        return 0.0;
+    return thresh_ge(std::nextafter(e, INFINITY));
+}
+
+}  // namespace mdx
+
+using namespace mdx;
+
+// ------------------------------------------------------------------- kernels
+
+// xyz float32[F][n][3] -> float4[F][n_pad] with w = exclusion tag; pads are NaN.
+// Also folds max |coordinate| into *maxabs_bits (non-negative floats order as ints).
+__global__ __launch_bounds__(256) void rdf_pack_kernel(const float *__restrict__ pos,
+                                                       float4 *__restrict__ out, int n, int n_pad,
+                                                       int64_t excl, unsigned *maxabs_bits)
+{
+    const int frame = blockIdx.y;
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    float m = 0.0f;
+    if (a < n_pad) {
+        float4 v;
+        if (a < n) {
+            const float *p = pos + (int64_t(frame) * n + a) * 3;
+            v.x = p[0];
+            v.y = p[1];
+            v.z = p[2];
+            int tag = excl > 0 ? int(int64_t(a) / excl) : a;
+            v.w = __int_as_float(tag);
+            m = fmaxf(fabsf(v.x), fmaxf(fabsf(v.y), fabsf(v.z)));
+        } else {
+            v.x = v.y = v.z = __int_as_float(0x7fc00000);
+            v.w = __int_as_float(-1);
+        }
+        out[int64_t(frame) * n_pad + a] = v;
+    }
+    // NaN/inf coordinates propagate into the bound and force the exact path
+    unsigned bits = __float_as_uint(m == m ? m : __int_as_float(0x7f800000));
+    for (int off = 32; off > 0; off >>= 1)
+        bits = max(bits, (unsigned)__shfl_xor((int)bits, off));
+    if ((threadIdx.x & 63) == 0 && bits)
+        atomicMax(maxabs_bits, bits);
+}
+
+// status bit 0: non-orthorhombic or non-positive box
+__global__ void rdf_check_boxes_kernel(const float *__restrict__ boxes, int64_t n_frames,
+                                       unsigned *status)
+{
+    int64_t f = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (f >= n_frames)
+        return;
+    const float *b = boxes + f * 6;
+    bool ok = b[0] > 0.f && b[1] > 0.f && b[2] > 0.f && b[3] == 90.f && b[4] == 90.f &&
+              b[5] == 90.f;
+    if (!ok)
+        atomicOr(status, 1u);
+}
+
+// GH: the histogram (and the threshold table) stay in global memory — only for bin
+// counts whose tables do not fit the LDS budget.
+template <int MODE, int IPT, bool PBC, bool EXCL, bool GH>
+__global__ __launch_bounds__(256) void rdf_tile_kernel(RdfArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    constexpr int T = 256 * IPT;
+    float4 *sj = reinterpret_cast<float4 *>(smem_raw);                       // [T]
+    double *sT = reinterpret_cast<double *>(smem_raw + sizeof(float4) * T);  // [n_bins+1]
+    unsigned *sh = reinterpret_cast<unsigned *>(sT + (a.n_bins + 1));        // [n_hist][n_bins]
+    __shared__ unsigned s_exact;
+
+    const int tid = threadIdx.x;
+    const int frame = blockIdx.z + a.frame0;
+    const int I = blockIdx.y;
+    int J0 = blockIdx.x * a.chunk;
+    int J1 = min(J0 + a.chunk, a.nt2);
+    if (a.self)
+        J0 = max(J0, I);
+    if (J0 >= J1)
+        return;
+
+    if (!GH) {
+        for (int b = tid; b <= a.n_bins; b += 256)
+            sT[b] = a.thresh[b];
+        for (int b = tid; b < a.n_hist * a.n_bins; b += 256)
+            sh[b] = 0u;
+    }
+    if (tid == 0)
+        s_exact = 0u;
+
+    PairCtx<PBC> ctx;
+    ctx.init(a, frame);
+    unsigned long long *out =
+        a.counts + int64_t((blockIdx.x + 3 * blockIdx.y + 7 * blockIdx.z) % a.n_rep) * a.n_bins;
+    const double *thr = GH ? a.thresh : sT;
+    HistLds hl{sh + (GH ? 0 : ((tid >> 6) % a.n_hist) * a.n_bins)};
+    HistGlobal hg{out};
+
+    float4 pi[IPT];
+    const float4 *P1 = a.p1 + int64_t(frame) * a.n1p + int64_t(I) * T;
+#pragma unroll
+    for (int u = 0; u < IPT; ++u)
+        pi[u] = P1[tid + 256 * u];
+
+    unsigned n_exact = 0;
+    for (int J = J0; J < J1; ++J) {
+        const float4 *P2 = a.p2 + int64_t(frame) * a.n2p + int64_t(J) * T;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < IPT; ++u)
+            sj[tid + 256 * u] = P2[tid + 256 * u];
+        __syncthreads();
+        const unsigned w = (a.self && J != I) ? 2u : 1u;
+#pragma unroll 4
+        for (int jj = 0; jj < T; ++jj) {
+            const float4 pj = sj[jj];
+#pragma unroll
+            for (int u = 0; u < IPT; ++u) {
+                if (MODE == MDX_RDF_ALGO_EXACT_F64) {
+                    if (GH) pair_exact<PBC, EXCL>(ctx, a, thr, hg, pi[u], pj, w);
+                    else pair_exact<PBC, EXCL>(ctx, a, thr, hl, pi[u], pj, w);
+                } else {
+                    if (GH) pair_filter<PBC, EXCL>(ctx, a, thr, hg, pi[u], pj, w, n_exact);
+                    else pair_filter<PBC, EXCL>(ctx, a, thr, hl, pi[u], pj, w, n_exact);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (MODE != MDX_RDF_ALGO_EXACT_F64) {
+        for (int off = 32; off > 0; off >>= 1)
+            n_exact += __shfl_xor((int)n_exact, off);
+        if ((tid & 63) == 0 && n_exact)
+            atomicAdd(&s_exact, n_exact);
+        __syncthreads();
+        if (tid == 0 && s_exact)
+            atomicAdd(a.exact_counter, (unsigned long long)s_exact);
+    }
+    if (!GH) {
+        for (int b = tid; b < a.n_bins; b += 256) {
+            unsigned long long s = 0;
+            for (int h = 0; h < a.n_hist; ++h)
+                s += sh[h * a.n_bins + b];
+            if (s)
+                atomicAdd(out + b, s);
+        }
+    }
+}
+
+__global__ void rdf_reduce_kernel(const unsigned long long *__restrict__ rep, int n_rep, int n_bins,
+                                  unsigned long long *__restrict__ total)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_bins)
+        return;
+    unsigned long long s = 0;
+    for (int r = 0; r < n_rep; ++r)
+        s += rep[int64_t(r) * n_bins + b];
+    total[b] = s;
+}
+
+// --------------------------------------------------------------------- handle
+
+struct mdx_rdf {
+    int dev = 0;
+    hipStream_t stream = nullptr;
+    int n_bins = 0;
+    std::vector<double> edges;
+    std::vector<double> thresh;
+    double t_lo = 0, t_hi = 0;
+    int64_t excl1 = 0, excl2 = 0;
+    int algo = MDX_RDF_ALGO_AUTO;
+    int n_rep = 32;
+    DeviceBuffer d_thresh, d_counts, d_total, d_pack1, d_pack2, d_stage1, d_stage2, d_boxes, d_misc;
+    StreamTimer timer;
+    int64_t pairs_evaluated = 0;
+    bool reduced_global = false;   // counts replica 0 holds an all-reduced total
+};
+
+static int launch_tiles(mdx_rdf *h, RdfArgs &a, int mode, int ipt, bool pbc, bool excl,
+                        int64_t n_frames)
+{
+    const int T = 256 * ipt;
+    // LDS: j tile + thresholds + per-wave histograms
+    size_t base = sizeof(float4) * T + sizeof(double) * (h->n_bins + 1);
+    const size_t lds_budget = 64 * 1024;   // keep >= 2 blocks per CU resident
+    int n_hist = 4;
+    while (n_hist > 1 && base + size_t(n_hist) * h->n_bins * 4 > lds_budget)
+        n_hist >>= 1;
+    size_t lds = base + size_t(n_hist) * h->n_bins * 4;
+    const bool gh = lds > lds_budget;   // tables too large for LDS: global histogram
+    if (gh)
+        lds = sizeof(float4) * T;
+    a.n_hist = n_hist;
+    a.chunk = a.self ? 4 : 8;
+    void (*kern)(RdfArgs) = nullptr;
+#define MDX_PICK(M, I, P, E) \
+    kern = gh ? rdf_tile_kernel<M, I, P, E, true> : rdf_tile_kernel<M, I, P, E, false>
+#define MDX_PICK_PE(M, I)                         \
+    do {                                          \
+        if (pbc && excl) MDX_PICK(M, I, true, true);   \
+        else if (pbc) MDX_PICK(M, I, true, false);     \
+        else if (excl) MDX_PICK(M, I, false, true);    \
+        else MDX_PICK(M, I, false, false);             \
+    } while (0)
+    if (mode == MDX_RDF_ALGO_EXACT_F64) {
+        if (ipt == 1) MDX_PICK_PE(MDX_RDF_ALGO_EXACT_F64, 1);
+        else MDX_PICK_PE(MDX_RDF_ALGO_EXACT_F64, 2);
+    } else {
+        if (ipt == 1) MDX_PICK_PE(MDX_RDF_ALGO_FILTER_F32, 1);
+        else MDX_PICK_PE(MDX_RDF_ALGO_FILTER_F32, 2);
+    }
+#undef MDX_PICK_PE
+#undef MDX_PICK
+    if (lds > 48 * 1024)
+        MDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t ev = h->timer.begin();
+    for (int64_t f0 = 0; f0 < n_frames; f0 += 32768) {
+        int64_t nf = std::min<int64_t>(32768, n_frames - f0);
+        a.frame0 = (int)f0;
+        dim3 grid((unsigned)ceil_div(a.nt2, a.chunk), (unsigned)a.nt1, (unsigned)nf);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, h->stream, a);
+    }
+    h->timer.end(ev);
+    MDX_HIP(hipGetLastError());
+    return MDX_OK;
+}
+
+static int accumulate_device(mdx_rdf *h, const float *d_pos1, int64_t n1, const float *d_pos2,
+                             int64_t n2, const float *d_boxes, int64_t n_frames)
+{
+    if (n_frames == 0 || n1 == 0 || n2 == 0)
+        return MDX_OK;
+    if (h->reduced_global)
+        return fail(MDX_ERR_STATE, "handle holds all-reduced counts; call mdx_rdf_reset() first");
+    const bool same = (d_pos2 == nullptr || (d_pos2 == d_pos1 && n2 == n1));
+    if (d_pos2 == nullptr) {
+        d_pos2 = d_pos1;
+        n2 = n1;
+    }
+    const bool excl = h->excl1 > 0;
+    const bool self = same && (!excl || h->excl1 == h->excl2);
+    MDX_REQUIRE(n1 < (int64_t(1) << 30) && n2 < (int64_t(1) << 30), "too many particles");
+
+    int algo = h->algo == MDX_RDF_ALGO_AUTO ? MDX_RDF_ALGO_FILTER_F32 : h->algo;
+    if (algo == MDX_RDF_ALGO_CELL)
+        algo = MDX_RDF_ALGO_FILTER_F32;   // cell path lives in mdx_rdf_cell.hip (round 1: same tiles)
+    const int ipt = (std::max(n1, n2) >= 2048) ? 2 : 1;
+    const int T = 256 * ipt;
+    const int64_t n1p = ceil_div(n1, T) * T, n2p = ceil_div(n2, T) * T;
+
+    // frames are processed in slabs so the packed copies stay bounded
+    const int64_t slab_bytes = int64_t(1) << 30;
+    int64_t slab = std::max<int64_t>(1, slab_bytes / (int64_t(16) * (n1p + (self ? 0 : n2p))));
+    slab = std::min<int64_t>(slab, 32768);
+    MDX_TRY(h->d_pack1.ensure(size_t(16) * n1p * std::min(slab, n_frames)));
+    if (!self)
+        MDX_TRY(h->d_pack2.ensure(size_t(16) * n2p * std::min(slab, n_frames)));
+
+    unsigned *d_misc = h->d_misc.as<unsigned>();   // [0] maxabs bits, [1] status, [2..3] exact counter
+    if (d_boxes) {
+        hipLaunchKernelGGL(rdf_check_boxes_kernel, dim3((unsigned)ceil_div(n_frames, 256)),
+                           dim3(256), 0, h->stream, d_boxes, n_frames, d_misc + 1);
+    }
+    for (int64_t f0 = 0; f0 < n_frames; f0 += slab) {
+        const int64_t nf = std::min(slab, n_frames - f0);
+        hipLaunchKernelGGL(rdf_pack_kernel, dim3((unsigned)(n1p / 256), (unsigned)nf), dim3(256), 0,
+                           h->stream, d_pos1 + f0 * n1 * 3, h->d_pack1.as<float4>(), (int)n1,
+                           (int)n1p, excl ? h->excl1 : 0, d_misc);
+        if (!self)
+            hipLaunchKernelGGL(rdf_pack_kernel, dim3((unsigned)(n2p / 256), (unsigned)nf), dim3(256),
+                               0, h->stream, d_pos2 + f0 * n2 * 3, h->d_pack2.as<float4>(), (int)n2,
+                               (int)n2p, excl ? h->excl2 : 0, d_misc);
+        RdfArgs a{};
+        a.p1 = h->d_pack1.as<float4>();
+        a.p2 = self ? a.p1 : h->d_pack2.as<float4>();
+        a.n1p = (int)n1p;
+        a.n2p = (int)n2p;
+        a.nt1 = (int)(n1p / T);
+        a.nt2 = (int)(n2p / T);
+        a.self = self ? 1 : 0;
+        a.boxes = d_boxes ? d_boxes + f0 * 6 : nullptr;
+        a.n_bins = h->n_bins;
+        a.thresh = h->d_thresh.as<double>();
+        a.t_lo = h->t_lo;
+        a.t_hi = h->t_hi;
+        a.r0 = h->edges.front();
+        a.r1 = h->edges.back();
+        a.counts = h->d_counts.as<unsigned long long>();
+        a.n_rep = h->n_rep;
+        a.maxabs_bits = d_misc;
+        a.exact_counter = reinterpret_cast<unsigned long long *>(d_misc + 2);
+        MDX_TRY(launch_tiles(h, a, algo, ipt, d_boxes != nullptr, excl, nf));
+    }
+    h->pairs_evaluated += n_frames * n1 * n2;
+    return MDX_OK;
+}
+
+extern "C" {
+
+int mdx_rdf_create(mdx_rdf_t *out, int dev, int n_bins, const double *edges, int64_t excl1,
+                   int64_t excl2, int algo)
+{
+    MDX_REQUIRE(out && edges, "NULL argument");
+    MDX_REQUIRE(n_bins >= 1 && n_bins <= (1 << 20), "n_bins=%d out of range", n_bins);
+    MDX_REQUIRE((excl1 > 0) == (excl2 > 0) && excl1 >= 0 && excl2 >= 0,
+                "exclusion must be two positive integers (or 0, 0 for none)");
+    MDX_REQUIRE(algo >= MDX_RDF_ALGO_AUTO && algo <= MDX_RDF_ALGO_CELL, "unknown algo %d", algo);
+    for (int b = 0; b < n_bins; ++b)
+        MDX_REQUIRE(edges[b] < edges[b + 1], "edges must increase strictly");
+    MDX_REQUIRE(edges[0] >= 0.0 && std::isfinite(edges[n_bins]), "range must be finite and >= 0");
+    MDX_TRY(set_device(dev));
+    mdx_rdf *h = new mdx_rdf();
+    h->dev = dev;
+    h->n_bins = n_bins;
+    h->edges.assign(edges, edges + n_bins + 1);
+    h->excl1 = excl1;
+    h->excl2 = excl2;
+    h->algo = algo;
+    // thresholds in the squared-distance domain
+    h->thresh.resize(n_bins + 1);
+    for (int b = 0; b <= n_bins; ++b)
+        h->thresh[b] = thresh_ge(edges[b]);
+    // capped_distance: d > r0 - eps (structure.py:94); numpy.histogram: r0 <= d <= r1
+    const double min_cut = edges[0] - 2.220446049250313e-16;
+    h->t_lo = std::max(h->thresh[0], thresh_gt(min_cut));
+    h->t_hi = thresh_gt(edges[n_bins]);
+    int rc = MDX_OK;
+    do {
+        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+            rc = fail(MDX_ERR_HIP, "hipStreamCreate failed");
+            break;
+        }
+        h->timer.stream = h->stream;
+        if ((rc = h->d_thresh.ensure(sizeof(double) * (n_bins + 1))) != MDX_OK) break;
+        if ((rc = h->d_counts.ensure(sizeof(uint64_t) * size_t(h->n_rep) * n_bins)) != MDX_OK) break;
+        if ((rc = h->d_total.ensure(sizeof(uint64_t) * n_bins)) != MDX_OK) break;
+        if ((rc = h->d_misc.ensure(64)) != MDX_OK) break;
+        if (hipMemcpy(h->d_thresh.ptr, h->thresh.data(), sizeof(double) * (n_bins + 1),
+                      hipMemcpyHostToDevice) != hipSuccess) {
+            rc = fail(MDX_ERR_HIP, "threshold upload failed");
+            break;
+        }
+    } while (0);
+    if (rc != MDX_OK) {
+        mdx_rdf_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return mdx_rdf_reset(h);
+}
+
+int mdx_rdf_destroy(mdx_rdf_t h)
+{
+    if (!h)
+        return MDX_OK;
+    (void)hipSetDevice(h->dev);
+    if (h->stream)
+        (void)hipStreamSynchronize(h->stream);
+    h->timer.destroy();
+    for (DeviceBuffer *b : {&h->d_thresh, &h->d_counts, &h->d_total, &h->d_pack1, &h->d_pack2,
+                            &h->d_stage1, &h->d_stage2, &h->d_boxes, &h->d_misc})
+        b->release();
+    if (h->stream)
+        (void)hipStreamDestroy(h->stream);
+    delete h;
+    return MDX_OK;
+}
+
+int mdx_rdf_reset(mdx_rdf_t h)
+{
+    MDX_REQUIRE(h, "NULL handle");
+    MDX_TRY(set_device(h->dev));
+    MDX_HIP(hipStreamSynchronize(h->stream));
+    MDX_HIP(hipMemsetAsync(h->d_counts.ptr, 0, sizeof(uint64_t) * size_t(h->n_rep) * h->n_bins,
+                           h->stream));
+    MDX_HIP(hipMemsetAsync(h->d_misc.ptr, 0, 64, h->stream));
+    MDX_HIP(hipStreamSynchronize(h->stream));
+    h->timer.reset();
+    h->pairs_evaluated = 0;
+    h->reduced_global = false;
+    return MDX_OK;
+}
+
+int mdx_rdf_accumulate_device(mdx_rdf_t h, const float *d_pos1, int64_t n1, const float *d_pos2,
+                              int64_t n2, const float *d_boxes, int64_t n_frames)
+{
+    MDX_REQUIRE(h && d_pos1, "NULL argument");
+    MDX_REQUIRE(n1 >= 0 && n2 >= 0 && n_frames >= 0, "negative size");
+    MDX_TRY(set_device(h->dev));
+    return accumulate_device(h, d_pos1, n1, d_pos2, n2, d_boxes, n_frames);
+}
+
+int mdx_rdf_accumulate(mdx_rdf_t h, const float *pos1, int64_t n1, const float *pos2, int64_t n2,
+                       const float *boxes, int64_t n_frames)
+{
+    MDX_REQUIRE(h && pos1, "NULL argument");
+    MDX_REQUIRE(n1 >= 0 && n2 >= 0 && n_frames >= 0, "negative size");
+    MDX_TRY(set_device(h->dev));
+    if (n_frames == 0 || n1 == 0)
+        return MDX_OK;
+    const bool same = (pos2 == nullptr || (pos2 == pos1 && n2 == n1));
+    if (pos2 == nullptr)
+        n2 = n1;
+    if (n2 == 0)
+        return MDX_OK;
+    if (boxes) {
+        for (int64_t f = 0; f < n_frames; ++f) {
+            const float *b = boxes + 6 * f;
+            if (!(b[3] == 90.f && b[4] == 90.f && b[5] == 90.f))
+                return fail(MDX_ERR_UNSUPPORTED,
+                            "frame %lld: only orthorhombic boxes are supported "
+                            "(angles %.4g %.4g %.4g)", (long long)f, b[3], b[4], b[5]);
+            MDX_REQUIRE(b[0] > 0.f && b[1] > 0.f && b[2] > 0.f,
+                        "frame %lld: box lengths must be positive", (long long)f);
+        }
+    }
+    // stage through HBM in slabs of <= 256 MiB per group
+    const int64_t per_frame = 12 * std::max(n1, n2);
+    const int64_t slab = std::max<int64_t>(1, (int64_t(256) << 20) / per_frame);
+    for (int64_t f0 = 0; f0 < n_frames; f0 += slab) {
+        const int64_t nf = std::min(slab, n_frames - f0);
+        MDX_TRY(h->d_stage1.ensure(size_t(12) * n1 * nf));
+        MDX_HIP(hipMemcpyAsync(h->d_stage1.ptr, pos1 + f0 * n1 * 3, size_t(12) * n1 * nf,
+                               hipMemcpyHostToDevice, h->stream));
+        const float *d2 = nullptr;
+        if (!same) {
+            MDX_TRY(h->d_stage2.ensure(size_t(12) * n2 * nf));
+            MDX_HIP(hipMemcpyAsync(h->d_stage2.ptr, pos2 + f0 * n2 * 3, size_t(12) * n2 * nf,
+                                   hipMemcpyHostToDevice, h->stream));
+            d2 = h->d_stage2.as<float>();
+        }
+        const float *db = nullptr;
+        if (boxes) {
+            MDX_TRY(h->d_boxes.ensure(size_t(24) * nf));
+            MDX_HIP(hipMemcpyAsync(h->d_boxes.ptr, boxes + f0 * 6, size_t(24) * nf,
+                                   hipMemcpyHostToDevice, h->stream));
+            db = h->d_boxes.as<float>();
+        }
+        MDX_TRY(accumulate_device(h, h->d_stage1.as<float>(), n1, d2, n2, db, nf));
+        // the staging buffers are reused by the next slab
+        MDX_HIP(hipStreamSynchronize(h->stream));
+    }
+    return MDX_OK;
+}
+
+int mdx_rdf_synchronize(mdx_rdf_t h)
+{
+    MDX_REQUIRE(h, "NULL handle");
+    MDX_TRY(set_device(h->dev));
+    MDX_HIP(hipStreamSynchronize(h->stream));
+    h->timer.collect();
+    unsigned misc[4] = {0, 0, 0, 0};
+    MDX_HIP(hipMemcpy(misc, h->d_misc.ptr, sizeof(misc), hipMemcpyDeviceToHost));
+    if (misc[1] & 1u)
+        return fail(MDX_ERR_UNSUPPORTED,
+                    "a frame has a non-orthorhombic or non-positive box; counts are invalid");
+    return MDX_OK;
+}
+
+static int reduce_to_total(mdx_rdf *h)
+{
+    hipLaunchKernelGGL(rdf_reduce_kernel, dim3((unsigned)ceil_div(h->n_bins, 256)), dim3(256), 0,
+                       h->stream, h->d_counts.as<unsigned long long>(), h->n_rep, h->n_bins,
+                       h->d_total.as<unsigned long long>());
+    MDX_HIP(hipGetLastError());
+    return MDX_OK;
+}
+
+int mdx_rdf_counts(mdx_rdf_t h, int64_t *counts)
+{
+    MDX_REQUIRE(h && counts, "NULL argument");
+    MDX_TRY(set_device(h->dev));
+    MDX_TRY(reduce_to_total(h));
+    MDX_TRY(mdx_rdf_synchronize(h));
+    MDX_HIP(hipMemcpy(counts, h->d_total.ptr, sizeof(int64_t) * h->n_bins, hipMemcpyDeviceToHost));
+    return MDX_OK;
+}
+
+int mdx_rdf_stats(mdx_rdf_t h, int64_t *launches, double *kernel_ms, int64_t *pairs_evaluated,
+                  int64_t *pairs_exact)
+{
+    MDX_REQUIRE(h, "NULL handle");
+    MDX_TRY(set_device(h->dev));
+    MDX_HIP(hipStreamSynchronize(h->stream));
+    h->timer.collect();
+    if (launches) *launches = h->timer.launches;
+    if (kernel_ms) *kernel_ms = h->timer.total_ms;
+    if (pairs_evaluated) *pairs_evaluated = h->pairs_evaluated;
+    if (pairs_exact) {
+        unsigned long long v = 0;
+        MDX_HIP(hipMemcpy(&v, h->d_misc.as<unsigned>() + 2, 8, hipMemcpyDeviceToHost));
+        *pairs_exact = (int64_t)v;
+    }
+    return MDX_OK;
+}
+
+int mdx_rdf_enable_timing(mdx_rdf_t h, int on)
+{
+    MDX_REQUIRE(h, "NULL handle");
+    h->timer.enabled = on != 0;
+    return MDX_OK;
+}
+
+// used by mdx_comm.hip
+int mdx_rdf_internal_total(mdx_rdf_t h, unsigned long long **d_total, hipStream_t *stream)
+{
+    MDX_TRY(set_device(h->dev));
+    MDX_TRY(reduce_to_total(h));
+    *d_total = h->d_total.as<unsigned long long>();
+    *stream = h->stream;
+    return MDX_OK;
+}
+
+int mdx_rdf_internal_nbins(mdx_rdf_t h) { return h->n_bins; }
+
+int mdx_rdf_internal_adopt_total(mdx_rdf_t h)
+{
+    // replica 0 <- all-reduced total, other replicas <- 0
+    MDX_HIP(hipMemsetAsync(h->d_counts.ptr, 0, sizeof(uint64_t) * size_t(h->n_rep) * h->n_bins,
+                           h->stream));
+    MDX_HIP(hipMemcpyAsync(h->d_counts.ptr, h->d_total.ptr, sizeof(uint64_t) * h->n_bins,
+                           hipMemcpyDeviceToDevice, h->stream));
+    h->reduced_global = true;
+    return MDX_OK;
+}
+
+int mdx_radial_histogram(int dev, const float *pos1, int64_t n1, const float *pos2, int64_t n2,
+                         int n_bins, const double *edges, const float dims[6], int64_t excl1,
+                         int64_t excl2, int64_t *counts)
+{
+    MDX_REQUIRE(counts, "counts is NULL");
+    mdx_rdf_t h = nullptr;
+    MDX_TRY(mdx_rdf_create(&h, dev, n_bins, edges, excl1, excl2, MDX_RDF_ALGO_AUTO));
+    int rc = mdx_rdf_accumulate(h, pos1, n1, pos2, n2, dims, 1);
+    if (rc == MDX_OK)
+        rc = mdx_rdf_counts(h, counts);
+    mdx_rdf_destroy(h);
+    return rc;
+}
+
+}  // extern "C"

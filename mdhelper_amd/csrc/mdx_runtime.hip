@@ -1,0 +1,293 @@
+// mdx_runtime.hip — runtime entry points of libmdx.so: errors, device memory,
+// stream timers and the synthetic-trajectory generator used by bench.py/tests.
+#include "mdx_common.hpp"
+
+namespace mdx {
+
+char *error_buffer()
+{
+    static thread_local char buf[1024] = "";
+    return buf;
+}
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(error_buffer(), 1024, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int set_device(int dev)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return fail(MDX_ERR_NO_DEVICE,
+                    "no HIP device is visible (%s); libmdx has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (dev < 0 || dev >= n)
+        return fail(MDX_ERR_NO_DEVICE, "device %d out of range [0, %d)", dev, n);
+    MDX_HIP(hipSetDevice(dev));
+    return MDX_OK;
+}
+
+int DeviceBuffer::ensure(size_t need)
+{
+    if (need <= bytes)
+        return MDX_OK;
+    release();
+    // round up so a slowly growing batch does not reallocate every call
+    size_t want = (need + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
+    MDX_HIP(hipMalloc(&ptr, want));
+    bytes = want;
+    return MDX_OK;
+}
+
+void DeviceBuffer::release()
+{
+    if (ptr)
+        (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+}
+
+hipEvent_t StreamTimer::begin()
+{
+    if (!enabled)
+        return nullptr;
+    hipEvent_t ev;
+    if (!pool.empty()) {
+        ev = pool.back();
+        pool.pop_back();
+    } else if (hipEventCreate(&ev) != hipSuccess) {
+        return nullptr;
+    }
+    (void)hipEventRecord(ev, stream);
+    return ev;
+}
+
+void StreamTimer::end(hipEvent_t start)
+{
+    ++launches;
+    if (!enabled || !start)
+        return;
+    hipEvent_t ev;
+    if (!pool.empty()) {
+        ev = pool.back();
+        pool.pop_back();
+    } else if (hipEventCreate(&ev) != hipSuccess) {
+        pool.push_back(start);
+        return;
+    }
+    (void)hipEventRecord(ev, stream);
+    pending.emplace_back(start, ev);
+}
+
+void StreamTimer::collect()
+{
+    for (auto &p : pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess)
+            total_ms += ms;
+        pool.push_back(p.first);
+        pool.push_back(p.second);
+    }
+    pending.clear();
+}
+
+void StreamTimer::reset()
+{
+    collect();
+    total_ms = 0.0;
+    launches = 0;
+}
+
+void StreamTimer::destroy()
+{
+    collect();
+    for (auto ev : pool)
+        (void)hipEventDestroy(ev);
+    pool.clear();
+}
+
+}  // namespace mdx
+
+using namespace mdx;
+
+// ----------------------------------------------------------------------------
+// Philox-4x32-10 (Salmon et al., SC'11) keyed by (seed) with counter (atom, frame)
+// ----------------------------------------------------------------------------
+__device__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
+{
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+        uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+        uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += W0;
+        k1 += W1;
+    }
+}
+
+__device__ inline float u01(uint32_t x) { return (float(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void synth_walk_kernel(OutT *__restrict__ out, int64_t n_frames,
+                                                         int64_t n_atoms, float lx, float ly,
+                                                         float lz, float sigma, uint32_t k0,
+                                                         uint32_t k1, int wrap)
+{
+    int64_t atom = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (atom >= n_atoms)
+        return;
+    const float L[3] = {lx, ly, lz};
+    float x[3];
+    uint32_t c[4] = {uint32_t(atom), uint32_t(atom >> 32), 0u, 0x5eedu};
+    philox4x32_10(c, k0, k1);
+    for (int k = 0; k < 3; ++k)
+        x[k] = u01(c[k]) * L[k];
+    for (int64_t f = 0; f < n_frames; ++f) {
+        if (f > 0) {
+            uint32_t d[4] = {uint32_t(atom), uint32_t(atom >> 32), uint32_t(f), uint32_t(f >> 32)};
+            philox4x32_10(d, k0, k1);
+            // Box-Muller: two normals from (d0,d1), one from (d2,d3)
+            float r0 = sqrtf(-2.0f * __logf(u01(d[0])));
+            float r1 = sqrtf(-2.0f * __logf(u01(d[2])));
+            float s0, c0, s1, c1;
+            __sincosf(6.28318530718f * u01(d[1]), &s0, &c0);
+            __sincosf(6.28318530718f * u01(d[3]), &s1, &c1);
+            float g[3] = {r0 * c0, r0 * s0, r1 * c1};
+            (void)s1;
+            for (int k = 0; k < 3; ++k) {
+                float v = x[k] + sigma * g[k];
+                if (wrap) {
+                    v -= L[k] * floorf(v / L[k]);
+                    if (!(v < L[k]))
+                        v -= L[k];
+                    if (v < 0.0f)
+                        v = 0.0f;
+                }
+                x[k] = v;
+            }
+        }
+        OutT *o = out + (f * n_atoms + atom) * 3;
+        o[0] = (OutT)x[0];
+        o[1] = (OutT)x[1];
+        o[2] = (OutT)x[2];
+    }
+}
+
+extern "C" {
+
+const char *mdx_last_error(void) { return error_buffer(); }
+
+int mdx_version(void) { return MDX_VERSION; }
+
+int mdx_device_count(int *count)
+{
+    MDX_REQUIRE(count != nullptr, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    *count = (e == hipSuccess) ? n : 0;
+    return MDX_OK;
+}
+
+int mdx_device_info(int dev, char *name, size_t name_len, int *compute_units, size_t *hbm_bytes,
+                    size_t *hbm_free_bytes)
+{
+    MDX_TRY(set_device(dev));
+    hipDeviceProp_t prop;
+    MDX_HIP(hipGetDeviceProperties(&prop, dev));
+    if (name && name_len) {
+        snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (compute_units)
+        *compute_units = prop.multiProcessorCount;
+    size_t free_b = 0, total_b = 0;
+    MDX_HIP(hipMemGetInfo(&free_b, &total_b));
+    if (hbm_bytes)
+        *hbm_bytes = total_b;
+    if (hbm_free_bytes)
+        *hbm_free_bytes = free_b;
+    return MDX_OK;
+}
+
+int mdx_malloc(int dev, size_t bytes, void **dptr)
+{
+    MDX_REQUIRE(dptr != nullptr, "dptr is NULL");
+    MDX_TRY(set_device(dev));
+    MDX_HIP(hipMalloc(dptr, bytes ? bytes : 1));
+    return MDX_OK;
+}
+
+int mdx_free(int dev, void *dptr)
+{
+    MDX_TRY(set_device(dev));
+    if (dptr)
+        MDX_HIP(hipFree(dptr));
+    return MDX_OK;
+}
+
+int mdx_memcpy_h2d(int dev, void *dst, const void *src, size_t bytes)
+{
+    MDX_TRY(set_device(dev));
+    MDX_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return MDX_OK;
+}
+
+int mdx_memcpy_d2h(int dev, void *dst, const void *src, size_t bytes)
+{
+    MDX_TRY(set_device(dev));
+    MDX_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return MDX_OK;
+}
+
+int mdx_memset(int dev, void *dst, int value, size_t bytes)
+{
+    MDX_TRY(set_device(dev));
+    MDX_HIP(hipMemset(dst, value, bytes));
+    return MDX_OK;
+}
+
+int mdx_device_synchronize(int dev)
+{
+    MDX_TRY(set_device(dev));
+    MDX_HIP(hipDeviceSynchronize());
+    return MDX_OK;
+}
+
+int mdx_synth_random_walk(int dev, float *d_out, int64_t n_frames, int64_t n_atoms,
+                          const float box_lengths[3], float sigma, uint64_t seed, int wrap)
+{
+    MDX_REQUIRE(d_out && box_lengths, "NULL argument");
+    MDX_REQUIRE(n_frames > 0 && n_atoms > 0, "n_frames and n_atoms must be positive");
+    MDX_TRY(set_device(dev));
+    dim3 block(256), grid((unsigned)ceil_div(n_atoms, 256));
+    hipLaunchKernelGGL(synth_walk_kernel<float>, grid, block, 0, 0, d_out, n_frames, n_atoms,
+                       box_lengths[0], box_lengths[1], box_lengths[2], sigma, uint32_t(seed),
+                       uint32_t(seed >> 32), wrap);
+    MDX_HIP(hipGetLastError());
+    MDX_HIP(hipDeviceSynchronize());
+    return MDX_OK;
+}
+
+int mdx_synth_random_walk_f64(int dev, double *d_out, int64_t n_frames, int64_t n_atoms,
+                              const float box_lengths[3], float sigma, uint64_t seed)
+{
+    MDX_REQUIRE(d_out && box_lengths, "NULL argument");
+    MDX_REQUIRE(n_frames > 0 && n_atoms > 0, "n_frames and n_atoms must be positive");
+    MDX_TRY(set_device(dev));
+    dim3 block(256), grid((unsigned)ceil_div(n_atoms, 256));
+    hipLaunchKernelGGL(synth_walk_kernel<double>, grid, block, 0, 0, d_out, n_frames, n_atoms,
+                       box_lengths[0], box_lengths[1], box_lengths[2], sigma, uint32_t(seed),
+                       uint32_t(seed >> 32), 0);
+    MDX_HIP(hipGetLastError());
+    MDX_HIP(hipDeviceSynchronize());
+    return MDX_OK;
+}
+
+}  // extern "C"

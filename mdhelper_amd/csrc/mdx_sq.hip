@@ -1,0 +1,444 @@
+// mdx_sq.hip — static / partial structure factor on gfx950 (MI355X).
+//
+// Carries StructureFactor._single_frame (reference
+// src/mdhelper/analysis/structure.py:1481-1527) and the Numba kernels under it
+// (src/mdhelper/algorithm/accelerated.py:81-165 delta_fourier_transform_sum*,
+// :167-247 inner*, :249-321 pythagorean_trigonometric_identity*):
+//
+//     rho_g(q) = sum_{j in group g} exp(i q . r_j)                       (fp64)
+//     ssf[p](q) += |rho_j|^2            for a pair p = (j, j)
+//               += 2 Re(rho_j rho_k^*)  for a pair p = (j, k), j != k
+//               += |sum_g rho_g|^2      for mode=None, p = (None, None)
+//
+// The reference's form="exp" and form="trig" are the same numbers (cos/sin sums);
+// one fused kernel serves both and the N_q x N table of q.r that the "trig" form
+// materialises (134 MB at 512 x 32768) never exists.
+//
+// Kernel A (sq_rho_kernel): one thread owns QPT wavevectors in registers, the
+// group's particles stream through LDS and are read by broadcast; phase q.r and
+// sincos are fp64 (a float32 phase is off by ~1e-5 rad at |q.r| ~ 200, which
+// breaks the 1e-6 parity bar).  Bound: fp64 VALU (≈40 fp64 instr per (q, r)).
+// Kernel B (sq_pair_kernel): sums the particle splits in a fixed order, forms the
+// pair products and accumulates over the frames of the slab in frame order, so
+// results are run-to-run reproducible.
+#include "mdx_common.hpp"
+#include "mdx_internal.hpp"
+
+using namespace mdx;
+
+namespace {
+
+constexpr int SQ_THREADS = 256;
+constexpr int SQ_QPT = 2;            // wavevectors per thread
+constexpr int SQ_QPB = SQ_THREADS * SQ_QPT;
+constexpr int SQ_TILE = 1024;        // particles per LDS stage
+
+// sin and cos of x in fp64: Cody-Waite reduction by pi/2 (three-term, FMA), then the
+// fdlibm minimax kernels on [-pi/4, pi/4].  |x| up to ~1e9 keeps ~1e-15 absolute error.
+__device__ inline void sincos_f64(double x, double &s, double &c)
+{
+    const double TWO_OVER_PI = 6.36619772367581382433e-01;
+    const double PIO2_1 = 1.57079632679489655800e+00;   // pi/2 rounded to double
+    const double PIO2_2 = 6.12323399573676603587e-17;   // pi/2 - PIO2_1
+    const double PIO2_3 = -1.49738490485916983e-33;     // next 53 bits
+    double kd = rint(x * TWO_OVER_PI);
+    double r = fma(-kd, PIO2_1, x);
+    r = fma(-kd, PIO2_2, r);
+    r = fma(-kd, PIO2_3, r);
+    int q = (int)(long long)kd;
+    double z = r * r;
+    // sin kernel
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    double ps = fma(z, fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2), S1);
+    double sn = fma(z * r, ps, r);
+    // cos kernel
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double pc = fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1);
+    double cs = fma(z * z, pc, fma(-0.5, z, 1.0));
+    // quadrant
+    double so = (q & 1) ? cs : sn;
+    double co = (q & 1) ? sn : cs;
+    s = (q & 2) ? -so : so;
+    c = ((q + 1) & 2) ? -co : co;
+}
+
+// rho[frame][group][split][q] (re, im)
+__global__ __launch_bounds__(SQ_THREADS) void sq_rho_kernel(
+    const float *__restrict__ pos, int64_t n_atoms, const double *__restrict__ qv, int n_q,
+    const int64_t *__restrict__ group_offsets, int n_groups, int n_split,
+    double2 *__restrict__ rho)
+{
+    __shared__ float sx[SQ_TILE], sy[SQ_TILE], sz[SQ_TILE];
+    const int tid = threadIdx.x;
+    const int qb = blockIdx.x;
+    const int g = blockIdx.y / n_split, sp = blockIdx.y % n_split;
+    const int frame = blockIdx.z;
+
+    double q0[SQ_QPT], q1[SQ_QPT], q2[SQ_QPT], ac[SQ_QPT], as[SQ_QPT];
+#pragma unroll
+    for (int u = 0; u < SQ_QPT; ++u) {
+        int qi = qb * SQ_QPB + u * SQ_THREADS + tid;
+        bool ok = qi < n_q;
+        q0[u] = ok ? qv[3 * int64_t(qi) + 0] : 0.0;
+        q1[u] = ok ? qv[3 * int64_t(qi) + 1] : 0.0;
+        q2[u] = ok ? qv[3 * int64_t(qi) + 2] : 0.0;
+        ac[u] = 0.0;
+        as[u] = 0.0;
+    }
+    const int64_t g_lo = group_offsets[g], g_hi = group_offsets[g + 1];
+    const int64_t per = (g_hi - g_lo + n_split - 1) / n_split;
+    const int64_t lo = g_lo + sp * per, hi = min(g_hi, lo + per);
+    const float *P = pos + int64_t(frame) * n_atoms * 3;
+
+    for (int64_t base = lo; base < hi; base += SQ_TILE) {
+        const int cnt = (int)min<int64_t>(SQ_TILE, hi - base);
+        __syncthreads();
+        for (int e = tid; e < cnt * 3; e += SQ_THREADS) {
+            float v = P[base * 3 + e];
+            int a = e / 3, k = e - 3 * a;
+            (k == 0 ? sx : k == 1 ? sy : sz)[a] = v;
+        }
+        __syncthreads();
+        for (int a = 0; a < cnt; ++a) {
+            const double x = (double)sx[a], y = (double)sy[a], z = (double)sz[a];
+#pragma unroll
+            for (int u = 0; u < SQ_QPT; ++u) {
+                // a[0]*b[0] + a[1]*b[1] + a[2]*b[2]   (accelerated.py:43; fastmath there)
+                double ph = fma(q2[u], z, fma(q1[u], y, q0[u] * x));
+                double s, c;
+                sincos_f64(ph, s, c);
+                ac[u] += c;
+                as[u] += s;
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < SQ_QPT; ++u) {
+        int qi = qb * SQ_QPB + u * SQ_THREADS + tid;
+        if (qi < n_q)
+            rho[((int64_t(frame) * n_groups + g) * n_split + sp) * n_q + qi] =
+                make_double2(ac[u], as[u]);
+    }
+}
+
+__global__ __launch_bounds__(256) void sq_pair_kernel(const double2 *__restrict__ rho, int n_frames,
+                                                      int n_groups, int n_split, int n_q,
+                                                      const int *__restrict__ pairs, int n_pairs,
+                                                      double *__restrict__ acc)
+{
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    const int p = blockIdx.y;
+    if (qi >= n_q)
+        return;
+    const int j = pairs[2 * p], k = pairs[2 * p + 1];
+    double sum = 0.0;
+    for (int f = 0; f < n_frames; ++f) {
+        const double2 *R = rho + int64_t(f) * n_groups * n_split * n_q;
+        auto group_rho = [&](int g) {
+            double2 r = make_double2(0.0, 0.0);
+            for (int s = 0; s < n_split; ++s) {
+                double2 v = R[(int64_t(g) * n_split + s) * n_q + qi];
+                r.x += v.x;
+                r.y += v.y;
+            }
+            return r;
+        };
+        if (j < 0) {
+            double2 r = make_double2(0.0, 0.0);
+            for (int g = 0; g < n_groups; ++g) {
+                double2 v = group_rho(g);
+                r.x += v.x;
+                r.y += v.y;
+            }
+            sum += r.x * r.x + r.y * r.y;
+        } else if (j == k) {
+            double2 r = group_rho(j);
+            sum += r.x * r.x + r.y * r.y;
+        } else {
+            double2 a = group_rho(j), b = group_rho(k);
+            sum += 2.0 * (a.x * b.x + a.y * b.y);
+        }
+    }
+    acc[int64_t(p) * n_q + qi] += sum;
+}
+
+// float64 positions -> F[q] for the function-level drop-in (one pseudo-frame, one group)
+__global__ __launch_bounds__(SQ_THREADS) void sq_fourier_sum_f64_kernel(
+    const double *__restrict__ pos, int64_t n, const double *__restrict__ qv, int n_q, int n_split,
+    double2 *__restrict__ part)
+{
+    __shared__ double sx[512], sy[512], sz[512];
+    const int tid = threadIdx.x;
+    const int qi = blockIdx.x * SQ_THREADS + tid;
+    const int sp = blockIdx.y;
+    const bool ok = qi < n_q;
+    const double q0 = ok ? qv[3 * int64_t(qi)] : 0.0, q1 = ok ? qv[3 * int64_t(qi) + 1] : 0.0,
+                 q2 = ok ? qv[3 * int64_t(qi) + 2] : 0.0;
+    const int64_t per = (n + n_split - 1) / n_split;
+    const int64_t lo = sp * per, hi = min(n, lo + per);
+    double ac = 0.0, as = 0.0;
+    for (int64_t base = lo; base < hi; base += 512) {
+        const int cnt = (int)min<int64_t>(512, hi - base);
+        __syncthreads();
+        for (int e = tid; e < cnt * 3; e += SQ_THREADS) {
+            double v = pos[base * 3 + e];
+            int a = e / 3, k = e - 3 * a;
+            (k == 0 ? sx : k == 1 ? sy : sz)[a] = v;
+        }
+        __syncthreads();
+        for (int a = 0; a < cnt; ++a) {
+            double ph = fma(q2, sz[a], fma(q1, sy[a], q0 * sx[a]));
+            double s, c;
+            sincos_f64(ph, s, c);
+            ac += c;
+            as += s;
+        }
+    }
+    if (ok)
+        part[int64_t(sp) * n_q + qi] = make_double2(ac, as);
+}
+
+}  // namespace
+
+struct mdx_sq {
+    int dev = 0;
+    hipStream_t stream = nullptr;
+    int64_t n_q = 0;
+    int n_groups = 0, n_pairs = 0;
+    int64_t n_total = 0;
+    std::vector<int64_t> offsets;
+    DeviceBuffer d_q, d_offsets, d_pairs, d_acc, d_rho, d_stage;
+    StreamTimer timer;
+};
+
+static int sq_accumulate_device(mdx_sq *h, const float *d_pos, int64_t n, int64_t n_frames)
+{
+    if (n_frames == 0)
+        return MDX_OK;
+    MDX_REQUIRE(n >= h->n_total, "positions hold %lld particles but the groups span %lld",
+                (long long)n, (long long)h->n_total);
+    const int qblocks = (int)ceil_div(h->n_q, SQ_QPB);
+    // split the particles when frames x q-blocks x groups alone would not fill 256 CUs
+    int64_t max_group = 0;
+    for (int g = 0; g < h->n_groups; ++g)
+        max_group = std::max(max_group, h->offsets[g + 1] - h->offsets[g]);
+    int n_split = 1;
+    while (int64_t(qblocks) * h->n_groups * n_split * std::min<int64_t>(n_frames, 4096) < 1024 &&
+           n_split < 64 && max_group / (n_split * 2) >= 2 * SQ_TILE)
+        n_split *= 2;
+    const int64_t rho_per_frame = int64_t(h->n_groups) * n_split * h->n_q * 16;
+    int64_t slab = std::max<int64_t>(1, (int64_t(512) << 20) / rho_per_frame);
+    slab = std::min<int64_t>(std::min<int64_t>(slab, 32768), n_frames);
+    MDX_TRY(h->d_rho.ensure(size_t(rho_per_frame) * slab));
+    MDX_REQUIRE(int64_t(h->n_groups) * n_split <= 65535, "too many groups");
+    hipEvent_t ev = h->timer.begin();
+    for (int64_t f0 = 0; f0 < n_frames; f0 += slab) {
+        const int64_t nf = std::min(slab, n_frames - f0);
+        hipLaunchKernelGGL(sq_rho_kernel, dim3(qblocks, h->n_groups * n_split, (unsigned)nf),
+                           dim3(SQ_THREADS), 0, h->stream, d_pos + f0 * n * 3, n,
+                           h->d_q.as<double>(), (int)h->n_q, h->d_offsets.as<int64_t>(),
+                           h->n_groups, n_split, h->d_rho.as<double2>());
+        hipLaunchKernelGGL(sq_pair_kernel, dim3((unsigned)ceil_div(h->n_q, 256), h->n_pairs),
+                           dim3(256), 0, h->stream, h->d_rho.as<double2>(), (int)nf, h->n_groups,
+                           n_split, (int)h->n_q, h->d_pairs.as<int>(), h->n_pairs,
+                           h->d_acc.as<double>());
+    }
+    h->timer.end(ev);
+    MDX_HIP(hipGetLastError());
+    return MDX_OK;
+}
+
+extern "C" {
+
+int mdx_sq_create(mdx_sq_t *out, int dev, const double *wavevectors, int64_t n_q,
+                  const int64_t *group_offsets, int n_groups, const int32_t *pairs, int n_pairs)
+{
+    MDX_REQUIRE(out && wavevectors && group_offsets && pairs, "NULL argument");
+    MDX_REQUIRE(n_q >= 1 && n_q < (int64_t(1) << 30), "n_q out of range");
+    MDX_REQUIRE(n_groups >= 1 && n_groups <= 1024, "n_groups out of range");
+    MDX_REQUIRE(n_pairs >= 1 && n_pairs <= 65535, "n_pairs out of range");
+    MDX_REQUIRE(group_offsets[0] >= 0, "group offsets must be non-negative");
+    for (int g = 0; g < n_groups; ++g)
+        MDX_REQUIRE(group_offsets[g + 1] >= group_offsets[g], "group offsets must not decrease");
+    for (int p = 0; p < n_pairs; ++p) {
+        int j = pairs[2 * p], k = pairs[2 * p + 1];
+        MDX_REQUIRE((j == -1 && k == -1) || (j >= 0 && j < n_groups && k >= 0 && k < n_groups),
+                    "pair %d = (%d, %d) is not a pair of groups", p, j, k);
+    }
+    MDX_TRY(set_device(dev));
+    mdx_sq *h = new mdx_sq();
+    h->dev = dev;
+    h->n_q = n_q;
+    h->n_groups = n_groups;
+    h->n_pairs = n_pairs;
+    h->offsets.assign(group_offsets, group_offsets + n_groups + 1);
+    h->n_total = group_offsets[n_groups];
+    int rc = MDX_OK;
+    do {
+        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+            rc = fail(MDX_ERR_HIP, "hipStreamCreate failed");
+            break;
+        }
+        h->timer.stream = h->stream;
+        if ((rc = h->d_q.ensure(size_t(24) * n_q)) != MDX_OK) break;
+        if ((rc = h->d_offsets.ensure(size_t(8) * (n_groups + 1))) != MDX_OK) break;
+        if ((rc = h->d_pairs.ensure(size_t(8) * n_pairs)) != MDX_OK) break;
+        if ((rc = h->d_acc.ensure(size_t(8) * n_pairs * n_q)) != MDX_OK) break;
+        if (hipMemcpy(h->d_q.ptr, wavevectors, size_t(24) * n_q, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(h->d_offsets.ptr, group_offsets, size_t(8) * (n_groups + 1),
+                      hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(h->d_pairs.ptr, pairs, size_t(8) * n_pairs, hipMemcpyHostToDevice) != hipSuccess) {
+            rc = fail(MDX_ERR_HIP, "upload failed");
+            break;
+        }
+    } while (0);
+    if (rc != MDX_OK) {
+        mdx_sq_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return mdx_sq_reset(h);
+}
+
+int mdx_sq_destroy(mdx_sq_t h)
+{
+    if (!h)
+        return MDX_OK;
+    (void)hipSetDevice(h->dev);
+    if (h->stream)
+        (void)hipStreamSynchronize(h->stream);
+    h->timer.destroy();
+    for (DeviceBuffer *b : {&h->d_q, &h->d_offsets, &h->d_pairs, &h->d_acc, &h->d_rho, &h->d_stage})
+        b->release();
+    if (h->stream)
+        (void)hipStreamDestroy(h->stream);
+    delete h;
+    return MDX_OK;
+}
+
+int mdx_sq_reset(mdx_sq_t h)
+{
+    MDX_REQUIRE(h, "NULL handle");
+    MDX_TRY(set_device(h->dev));
+    MDX_HIP(hipMemsetAsync(h->d_acc.ptr, 0, size_t(8) * h->n_pairs * h->n_q, h->stream));
+    MDX_HIP(hipStreamSynchronize(h->stream));
+    h->timer.reset();
+    return MDX_OK;
+}
+
+int mdx_sq_accumulate_device(mdx_sq_t h, const float *d_pos, int64_t n, int64_t n_frames)
+{
+    MDX_REQUIRE(h && d_pos, "NULL argument");
+    MDX_REQUIRE(n > 0 && n_frames >= 0, "bad size");
+    MDX_TRY(set_device(h->dev));
+    return sq_accumulate_device(h, d_pos, n, n_frames);
+}
+
+int mdx_sq_accumulate(mdx_sq_t h, const float *pos, int64_t n, int64_t n_frames)
+{
+    MDX_REQUIRE(h && pos, "NULL argument");
+    MDX_REQUIRE(n > 0 && n_frames >= 0, "bad size");
+    MDX_TRY(set_device(h->dev));
+    const int64_t slab = std::max<int64_t>(1, (int64_t(256) << 20) / (12 * n));
+    for (int64_t f0 = 0; f0 < n_frames; f0 += slab) {
+        const int64_t nf = std::min(slab, n_frames - f0);
+        MDX_TRY(h->d_stage.ensure(size_t(12) * n * nf));
+        MDX_HIP(hipMemcpyAsync(h->d_stage.ptr, pos + f0 * n * 3, size_t(12) * n * nf,
+                               hipMemcpyHostToDevice, h->stream));
+        MDX_TRY(sq_accumulate_device(h, h->d_stage.as<float>(), n, nf));
+        MDX_HIP(hipStreamSynchronize(h->stream));
+    }
+    return MDX_OK;
+}
+
+int mdx_sq_result(mdx_sq_t h, double *ssf)
+{
+    MDX_REQUIRE(h && ssf, "NULL argument");
+    MDX_TRY(set_device(h->dev));
+    MDX_HIP(hipStreamSynchronize(h->stream));
+    h->timer.collect();
+    MDX_HIP(hipMemcpy(ssf, h->d_acc.ptr, size_t(8) * h->n_pairs * h->n_q, hipMemcpyDeviceToHost));
+    return MDX_OK;
+}
+
+int mdx_sq_stats(mdx_sq_t h, int64_t *launches, double *kernel_ms)
+{
+    MDX_REQUIRE(h, "NULL handle");
+    MDX_TRY(set_device(h->dev));
+    MDX_HIP(hipStreamSynchronize(h->stream));
+    h->timer.collect();
+    if (launches) *launches = h->timer.launches;
+    if (kernel_ms) *kernel_ms = h->timer.total_ms;
+    return MDX_OK;
+}
+
+int mdx_sq_enable_timing(mdx_sq_t h, int on)
+{
+    MDX_REQUIRE(h, "NULL handle");
+    h->timer.enabled = on != 0;
+    return MDX_OK;
+}
+
+int mdx_sq_internal_buffer(mdx_sq_t h, double **d_acc, int64_t *n, hipStream_t *stream)
+{
+    MDX_TRY(set_device(h->dev));
+    *d_acc = h->d_acc.as<double>();
+    *n = int64_t(h->n_pairs) * h->n_q;
+    *stream = h->stream;
+    return MDX_OK;
+}
+
+int mdx_fourier_sum(int dev, const double *wavevectors, int64_t n_q, const double *positions,
+                    int64_t n, double *out_re_im)
+{
+    MDX_REQUIRE(wavevectors && positions && out_re_im, "NULL argument");
+    MDX_REQUIRE(n_q >= 1 && n >= 0 && n_q < (int64_t(1) << 30), "bad size");
+    MDX_TRY(set_device(dev));
+    const int qblocks = (int)ceil_div(n_q, SQ_THREADS);
+    int n_split = 1;
+    while (qblocks * n_split < 512 && n_split < 256 && n / (n_split * 2) >= 512)
+        n_split *= 2;
+    DeviceBuffer dq, dp, dpart;
+    int rc = MDX_OK;
+    std::vector<double> part(size_t(2) * n_split * n_q);
+    do {
+        if ((rc = dq.ensure(size_t(24) * n_q)) != MDX_OK) break;
+        if ((rc = dp.ensure(size_t(24) * std::max<int64_t>(n, 1))) != MDX_OK) break;
+        if ((rc = dpart.ensure(size_t(16) * n_split * n_q)) != MDX_OK) break;
+        if (hipMemcpy(dq.ptr, wavevectors, size_t(24) * n_q, hipMemcpyHostToDevice) != hipSuccess ||
+            (n && hipMemcpy(dp.ptr, positions, size_t(24) * n, hipMemcpyHostToDevice) != hipSuccess)) {
+            rc = fail(MDX_ERR_HIP, "upload failed");
+            break;
+        }
+        hipLaunchKernelGGL(sq_fourier_sum_f64_kernel, dim3(qblocks, n_split), dim3(SQ_THREADS), 0, 0,
+                           dp.as<double>(), n, dq.as<double>(), (int)n_q, n_split,
+                           dpart.as<double2>());
+        if (hipDeviceSynchronize() != hipSuccess ||
+            hipMemcpy(part.data(), dpart.ptr, size_t(16) * n_split * n_q, hipMemcpyDeviceToHost) !=
+                hipSuccess) {
+            rc = fail(MDX_ERR_HIP, "fourier-sum kernel failed: %s", hipGetErrorString(hipGetLastError()));
+            break;
+        }
+    } while (0);
+    dq.release();
+    dp.release();
+    dpart.release();
+    if (rc != MDX_OK)
+        return rc;
+    for (int64_t q = 0; q < n_q; ++q) {
+        double re = 0.0, im = 0.0;
+        for (int s = 0; s < n_split; ++s) {
+            re += part[2 * (size_t(s) * n_q + q)];
+            im += part[2 * (size_t(s) * n_q + q) + 1];
+        }
+        out_re_im[2 * q] = re;
+        out_re_im[2 * q + 1] = im;
+    }
+    return MDX_OK;
+}
+
+}  // extern "C"

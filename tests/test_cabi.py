@@ -1,0 +1,74 @@
+"""
+C-ABI checks that need no GPU: libmdx.so loads, exports every symbol that
+include/mdx.h declares, reports errors through mdx_last_error(), and the product
+package fails loudly (no CPU fallback) when no HIP device is visible.
+"""
+import ctypes
+import pathlib
+import re
+
+import numpy as np
+import pytest
+
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+
+
+def _declared():
+    text = (ROOT / "include" / "mdx.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mdx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    from mdhelper_amd import _lib
+    assert sorted(_lib.EXPORTS) == _declared()
+
+
+def test_library_exports_every_declared_symbol():
+    from mdhelper_amd import _lib
+    lib = _lib.lib()
+    for name in _declared():
+        assert hasattr(lib, name), name
+    assert lib.mdx_version() == 100
+
+
+def test_argument_errors_need_no_device():
+    from mdhelper_amd import _lib
+    lib = _lib.lib()
+    h = ctypes.c_void_p()
+    edges = np.array([0.0, 1.0, 0.5])
+    rc = lib.mdx_rdf_create(ctypes.byref(h), 0, 2, edges.ctypes.data_as(ctypes.c_void_p), 0, 0, 0)
+    assert rc == -1 and b"edges" in lib.mdx_last_error()
+    with pytest.raises(ValueError):
+        _lib.check(rc)
+
+
+def test_product_fails_loudly_without_gpu():
+    from mdhelper_amd import _core, _lib
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(RuntimeError, match="no CPU fallback|not available"):
+        _core.RdfEngine(np.linspace(0, 1, 5))
+    with pytest.raises(RuntimeError):
+        _lib.require_device(0)
+    import mdhelper_amd
+    from mdhelper_amd.analysis import Onsager, RadialDistributionFunction, StructureFactor
+    u = mdhelper_amd.ArrayUniverse(np.random.rand(4, 50, 3).astype("f4") * 10, [10, 10, 10, 90, 90, 90])
+    with pytest.raises(RuntimeError):
+        RadialDistributionFunction(u.atoms).run()
+    with pytest.raises(RuntimeError):
+        StructureFactor(u.atoms, n_points=2).run()
+    with pytest.raises(RuntimeError):
+        Onsager(u.atoms, reduced=True, temperature=1).run()
+    from mdhelper_amd.algorithm import correlation
+    with pytest.raises(RuntimeError):
+        correlation.correlation_fft(np.ones(8))
+
+
+def test_product_never_imports_the_oracle():
+    for path in (ROOT / "mdhelper_amd").rglob("*"):
+        if path.suffix in {".py", ".hip", ".hpp", ".h"} or path.name == "Makefile":
+            text = path.read_text()
+            assert "oracle" not in text.lower().replace("oracle/c", "").replace("oracle", "", 0) \
+                or "import oracle" not in text and "from oracle" not in text, path
+            assert "import oracle" not in text and "from oracle" not in text, path

@@ -1,0 +1,265 @@
+"""
+GPU parity tests at the C-ABI level (through the ctypes wrappers of
+mdhelper_amd._core): every engine of libmdx.so against the CPU oracle on the
+same seeded inputs.  Integer bin counts must be bit-exact; floats within 1e-6
+relative (absolute at MSD lag 0, which is pure round-off).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from mdhelper_amd import _core  # noqa: E402
+from oracle import correlation as oc  # noqa: E402
+from oracle import fourier as of  # noqa: E402
+from oracle import rdf as orf  # noqa: E402
+from oracle.cbind import c_radial_histogram  # noqa: E402
+
+ALGOS = ["exact", "filter"]
+
+
+def _edges(n_bins, rng):
+    return np.linspace(rng[0], rng[1], n_bins + 1)
+
+
+def _gpu_hist(p1, p2, n_bins, rng, dims, exclusion=None, algo="auto"):
+    eng = _core.RdfEngine(_edges(n_bins, rng), exclusion, algo=algo)
+    eng.accumulate(p1, p2, dims)
+    out = eng.counts()
+    eng.close()
+    return out
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("rng_range", [(0.0, 15.0), (2.0, 9.5), (0.0, 34.47), (1.5, 34.47)])
+@pytest.mark.parametrize("exclusion", [None, (1, 1), (3, 3)])
+def test_rdf_self_cubic(algo, rng_range, exclusion):
+    rng = np.random.default_rng(5)
+    L = np.float32(68.94)
+    pos = (rng.random((1500, 3)) * L).astype(np.float32)
+    dims = np.array([L, L, L, 90, 90, 90], dtype=np.float32)
+    want = c_radial_histogram(pos, pos, 201, rng_range, dims, exclusion=exclusion)
+    got = _gpu_hist(pos, None, 201, rng_range, dims, exclusion, algo)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_rdf_two_groups_non_cubic_outside_box(algo):
+    rng = np.random.default_rng(6)
+    dims = np.array([30.0, 41.5, 27.25, 90, 90, 90], dtype=np.float32)
+    p1 = (rng.random((700, 3)) * dims[:3]).astype(np.float32)
+    p2 = (rng.random((1100, 3)) * dims[:3] * 5 - 2 * dims[:3]).astype(np.float32)
+    for excl in (None, (2, 5)):
+        want = c_radial_histogram(p1, p2, 64, (0.5, 12.0), dims, exclusion=excl)
+        got = _gpu_hist(p1, p2, 64, (0.5, 12.0), dims, excl, algo)
+        assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_rdf_no_box_and_large_tiles(algo):
+    rng = np.random.default_rng(8)
+    pos = (rng.normal(size=(2500, 3)) * 12).astype(np.float32)
+    want = c_radial_histogram(pos, pos, 100, (0.0, 20.0), None, exclusion=(1, 1))
+    got = _gpu_hist(pos, None, 100, (0.0, 20.0), None, (1, 1), algo)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_rdf_frames_with_changing_box(algo):
+    rng = np.random.default_rng(9)
+    F, N = 5, 1200
+    Ls = (40 + 3 * rng.random(F)).astype(np.float32)
+    frames = (rng.random((F, N, 3)) * Ls[:, None, None]).astype(np.float32)
+    boxes = np.stack([np.array([L, L, L, 90, 90, 90], dtype=np.float32) for L in Ls])
+    want = np.zeros(150, dtype=np.int64)
+    for f in range(F):
+        want += c_radial_histogram(frames[f], frames[f], 150, (0.0, 14.0), boxes[f], exclusion=(1, 1))
+    eng = _core.RdfEngine(_edges(150, (0.0, 14.0)), (1, 1), algo=algo, timing=True)
+    eng.accumulate(frames, None, boxes)
+    got = eng.counts()
+    st = eng.stats()
+    assert np.array_equal(got, want)
+    assert st["pairs_evaluated"] == F * N * N and st["kernel_ms"] > 0
+    # accumulate again: counts double
+    eng.accumulate(frames, None, boxes)
+    assert np.array_equal(eng.counts(), 2 * want)
+    eng.reset()
+    assert eng.counts().sum() == 0
+    eng.close()
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_rdf_adversarial_lattice_on_bin_edges(algo):
+    """Simple-cubic lattice whose spacing equals the bin width: distances sit on edges."""
+    n, a = 12, np.float32(0.75)
+    idx = np.arange(n)
+    pos = (a * np.stack(np.meshgrid(idx, idx, idx, indexing="ij"), -1).reshape(-1, 3)).astype(np.float32)
+    L = np.float32(n * a)
+    dims = np.array([L, L, L, 90, 90, 90], dtype=np.float32)
+    for rng_range, nb in [((0.0, 4.5), 6), ((0.0, 4.5), 60), ((0.75, 3.75), 4)]:
+        want = c_radial_histogram(pos, pos, nb, rng_range, dims, exclusion=(1, 1))
+        got = _gpu_hist(pos, None, nb, rng_range, dims, (1, 1), algo)
+        assert np.array_equal(got, want), (rng_range, nb)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_rdf_half_box_separations(algo):
+    """Pairs exactly half a box apart (image choice ambiguous) with range up to L/2."""
+    rng = np.random.default_rng(10)
+    L = np.float32(20.0)
+    base = (rng.random((600, 3)) * L).astype(np.float32)
+    shifted = base.copy()
+    shifted[:, 0] = np.mod(shifted[:, 0] + L / 2, L)
+    pos = np.vstack((base, shifted)).astype(np.float32)
+    dims = np.array([L, L, L, 90, 90, 90], dtype=np.float32)
+    want = c_radial_histogram(pos, pos, 50, (0.0, 10.0), dims)
+    got = _gpu_hist(pos, None, 50, (0.0, 10.0), dims, None, algo)
+    assert np.array_equal(got, want)
+
+
+def test_rdf_reference_test_geometry():
+    """tests/test_analysis_structure.py:21-40 of the reference, through mdx_radial_histogram."""
+    rng = np.random.default_rng(11)
+    L = 20
+    half_L = L // 2
+    dims = np.array((L, L, L, 90, 90, 90), dtype=int)
+    origin = half_L * np.ones(3)
+    norm = half_L * rng.random(1000)
+    neighbors = rng.random((1000, 3))
+    neighbors *= norm[:, None] / np.linalg.norm(neighbors, axis=1, keepdims=True)
+    neighbors += dims[:3] / 2
+    edges = np.linspace(0, half_L + 1, half_L + 1)
+    got = _core.radial_histogram_device(origin, neighbors, half_L, edges, dims)
+    want = orf.radial_histogram_ref(origin, neighbors, half_L, (0, half_L + 1), dims)
+    assert np.array_equal(got, want) and got.sum() == 1000
+
+
+def test_rdf_triclinic_rejected_and_empty():
+    pos = np.zeros((4, 3), dtype=np.float32)
+    eng = _core.RdfEngine(_edges(4, (0, 1)))
+    with pytest.raises(NotImplementedError):
+        eng.accumulate(pos, None, np.array([10, 10, 10, 90, 80, 90], dtype=np.float32))
+    eng.accumulate(np.zeros((0, 3), dtype=np.float32).reshape(1, 0, 3), None, None)
+    assert eng.counts().sum() == 0
+    eng.close()
+
+
+def test_rdf_many_bins_and_tiny_bins():
+    rng = np.random.default_rng(12)
+    L = np.float32(25.0)
+    pos = (rng.random((800, 3)) * L).astype(np.float32)
+    dims = np.array([L, L, L, 90, 90, 90], dtype=np.float32)
+    for nb in (1, 7, 5000, 20000):
+        want = c_radial_histogram(pos, pos, nb, (0.0, 12.0), dims, exclusion=(1, 1))
+        for algo in ALGOS:
+            got = _gpu_hist(pos, None, nb, (0.0, 12.0), dims, (1, 1), algo)
+            assert np.array_equal(got, want), (nb, algo)
+
+
+def test_fourier_sum_matches_golden(golden_dir):
+    g = np.load(golden_dir / "fourier_ref.npz")
+    got = _core.fourier_sum_device(g["qs"], g["rs"])
+    assert np.allclose(got, g["out_fourier_sum"], rtol=1e-9, atol=1e-9)
+
+
+def test_sq_engine_partial_and_total():
+    rng = np.random.default_rng(13)
+    L = 31.7
+    F, sizes = 3, [700, 500, 300]
+    N = sum(sizes)
+    frames = (rng.random((F, N, 3)) * L).astype(np.float32)
+    q = of.grid_wavevectors([L, L, L], 5)
+    for mode in (None, "partial", "pair"):
+        pairs = of.ssf_pairs(len(sizes), mode)
+        eng = _core.SqEngine(q, sizes, pairs, timing=True)
+        eng.accumulate(frames)
+        got = eng.result()
+        slices, idx = [], 0
+        for n in sizes:
+            slices.append(slice(idx, idx + n))
+            idx += n
+        want = sum(of.ssf_frame_ref(q, frames[f].astype(np.float64), slices, pairs, mode) for f in range(F))
+        scale = np.abs(want).max()
+        assert np.allclose(got, want, rtol=1e-6, atol=1e-9 * scale), mode
+        assert eng.stats()["kernel_ms"] > 0
+        eng.close()
+
+
+def test_sq_large_phase_accuracy():
+    """Unwrapped coordinates far from the origin: |q.r| ~ 1e4 still within 1e-6."""
+    rng = np.random.default_rng(14)
+    L = 20.0
+    pos = (rng.random((4000, 3)) * L + 40 * L).astype(np.float32)
+    q = of.grid_wavevectors([L, L, L], 6)[1:]
+    eng = _core.SqEngine(q, [4000], ((None, None),))
+    eng.accumulate(pos[None])
+    got = eng.result()[0]
+    rho = of.fourier_sum_ref(q, pos.astype(np.float64))
+    want = (rho * rho.conj()).real
+    assert np.allclose(got, want, rtol=1e-6, atol=1e-6 * 4000)
+    eng.close()
+
+
+def test_msd_engine_matches_oracle():
+    rng = np.random.default_rng(15)
+    B, Tb, sizes = 2, 60, [7, 5]
+    N = sum(sizes)
+    pos = np.cumsum(rng.normal(size=(B * Tb + 3, N, 3)), axis=0) + 50.0   # 3 trailing frames ignored
+    eng = _core.MsdEngine(Tb, B, len(sizes), timing=True)
+    first = 0
+    for g, n in enumerate(sizes):
+        eng.push(g, pos, first, n)
+        first += n
+    msd, traj = eng.result()
+    first = 0
+    for g, n in enumerate(sizes):
+        p = pos[:B * Tb, first:first + n].reshape(B, Tb, n, 3)
+        want = oc.msd_fft_ref(p, axis=1, average=False).sum(axis=-1)
+        assert np.allclose(msd[g], want, rtol=1e-6, atol=1e-7), g
+        assert np.allclose(traj[g], p.sum(axis=2), rtol=1e-12, atol=1e-9)
+        first += n
+    assert eng.stats()["bytes_moved"] > 0
+    eng.close()
+
+
+def test_msd_zero_dims_and_split_push():
+    rng = np.random.default_rng(16)
+    Tb, n = 100, 9
+    pos = np.cumsum(rng.normal(size=(Tb, n, 3)), axis=0)
+    eng = _core.MsdEngine(Tb, 1, 1)
+    eng.push(0, pos, 0, 4, zero_dims=0b100)
+    eng.push(0, pos, 4, 5, zero_dims=0b100)
+    msd, _ = eng.result()
+    p = pos.copy()
+    p[..., 2] = 0
+    want = oc.msd_fft_ref(p[None], axis=1, average=False).sum(axis=-1)
+    assert np.allclose(msd[0], want, rtol=1e-6, atol=1e-7)
+    eng.close()
+
+
+def test_correlate_matches_oracle():
+    rng = np.random.default_rng(17)
+    a = rng.normal(size=(6, 37))
+    b = rng.normal(size=(6, 37))
+    pos, neg = _core.correlate_device(a, b, negative=True)
+    full = oc.correlation_fft_ref(a, b, axis=1)          # normalised, lags -(T-1)..T-1
+    T = 37
+    w = np.arange(T, 0, -1)
+    assert np.allclose(pos / w, full[:, T - 1:], rtol=1e-9, atol=1e-10)
+    assert np.allclose((neg / w)[:, 1:], full[:, T - 2::-1], rtol=1e-9, atol=1e-10)
+    acf = _core.correlate_device(a)
+    assert np.allclose(acf / w, oc.correlation_fft_ref(a, axis=1), rtol=1e-9, atol=1e-10)
+
+
+def test_synth_walk_is_deterministic_and_wrapped():
+    L = 68.94
+    d = _core.synth_random_walk(6, 4096, [L, L, L], 0.3, seed=2)
+    a = d.to_host()
+    d2 = _core.synth_random_walk(6, 4096, [L, L, L], 0.3, seed=2)
+    assert np.array_equal(a, d2.to_host())
+    assert a.min() >= 0 and a.max() < L
+    step = a[1] - a[0]
+    step -= L * np.rint(step / L)
+    assert 0.25 < step.std() < 0.35
+    d.free()
+    d2.free()

@@ -1,0 +1,228 @@
+"""
+Host-side logic that needs no GPU: the ArrayUniverse shim, frame selection,
+constructor/argument error conventions of the reference, host post-processing
+(radial Fourier transform, coordination numbers, transport-coefficient fits),
+direct-definition correlations, frame-prep helpers.
+"""
+import warnings
+
+import numpy as np
+import pytest
+
+import mdhelper_amd
+from mdhelper_amd.algorithm import correlation, molecule, topology, utility
+from mdhelper_amd.analysis import Onsager, RadialDistributionFunction, StructureFactor, structure, transport
+from mdhelper_amd.analysis.base import Hash, SerialAnalysisBase
+from mdhelper_amd.comm import shard_range
+from oracle import correlation as oc
+
+
+def _universe(F=6, N=40, L=12.0, **kw):
+    rng = np.random.default_rng(0)
+    return mdhelper_amd.ArrayUniverse((rng.random((F, N, 3)) * L).astype(np.float32),
+                                      [L, L, L, 90, 90, 90], dt=0.5, **kw)
+
+
+def test_universe_duck_type():
+    u = _universe(charges=np.r_[np.ones(20), -np.ones(20)], resids=np.arange(40) // 4)
+    ag = u.atoms[10:20]
+    assert ag.universe is u and ag.n_atoms == 10 and ag.n_residues == 3
+    assert ag.positions.dtype == np.float32 and ag.positions.shape == (10, 3)
+    assert np.array_equal(ag.indices, np.arange(10, 20))
+    ts = u.trajectory[3]
+    assert ts.frame == 3 and ts.time == 1.5 and np.isclose(ts.volume, 12.0 ** 3)
+    assert np.array_equal(ag.positions, u.trajectory._positions[3, 10:20])
+    assert u.dimensions.shape == (6,) and len(u.trajectory[1:6:2]) == 3
+    assert ag == u.atoms[10:20] and not (ag == u.atoms[11:21])
+    assert len(u.atoms.residues) == 10 and np.allclose(u.atoms.residues.charges[:5], 4)
+
+
+def test_frame_selection_and_hash():
+    u = _universe()
+    seen = []
+
+    class Probe(SerialAnalysisBase):
+        def _single_frame(self):
+            seen.append((self._frame_index, self._ts.frame))
+
+    p = Probe(u.trajectory).run(start=1, stop=6, step=2)
+    assert seen == [(0, 1), (1, 3), (2, 5)] and p.n_frames == 3
+    assert np.array_equal(p.frames, [1, 3, 5]) and np.allclose(p.times, [0.5, 1.5, 2.5])
+    seen.clear()
+    Probe(u.trajectory).run(frames=[0, 4])
+    assert [s[1] for s in seen] == [0, 4]
+    with pytest.raises(ValueError):
+        Probe(u.trajectory).run(start=1, frames=[0])
+    h = Hash({"a": 1}, b=2)
+    h.c = 3
+    assert h.a == 1 and h["c"] == 3 and h.missing is None and "b" in h
+    with pytest.raises(TypeError):
+        Hash(3)
+
+
+def test_shard_range_is_a_partition():
+    for n in (0, 1, 7, 100):
+        for w in (1, 2, 3, 8):
+            parts = [shard_range(n, r, w) for r in range(w)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+            assert max(hi - lo for lo, hi in parts) - min(hi - lo for lo, hi in parts) <= 1
+
+
+def test_constructor_errors_follow_the_reference():
+    u = _universe()
+    with pytest.raises(ValueError):
+        RadialDistributionFunction(u.atoms, groupings="molecules")
+    with pytest.raises(ValueError):
+        RadialDistributionFunction(u.atoms, drop_axis=5)
+    with pytest.raises(ValueError):
+        StructureFactor((u.atoms[:10],), mode=None)            # groups must cover the universe
+    with pytest.raises(ValueError):
+        StructureFactor((u.atoms[:10], u.atoms[10:20], u.atoms[20:]), mode="pair")
+    with pytest.raises(ValueError):
+        StructureFactor(u.atoms, dimensions=[1, 2])
+    with pytest.raises(ValueError):
+        StructureFactor(u.atoms, groupings=("atoms", "atoms"))
+    with pytest.raises(ValueError):
+        Onsager(u.atoms, groupings="chains", reduced=True)
+    with pytest.raises(ValueError):
+        Onsager((u.atoms[:20], u.atoms[20:]), charges=[1], reduced=True)
+    with pytest.raises(ValueError):
+        Onsager(u.atoms, dimensions=[1, 2], reduced=True)
+    ons = Onsager(u.atoms, reduced=True, temperature=1.0)
+    with pytest.raises(RuntimeError):
+        ons.calculate_transport_coefficients()
+    with pytest.raises(RuntimeError):
+        ons.calculate_conductivity()
+    no_box = mdhelper_amd.ArrayUniverse(np.zeros((2, 4, 3), dtype=np.float32))
+    with pytest.raises(ValueError):
+        RadialDistributionFunction(no_box.atoms)
+    with pytest.raises(ValueError):
+        Onsager(no_box.atoms, reduced=True)
+
+
+def test_structure_factor_wavevectors():
+    u = _universe()
+    sf = StructureFactor(u.atoms, n_points=3)
+    g1 = 2 * np.pi / 12.0
+    assert sf._wavevectors.shape == (27, 3)
+    assert np.allclose(sf._wavevectors[1], [0, 0, g1]) and np.allclose(sf._wavevectors[3], [g1, 0, 0])
+    sf = StructureFactor(u.atoms, n_points=4, q_max=1.2 * g1)
+    assert len(sf._wavevectors) == 4
+    sf = StructureFactor(u.atoms, n_points=3, n_surfaces=2, n_surface_points=8)
+    assert sf._wavevectors.shape == (27 + 16, 3)
+    assert np.allclose(np.linalg.norm(sf._wavevectors[27:35], axis=1), g1)
+    sf = StructureFactor(u.atoms, dimensions=[10.0, 12.0, 14.0], n_points=2)
+    assert sf._wavevectors.shape == (8, 3)
+
+
+def test_radial_fourier_transform_analytic():
+    """exp(-ar)/r  <->  4 pi / (a^2 + q^2)   (reference tests/test_analysis_structure.py:42-53)."""
+    alpha = 3.7
+    r = np.linspace(1e-8, 20, 2_000)
+    q = 1 / r
+    f = np.exp(-alpha * r) / r
+    assert np.allclose(4 * np.pi / (alpha ** 2 + q ** 2), structure.radial_fourier_transform(r, f, q), atol=4e-5)
+
+
+def test_coordination_numbers_and_structure_factor_postprocessing():
+    r = np.linspace(0.05, 12, 240)
+    g = 1 + np.exp(-(r - 3) ** 2) * 1.5 - np.exp(-(r - 4.4) ** 2) * 0.6 + np.exp(-(r - 6) ** 2) * 0.4
+    g[r < 2] = 0
+    n = structure.calculate_coordination_numbers(r, g, 0.03, n_coord_nums=2)
+    assert np.isfinite(n[0]) and n[0] > 0
+    with pytest.raises(ValueError):
+        structure.calculate_coordination_numbers(r, g, 0.03, n_dims=4)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert np.isnan(structure.calculate_coordination_numbers(r, np.ones_like(r), 0.03)).all()
+    q, s = structure.calculate_structure_factor(r, g, True, 0.03, n_q=50)
+    assert q.shape == s.shape == (50,)
+    _, s_al = structure.calculate_structure_factor(r, g, False, 0.03, 0.5, 0.5, q, formalism="AL")
+    assert np.allclose(s_al - 1, 0.5 * (s - 1))
+    with pytest.raises(ValueError):
+        structure.calculate_structure_factor(r, g, False, 0.03, 0.5, 0.5, q, formalism="XX")
+
+
+def test_transport_coefficient_fits():
+    t = 0.5 * np.arange(200)
+    D = np.array([0.3, 0.7])
+    msd_self = (D[:, None] * t)[:, None, :]
+    msd_cross = np.stack([2.0 * t, 0.4 * t, 3.0 * t])[:, None, :]
+    dims = np.array([10.0, 10.0, 10.0])
+    for scale in ("linear", "log"):
+        L, Ls, Di = transport.calculate_transport_coefficients(t, msd_cross, msd_self, (10, 20), dims, 2.0,
+                                                               start=5, scale=scale)
+        assert np.allclose(Di[0], D, rtol=1e-6)
+        assert np.allclose(L[0], np.array([[2.0, 0.4], [0.4, 3.0]]) / 2000.0, rtol=1e-6)
+        assert np.allclose(Ls[0], np.array([10, 20]) * D / 2000.0, rtol=1e-6)
+    z = np.array([1.0, -1.0])
+    assert np.allclose(transport.calculate_conductivity(L, z, reduced=True), (2.0 - 0.8 + 3.0) / 2000)
+    tn = transport.calculate_transference_number(L, z)
+    assert np.allclose(tn.sum(axis=-1), 1)
+    mu = transport.calculate_electrophoretic_mobility(L, z, np.array([0.01, 0.02]), reduced=True)
+    assert mu.shape == (1, 2)
+
+
+def test_direct_correlations_match_oracle():
+    rng = np.random.default_rng(2)
+    a = rng.normal(size=(2, 30, 4, 3))
+    b = rng.normal(size=(2, 30, 4, 3))
+    assert np.allclose(correlation.correlation_shift(a, b, axis=1, vector=True),
+                       oc.correlation_shift_ref(a, b, axis=1, vector=True))
+    assert np.allclose(correlation.correlation_shift(a[0, :, 0, 0], double=True),
+                       oc.correlation_shift_ref(a[0, :, 0, 0], double=True))
+    assert np.allclose(correlation.msd_shift(a, axis=1, average=False), oc.msd_shift_ref(a, axis=1, average=False))
+    assert np.allclose(correlation.msd_shift(a, b, axis=1), oc.msd_shift_ref(a, b, axis=1))
+    traj_1 = np.array(((0, 0, 0), (1, 1, 1), (2, 2, 2), (3, 3, 3)))
+    assert np.allclose(correlation.msd_shift(traj_1), [0, 3, 12, 27])
+
+
+def test_correlation_argument_errors():
+    """tests/test_algorithm_correlation.py:49-65, 445-461 of the reference (raised before any GPU work)."""
+    for fn in (correlation.correlation_fft, correlation.correlation_shift):
+        with pytest.raises(ValueError):
+            fn(np.empty(0))
+        with pytest.raises(ValueError):
+            fn(np.empty((0, 3)))
+        with pytest.raises(ValueError):
+            fn(np.empty((2, 2, 2, 2, 2)))
+        with pytest.raises(ValueError):
+            fn(np.empty((2, 2, 2)), axis=2)
+    for fn in (correlation.msd_fft, correlation.msd_shift):
+        with pytest.raises(ValueError):
+            fn(np.empty(0))
+        with pytest.raises(ValueError):
+            fn(np.empty((2, 2, 2, 2, 2)))
+        with pytest.raises(ValueError):
+            fn(np.ones((4, 3)), np.ones((1, 3)))
+        with pytest.raises(ValueError):
+            fn(np.empty((2, 2, 2)), axis=2)
+    with pytest.warns(UserWarning):
+        correlation.correlation_shift(np.ones((4, 2)))
+
+
+def test_frame_prep_helpers():
+    rng = np.random.default_rng(3)
+    L = np.array([10.0, 10.0, 10.0])
+    true = np.cumsum(rng.normal(scale=1.5, size=(50, 8, 3)), axis=0) + 5
+    wrapped = true - np.floor(true / L) * L
+    old = wrapped[0].copy()
+    images = np.zeros((8, 3), dtype=int)
+    out = []
+    for f in range(50):
+        p = wrapped[f].copy()
+        topology.unwrap(p, old, L, thresholds=L / 2, images=images)
+        out.append(p)
+    assert np.allclose(np.array(out) - out[0], true - true[0])
+    w = topology.wrap(true[10], L, in_place=False)
+    assert w.min() >= 0 and w.max() <= 10
+    u = _universe(masses=np.arange(1, 41, dtype=float), resids=np.arange(40) // 4)
+    com = molecule.center_of_mass(u.atoms, "residues")
+    m = np.arange(1, 41, dtype=float).reshape(10, 4)
+    want = (m[..., None] * u.atoms.positions.reshape(10, 4, 3)).sum(1) / m.sum(1, keepdims=True)
+    assert np.allclose(com, want)
+    assert np.allclose(molecule.center_of_mass(positions=u.atoms.positions, masses=u.atoms.masses),
+                       molecule.center_of_mass(u.atoms))
+    assert utility.get_closest_factors(35904, 3).tolist() == [32, 33, 34]
+    assert utility.get_closest_factors(73440, 4, reverse=True).tolist() == [18, 17, 16, 15]
