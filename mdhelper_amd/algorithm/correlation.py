@@ -56,7 +56,8 @@ def _validate(arr1, arr2, axis, min_dim, noun, warn_dim):
 def _series(arr, axis):
     """Time axis last, everything else flattened: float64[n_series, n_t]."""
     moved = np.moveaxis(arr, axis, -1)
-    return np.ascontiguousarray(moved.reshape(-1, moved.shape[-1]), dtype=np.float64), moved.shape
+    dtype = np.complex128 if np.iscomplexobj(moved) else np.float64
+    return np.ascontiguousarray(moved.reshape(-1, moved.shape[-1]), dtype=dtype), moved.shape
 
 
 def _unseries(flat, shape, axis):

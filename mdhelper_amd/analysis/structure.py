@@ -258,8 +258,9 @@ class RadialDistributionFunction(DynamicAnalysisBase):
                 pos2 = np.array(pos2, dtype=np.float32)
                 pos2[:, self._drop_axis] = 0
             dims[self._drop_axis] = dims[:3].max()
-        if self._norm == "rdf":
-            self._area_or_volume += self._frame_volume(dims)
+        # always tracked (the reference only does for norm="rdf", which leaves _get_rdf()
+        # without a volume for the other norms)
+        self._area_or_volume += self._frame_volume(dims)
         self._batch.add([pos1] if self._same else [pos1, pos2], dims)
 
     def _conclude(self):
@@ -313,8 +314,7 @@ class RadialDistributionFunction(DynamicAnalysisBase):
             sel = mine[b0:b0 + block]
             pos = traj.frame_block(sel)
             boxes = traj.box_block(sel)
-            if self._norm == "rdf":
-                self._area_or_volume += float(np.prod(boxes[:, :3].astype(np.float64), axis=1).sum())
+            self._area_or_volume += float(np.prod(boxes[:, :3].astype(np.float64), axis=1).sum())
             p1 = pos if all1 else pos[:, i1]
             p2 = None if self._same else pos[:, i2]
             self._engine.accumulate(p1, p2, boxes)

@@ -1,0 +1,285 @@
+"""
+GPU parity tests of the operator surface (RadialDistributionFunction,
+StructureFactor, Onsager, correlation_fft / msd_fft, radial_histogram) against
+the oracle's restatement of the reference drivers and against the golden
+vectors produced by the reference's own correlation.py / accelerated.py.
+"""
+import warnings
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import mdhelper_amd  # noqa: E402
+from mdhelper_amd.algorithm import correlation  # noqa: E402
+from mdhelper_amd.analysis import Onsager, RadialDistributionFunction, StructureFactor, structure  # noqa: E402
+from oracle import correlation as oc  # noqa: E402
+from oracle import fourier as of  # noqa: E402
+from oracle import rdf as orf  # noqa: E402
+
+
+def lj_melt(F=100, n_side=10, seed=1):
+    """C1: 1000-atom jittered simple-cubic lattice, rho* = 0.8442."""
+    a = 1.0577
+    L = n_side * a
+    rng = np.random.default_rng(seed)
+    idx = np.arange(n_side)
+    lattice = a * np.stack(np.meshgrid(idx, idx, idx, indexing="ij"), -1).reshape(-1, 3)
+    frames = lattice[None] + rng.normal(scale=0.1 * a, size=(F, n_side ** 3, 3))
+    return np.mod(frames, L).astype(np.float32), np.float32(L)
+
+
+def test_c1_rdf_lj_melt_matches_reference_driver():
+    """BASELINE config C1: RDF on a 1000-atom LJ melt, 100 frames."""
+    frames, L = lj_melt()
+    dims = np.array([L, L, L, 90, 90, 90], dtype=np.float32)
+    u = mdhelper_amd.ArrayUniverse(frames, dims)
+    rng_range = (0.0, float(L) / 2)
+    rdf = RadialDistributionFunction(u.atoms, n_bins=201, range=rng_range, exclusion=(1, 1)).run()
+    ref = orf.rdf_run_ref(frames, dims, 201, rng_range, exclusion=(1, 1))
+    assert rdf.results.counts.dtype == np.int64
+    assert np.array_equal(rdf.results.counts, ref["counts"])
+    assert np.allclose(rdf.results.rdf, ref["rdf"], rtol=1e-6)
+    assert np.array_equal(rdf.results.edges, ref["edges"]) and np.array_equal(rdf.results.bins, ref["bins"])
+    # generic per-frame path (what a real MDAnalysis universe takes) gives the same counts
+    slow = RadialDistributionFunction(u.atoms, n_bins=201, range=rng_range, exclusion=(1, 1))
+    slow.run(start=0, stop=100, step=3)
+    ref3 = orf.rdf_run_ref(frames[::3], dims, 201, rng_range, exclusion=(1, 1))
+    assert np.array_equal(slow.results.counts, ref3["counts"])
+    # post-processing runs on the result
+    rdf.calculate_coordination_numbers(0.8442 / 1.0577 ** 3 * 1.0577 ** 3)
+    rdf.calculate_pmf(300)
+    rdf.calculate_structure_factor(0.8442, n_q=64)
+    assert rdf.results.ssf.shape == (64,) and np.isfinite(rdf.results.pmf[50:]).all()
+
+
+def test_rdf_two_groups_norms_and_drop_axis():
+    rng = np.random.default_rng(2)
+    L = np.float32(24.0)
+    frames = (rng.random((7, 900, 3)) * L).astype(np.float32)
+    dims = np.array([L, L, L, 90, 90, 90], dtype=np.float32)
+    u = mdhelper_amd.ArrayUniverse(frames, dims, resids=np.arange(900) // 3)
+    a, b = u.atoms[:400], u.atoms[400:]
+    for norm in ("rdf", "density", None):
+        r = RadialDistributionFunction(a, b, 50, (0.5, 10.0), norm=norm).run()
+        ref = orf.rdf_run_ref(frames, dims, 50, (0.5, 10.0), sel1=slice(0, 400), sel2=slice(400, 900), norm=norm)
+        assert np.array_equal(r.results.counts, ref["counts"])
+        assert np.allclose(r.results.rdf, ref["rdf"], rtol=1e-6)
+        assert np.allclose(r._get_rdf(), orf.rdf_run_ref(frames, dims, 50, (0.5, 10.0), sel1=slice(0, 400),
+                                                         sel2=slice(400, 900))["rdf"], rtol=1e-6)
+    # residue centres of mass go through the per-frame path
+    r = RadialDistributionFunction(u.atoms, n_bins=30, range=(0.0, 8.0), groupings="residues",
+                                   exclusion=(1, 1)).run()
+    com = frames.reshape(7, 300, 3, 3).astype(np.float64).mean(axis=2).astype(np.float32)
+    ref = orf.rdf_run_ref(com, dims, 30, (0.0, 8.0), exclusion=(1, 1))
+    assert np.array_equal(r.results.counts, ref["counts"])
+    # 2-D mode: drop z
+    r = RadialDistributionFunction(u.atoms, n_bins=30, range=(0.0, 8.0), drop_axis="z", exclusion=(1, 1)).run()
+    flat = frames.copy()
+    flat[..., 2] = 0
+    want = np.zeros(30, dtype=np.int64)
+    for f in range(7):
+        want += orf.radial_histogram_ref(flat[f], flat[f], 30, (0.0, 8.0), dims, exclusion=(1, 1))
+    assert np.array_equal(r.results.counts, want)
+    assert np.isfinite(r.results.rdf).all()
+
+
+def test_radial_histogram_function():
+    rng = np.random.default_rng(11)
+    L = 20
+    half_L = L // 2
+    dims = np.array((L, L, L, 90, 90, 90), dtype=int)
+    origin = half_L * np.ones(3)
+    norm = half_L * rng.random(1000)
+    neighbors = rng.random((1000, 3))
+    neighbors *= norm[:, None] / np.linalg.norm(neighbors, axis=1, keepdims=True)
+    neighbors += dims[:3] / 2
+    got = structure.radial_histogram(origin, neighbors, n_bins=half_L, range=(0, half_L + 1), dims=dims)
+    want = orf.radial_histogram_ref(origin, neighbors, half_L, (0, half_L + 1), dims)
+    assert np.array_equal(got, want)
+    with pytest.raises(NotImplementedError):
+        structure.radial_histogram(origin, neighbors, 4, (0, 5), [20, 20, 20, 90, 60, 90])
+
+
+@pytest.mark.parametrize("mode", [None, "pair", "partial"])
+@pytest.mark.parametrize("form", ["exp", "trig"])
+def test_structure_factor_matches_reference_driver(mode, form):
+    rng = np.random.default_rng(3)
+    L = 18.0
+    frames = (rng.random((5, 600, 3)) * L).astype(np.float32)
+    u = mdhelper_amd.ArrayUniverse(frames, [L, L, L, 90, 90, 90])
+    groups = (u.atoms[:350], u.atoms[350:])
+    sf = StructureFactor(groups, mode=mode, form=form, n_points=5).run()
+    q = of.grid_wavevectors([L, L, L], 5)
+    ref = of.ssf_run_ref(frames.astype(np.float64), [350, 250], q, mode=mode, form=form)
+    assert sf.results.pairs == ref["pairs"]
+    assert np.allclose(sf.results.wavenumbers, ref["wavenumbers"])
+    assert np.allclose(sf.results.ssf, ref["ssf"], rtol=1e-6, atol=1e-8)
+    raw = StructureFactor(groups, mode=mode, n_points=3, sort=False, unique=False).run(step=2)
+    ref = of.ssf_run_ref(frames[::2].astype(np.float64), [350, 250], of.grid_wavevectors([L, L, L], 3),
+                         mode=mode, sort=False, unique=False)
+    assert np.allclose(raw.results.ssf, ref["ssf"], rtol=1e-6, atol=1e-8)
+
+
+def test_structure_factor_bragg_peaks():
+    n, a = 6, 1.5
+    L = n * a
+    idx = np.arange(n)
+    pos = (a * np.stack(np.meshgrid(idx, idx, idx, indexing="ij"), -1).reshape(-1, 3)).astype(np.float32)
+    u = mdhelper_amd.ArrayUniverse(pos[None], [L, L, L, 90, 90, 90])
+    sf = StructureFactor(u.atoms, n_points=2 * n, sort=False, unique=False).run()
+    m = np.rint(sf._wavevectors * L / (2 * np.pi)).astype(int)
+    bragg = np.all(m % n == 0, axis=1)
+    assert np.allclose(sf.results.ssf[0][bragg], n ** 3, rtol=1e-6)
+    assert np.allclose(sf.results.ssf[0][~bragg], 0, atol=1e-6)
+
+
+def test_correlation_fft_matches_reference_golden(golden_dir):
+    g = np.load(golden_dir / "correlation_ref.npz")
+    a, b, walk, walk2 = g["a"], g["b"], g["walk"], g["walk2"]
+    cases = {
+        "acf_1d": (correlation.correlation_fft, (a[0, :, 0, 0],), {}),
+        "acf_2d_axis0": (correlation.correlation_fft, (a[0, :, :, 0],), {"axis": 0}),
+        "acf_2d_axis1": (correlation.correlation_fft, (a[:, :, 0, 0],), {"axis": 1}),
+        "acf_vec_axis0": (correlation.correlation_fft, (a[0, :, 0],), {"axis": 0, "vector": True}),
+        "acf_3d_vec": (correlation.correlation_fft, (a[0],), {"axis": 0, "vector": True}),
+        "acf_3d_vec_avg": (correlation.correlation_fft, (a[0],), {"axis": 0, "vector": True, "average": True}),
+        "acf_4d_vec": (correlation.correlation_fft, (a,), {"axis": 1, "vector": True}),
+        "acf_4d_vec_dbl_avg": (correlation.correlation_fft, (a,), {"axis": 1, "vector": True, "double": True, "average": True}),
+        "acf_4d_scalar": (correlation.correlation_fft, (a,), {"axis": 1}),
+        "ccf_1d": (correlation.correlation_fft, (a[0, :, 0, 0], b[0, :, 0, 0]), {}),
+        "ccf_1d_dbl": (correlation.correlation_fft, (a[0, :, 0, 0], b[0, :, 0, 0]), {"double": True}),
+        "ccf_2d_axis1": (correlation.correlation_fft, (a[:, :, 0, 0], b[:, :, 0, 0]), {"axis": 1}),
+        "ccf_3d_vec": (correlation.correlation_fft, (a[0], b[0]), {"axis": 0, "vector": True}),
+        "ccf_4d_vec": (correlation.correlation_fft, (a, b), {"axis": 1, "vector": True}),
+        "ccf_4d_vec_dbl": (correlation.correlation_fft, (a, b), {"axis": 1, "vector": True, "double": True}),
+        "msd_self": (correlation.msd_fft, (walk,), {"axis": 1, "average": False}),
+        "msd_avg": (correlation.msd_fft, (walk,), {"axis": 1}),
+        "msd_coll": (correlation.msd_fft, (walk.sum(axis=2),), {"axis": 1}),
+        "msd_cross": (correlation.msd_fft, (walk.sum(axis=2), walk2.sum(axis=2)), {"axis": 1}),
+        "msd_cross_particles": (correlation.msd_fft, (walk, walk2), {"axis": 1, "average": False}),
+        "msd_tn3_axis0": (correlation.msd_fft, (walk[0],), {"axis": 0, "average": False}),
+        "msd_t3_axis0": (correlation.msd_fft, (walk[0, :, 0],), {"axis": 0}),
+    }
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for name, (fn, args, kwargs) in cases.items():
+            got = fn(*args, **kwargs)
+            want = g["out_" + name]
+            assert got.shape == want.shape, name
+            scale = max(1.0, np.abs(want).max())
+            assert np.allclose(got, want, rtol=1e-6, atol=1e-9 * scale), name
+    # closed forms of the reference tests (test_algorithm_correlation.py:438-472)
+    assert np.allclose(correlation.msd_fft(g["traj_1"].tolist()), [0, 3, 12, 27], atol=1e-9)
+    assert np.allclose(correlation.msd_fft(g["traj_2"]), [0, 12, 48, 108], atol=1e-9)
+    assert np.allclose(correlation.msd_fft(g["traj_1"], g["traj_2"].tolist()), [0, 6, 24, 54], atol=1e-9)
+    # all-ones ACF = 1 (scalar) / d (vector)  (:67-102)
+    ones = np.ones((3, 20, 4, 3))
+    assert np.allclose(correlation.correlation_fft(ones[0, :, 0, 0]), 1)
+    assert np.allclose(correlation.correlation_fft(ones, axis=1, vector=True), 3)
+    # complex input goes through four real correlations
+    z = a[0, :, 0, 0] + 1j * b[0, :, 0, 0]
+    T = len(z)
+    want = np.array([np.sum(np.conj(z[:T - m]) * z[m:]) / (T - m) for m in range(T)])
+    assert np.allclose(correlation.correlation_fft(z), want)
+
+
+def _random_walk_universe(T=400, sizes=(30, 20), seed=4, sigma=0.1):
+    rng = np.random.default_rng(seed)
+    N = sum(sizes)
+    pos = 20.0 + np.cumsum(rng.normal(scale=sigma, size=(T, N, 3)), axis=0)
+    u = mdhelper_amd.ArrayUniverse(pos, [40.0, 40.0, 40.0, 90, 90, 90], dt=2.0,
+                                   charges=np.r_[np.ones(sizes[0]), -np.ones(sizes[1])])
+    return u, pos.astype(np.float32).astype(np.float64)
+
+
+def _onsager_ref(pos, sizes, n_blocks, dims=(40.0, 40.0, 40.0)):
+    """Restatement of Onsager._conclude (reference transport.py:1016-1059) on the oracle."""
+    T = (pos.shape[0] // n_blocks) * n_blocks
+    pos = pos[:T]
+    slices, idx = [], 0
+    for n in sizes:
+        slices.append(slice(idx, idx + n))
+        idx += n
+    g = len(sizes)
+    pairs = [(i, j) for i in range(g) for j in range(i, g)]
+    cross = np.empty((len(pairs), n_blocks, T // n_blocks))
+    self_ = np.empty((g, n_blocks, T // n_blocks))
+    for i, (i1, i2) in enumerate(pairs):
+        p1 = pos[:, slices[i1]].reshape(n_blocks, -1, sizes[i1], 3)
+        if i1 == i2:
+            cross[i] = oc.msd_fft_ref(p1.sum(axis=2), axis=1)
+            self_[i1] = oc.msd_fft_ref(p1, axis=1, average=False).sum(axis=-1) / sizes[i1]
+        else:
+            p2 = pos[:, slices[i2]].reshape(n_blocks, -1, sizes[i2], 3)
+            cross[i] = oc.msd_fft_ref(p1.sum(axis=2), p2.sum(axis=2), axis=1)
+    return cross / 6, self_ / 6
+
+
+@pytest.mark.parametrize("n_blocks", [1, 4])
+def test_onsager_matches_reference_driver(n_blocks):
+    u, pos = _random_walk_universe()
+    groups = (u.atoms[:30], u.atoms[30:])
+    ons = Onsager(groups, temperature=1.0, reduced=True, n_blocks=n_blocks).run()
+    cross, self_ = _onsager_ref(pos, (30, 20), n_blocks)
+    assert ons.results.pairs == ((0, 0), (0, 1), (1, 1))
+    assert np.allclose(ons.results.times, 2.0 * np.arange(400 // n_blocks))
+    assert np.allclose(ons.results.msd_self, self_, rtol=1e-6, atol=1e-8)
+    assert np.allclose(ons.results.msd_cross, cross, rtol=1e-6, atol=1e-7)
+    # physics: MSD(m)/6 = sigma^2 m / 2 for a free walk
+    m = np.arange(1, 20)
+    assert np.allclose(ons.results.msd_self[0, 0, 1:20], 0.01 * m / 2, rtol=0.25)
+    # direct definition agrees with the FFT route (reference test_algorithm_correlation.py:410-436)
+    direct = Onsager(groups, temperature=1.0, reduced=True, n_blocks=n_blocks, fft=False).run(stop=120)
+    fftrun = Onsager(groups, temperature=1.0, reduced=True, n_blocks=n_blocks).run(stop=120)
+    assert np.allclose(direct.results.msd_self, fftrun.results.msd_self, rtol=1e-6, atol=1e-8)
+    assert np.allclose(direct.results.msd_cross, fftrun.results.msd_cross, rtol=1e-6, atol=1e-7)
+    ons.calculate_transport_coefficients(start=1, stop=60, scale="linear")
+    ons.calculate_conductivity()
+    ons.calculate_electrophoretic_mobility()
+    ons.calculate_transference_number()
+    assert ons.results.L_ij.shape == (n_blocks, 2, 2) and np.isfinite(ons.results.D_i).all()
+    assert np.allclose(ons.results.transference_numbers.sum(axis=-1), 1)
+
+
+def test_onsager_blocks_warning_center_and_unwrap():
+    u, pos = _random_walk_universe(T=103)
+    with pytest.warns(UserWarning):
+        ons = Onsager(u.atoms, temperature=1.0, reduced=True, n_blocks=4).run()
+    cross, self_ = _onsager_ref(pos, (50,), 4)
+    assert np.allclose(ons.results.msd_self, self_, rtol=1e-6, atol=1e-8)
+    # centre-of-mass removal (per-frame path)
+    cen = Onsager(u.atoms, temperature=1.0, reduced=True, center=True).run()
+    centred = pos - pos.mean(axis=1, keepdims=True)
+    _, self_c = _onsager_ref(centred, (50,), 1)
+    assert np.allclose(cen.results.msd_self, self_c, rtol=1e-5, atol=1e-7)
+    # wrapped input + unwrap=True recovers the unwrapped answer
+    L = 40.0
+    rng = np.random.default_rng(9)
+    true = 20.0 + np.cumsum(rng.normal(scale=1.0, size=(150, 12, 3)), axis=0)
+    wrapped = np.mod(true, L)
+    uw = mdhelper_amd.ArrayUniverse(wrapped, [L, L, L, 90, 90, 90])
+    ut = mdhelper_amd.ArrayUniverse(true, [L, L, L, 90, 90, 90])
+    a = Onsager(uw.atoms, temperature=1.0, reduced=True, unwrap=True).run()
+    b = Onsager(ut.atoms, temperature=1.0, reduced=True).run()
+    assert np.allclose(a.results.msd_self, b.results.msd_self, rtol=1e-3, atol=1e-3)
+
+
+def test_zero_dimension_is_dropped():
+    u, pos = _random_walk_universe(T=90)
+    ons = Onsager(u.atoms, temperature=1.0, reduced=True, dimensions=[40.0, 40.0, 0.0]).run()
+    p = pos.copy()
+    p[..., 2] = 0
+    ref = oc.msd_fft_ref(p[None], axis=1, average=False).sum(axis=-1) / 50 / 4
+    assert np.allclose(ons.results.msd_self[0], ref, rtol=1e-6, atol=1e-8)
+
+
+def test_save_roundtrip(tmp_path):
+    frames, L = lj_melt(F=3)
+    u = mdhelper_amd.ArrayUniverse(frames, [L, L, L, 90, 90, 90])
+    rdf = RadialDistributionFunction(u.atoms, n_bins=20, range=(0.0, 4.0), exclusion=(1, 1), parallel=True)
+    rdf.run(n_jobs=4, module="joblib")
+    rdf.save(str(tmp_path / "rdf"))
+    data = np.load(tmp_path / "rdf.npz")
+    assert np.array_equal(data["counts"], rdf.results.counts)

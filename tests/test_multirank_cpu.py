@@ -1,0 +1,151 @@
+"""
+World-size-2 tests of the sharded drivers on CPU (gloo): frames (RDF, S(q)) and
+particles (Onsager) shard across ranks and the accumulators meet in one
+all-reduce.  There is no GPU here, so the device engines are replaced — in this
+test only — by oracle-backed stand-ins with the same interface; what is under
+test is the host logic: the shard each rank takes, the reduction, and the
+bit-exact / 1e-6 agreement of the reduced result with a single-rank run.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleRdfEngine:
+    def __init__(self, edges, exclusion=None, **kw):
+        self.edges, self.exclusion = np.asarray(edges), exclusion
+        self.n_bins = len(edges) - 1
+        self._counts = np.zeros(self.n_bins, dtype=np.int64)
+
+    def accumulate(self, pos1, pos2=None, boxes=None):
+        from oracle.cbind import c_radial_histogram
+        pos1 = np.asarray(pos1)
+        for f in range(pos1.shape[0]):
+            p2 = pos1[f] if pos2 is None else np.asarray(pos2)[f]
+            c_radial_histogram(pos1[f], p2, self.n_bins, (self.edges[0], self.edges[-1]),
+                               None if boxes is None else np.asarray(boxes)[f],
+                               exclusion=self.exclusion, counts=self._counts, n_threads=1)
+
+    def counts(self):
+        return self._counts.copy()
+
+    def close(self):
+        pass
+
+
+class OracleSqEngine:
+    def __init__(self, wavevectors, group_sizes, pairs, **kw):
+        self.q, self.sizes, self.pairs = np.asarray(wavevectors), list(group_sizes), pairs
+        self._acc = np.zeros((len(pairs), len(self.q)))
+
+    def accumulate(self, pos):
+        from oracle import fourier as of
+        slices, idx = [], 0
+        for n in self.sizes:
+            slices.append(slice(idx, idx + n))
+            idx += n
+        mode = None if self.pairs[0][0] is None else "partial"
+        for f in range(len(pos)):
+            self._acc += of.ssf_frame_ref(self.q, np.asarray(pos[f], dtype=np.float64), slices, self.pairs, mode)
+
+    def result(self):
+        return self._acc.copy()
+
+    def close(self):
+        pass
+
+
+class OracleMsdEngine:
+    def __init__(self, t_block, n_blocks, n_groups, **kw):
+        self.tb, self.b, self.g = t_block, n_blocks, n_groups
+        self._msd = np.zeros((n_groups, n_blocks, t_block))
+        self._traj = np.zeros((n_groups, n_blocks, t_block, 3))
+
+    def push(self, group, positions, first, count, zero_dims=0):
+        from oracle import correlation as oc
+        p = np.asarray(positions)[:self.tb * self.b, first:first + count].reshape(self.b, self.tb, count, 3).copy()
+        for k in range(3):
+            if (zero_dims >> k) & 1:
+                p[..., k] = 0
+        self._msd[group] += oc.msd_fft_ref(p, axis=1, average=False).sum(axis=-1)
+        self._traj[group] += p.sum(axis=2)
+
+    def result(self, want_msd=True):
+        return self._msd.copy(), self._traj.copy()
+
+    def close(self):
+        pass
+
+
+def _install_stand_ins():
+    from mdhelper_amd import _core
+    from mdhelper_amd.algorithm import correlation
+    from oracle import correlation as oc
+    _core.RdfEngine, _core.SqEngine, _core.MsdEngine = OracleRdfEngine, OracleSqEngine, OracleMsdEngine
+    correlation.msd_fft = oc.msd_fft_ref
+
+
+def _build_inputs():
+    rng = np.random.default_rng(21)
+    L = np.float32(14.0)
+    frames = (rng.random((9, 300, 3)) * L).astype(np.float32)
+    walk = 7.0 + np.cumsum(rng.normal(scale=0.2, size=(60, 25, 3)), axis=0)
+    return frames, L, walk
+
+
+def _analyses(comm):
+    import mdhelper_amd
+    from mdhelper_amd.analysis import Onsager, RadialDistributionFunction, StructureFactor
+    frames, L, walk = _build_inputs()
+    u = mdhelper_amd.ArrayUniverse(frames, [L, L, L, 90, 90, 90])
+    rdf = RadialDistributionFunction(u.atoms, n_bins=40, range=(0.0, 6.0), exclusion=(1, 1), comm=comm).run()
+    slow = RadialDistributionFunction(u.atoms[:100], u.atoms[100:], n_bins=40, range=(0.0, 6.0),
+                                      groupings="residues", comm=comm).run()
+    sf = StructureFactor((u.atoms[:120], u.atoms[120:]), mode="partial", n_points=3, comm=comm).run()
+    uw = mdhelper_amd.ArrayUniverse(walk, [14.0, 14.0, 14.0, 90, 90, 90])
+    ons = Onsager((uw.atoms[:15], uw.atoms[15:]), temperature=1.0, reduced=True, n_blocks=2, comm=comm).run()
+    return {"counts": rdf.results.counts, "rdf": rdf.results.rdf, "counts_slow": slow.results.counts,
+            "ssf": sf.results.ssf, "msd_self": ons.results.msd_self, "msd_cross": ons.results.msd_cross}
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _install_stand_ins()
+    from mdhelper_amd.comm import TorchDistComm
+    res = _analyses(TorchDistComm())
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _single(rank, out_dir):
+    sys.path.insert(0, ROOT)
+    _install_stand_ins()
+    from mdhelper_amd.comm import SerialComm
+    np.savez(os.path.join(out_dir, "single.npz"), **_analyses(SerialComm()))
+
+
+def test_world_size_2_matches_single_rank(tmp_path):
+    # stand-ins are installed in child processes only, never in the pytest process
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_single, args=(str(tmp_path),), nprocs=1, join=True)
+    single = np.load(tmp_path / "single.npz")
+    for rank in range(2):
+        got = np.load(tmp_path / f"rank{rank}.npz")
+        assert np.array_equal(got["counts"], single["counts"])            # integer sums: bit-exact
+        assert np.array_equal(got["counts_slow"], single["counts_slow"])
+        assert np.allclose(got["rdf"], single["rdf"], rtol=1e-12)
+        assert np.allclose(got["ssf"], single["ssf"], rtol=1e-9, atol=1e-12)
+        assert np.allclose(got["msd_self"], single["msd_self"], rtol=1e-9, atol=1e-12)
+        assert np.allclose(got["msd_cross"], single["msd_cross"], rtol=1e-9, atol=1e-10)
+    assert single["counts"].sum() > 0
