@@ -156,12 +156,19 @@ def bench_rdf(args, world, wide=False):
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "kernel": "rdf_tile_kernel", "kernel_ms_per_launch": st["kernel_ms"] / launches,
+            "kernel": "rdf_cell_pair_kernel (algo cell/auto) or rdf_tile_kernel (exact/filter)",
+            "kernel_ms_per_launch": st["kernel_ms"] / launches,
             "algorithmic_bytes_per_launch": alg_bytes_per_launch,
             "note": "O(N^2) arithmetic on O(N) bytes: the kernel is VALU/LDS-atomic bound, see 'valu'",
             "valu": {
-                "ordered_pairs_per_sec_kernel": pairs_eval_rate,
-                "exact_path_fraction": st["pairs_exact"] / max(st["pairs_evaluated"], 1),
+                "ordered_pairs_covered_per_sec_kernel": pairs_eval_rate,
+                "distance_evaluations_per_sec_kernel": st["pairs_computed"] / kernel_s if kernel_s > 0 else 0.0,
+                "evaluated_fraction_of_pair_space": st["pairs_computed"] / max(st["pairs_evaluated"], 1),
+                "exact_path_fraction_of_evaluations": st["pairs_exact"] / max(st["pairs_computed"], 1),
+                "image_search_path_fraction": st["cell_units_general"] / max(st["cell_units"], 1),
+                # 7 float32 VALU instructions per evaluation in the culled inner loop
+                "fp32_valu_frac_est": (st["pairs_computed"] / kernel_s * 7 * 2 / 1e12 / FP32_VALU_PEAK_TFLOPS)
+                if kernel_s > 0 else 0.0,
             },
         },
     }
@@ -177,7 +184,8 @@ def cpu_baseline_rdf(args, traj, box, edges, rng, n_bins, N, eng):
     """C oracle (OpenMP, all host cores) on a bounded sample of the same frames + parity check."""
     from mdhelper_amd import _core
     from oracle import cbind
-    threads = max(1, len(os.sched_getaffinity(0)))
+    # one GPU's share of the host (16 cores on the bench boxes) unless told otherwise
+    threads = int(os.environ.get("MDX_CPU_THREADS", min(16, max(1, len(os.sched_getaffinity(0))))))
     frames = traj.to_host(0, 1)
     t0 = time.perf_counter()
     c0 = cbind.c_radial_histogram(frames[0], frames[0], n_bins, rng, box, exclusion=(1, 1),

@@ -119,11 +119,16 @@ int mdx_rdf_synchronize(mdx_rdf_t h);
 /* Sum the counts of every rank's handle (one RCCL all-reduce, uint64 sum). */
 int mdx_rdf_allreduce(mdx_rdf_t h, mdx_comm_t comm);
 /* Timing / statistics of the pair kernel, measured with HIP events on the
- * handle's stream: launches since reset, total milliseconds, pair distances
- * evaluated, pairs re-evaluated by the exact path.  Any pointer may be NULL. */
+ * handle's stream: launches since reset, total milliseconds, ordered pairs
+ * covered (frames * n1 * n2), pairs re-evaluated by the exact path, and distance
+ * evaluations actually executed (after symmetry and tile culling, padding
+ * included).  Any pointer may be NULL. */
 int mdx_rdf_stats(mdx_rdf_t h, int64_t *launches, double *kernel_ms,
-                  int64_t *pairs_evaluated, int64_t *pairs_exact);
+                  int64_t *pairs_evaluated, int64_t *pairs_exact, int64_t *pairs_computed);
 int mdx_rdf_enable_timing(mdx_rdf_t h, int on);
+/* Raw device counters since reset: [0] exact re-evaluations, [1] (64 x 16)-pair units run by
+ * the cell kernel, [2] units on its per-pair image-search path, [3] brute-force evaluations. */
+int mdx_rdf_debug_counters(mdx_rdf_t h, int64_t out[4]);
 
 /* Function-level drop-in for structure.radial_histogram (structure.py:32-104):
  * one frame, host buffers, counts overwritten. */

@@ -206,10 +206,13 @@ class RdfEngine(_Engine):
         check(lib().mdx_rdf_allreduce(self.handle, comm.handle))
 
     def stats(self):
-        n, ms, pe, px = c_int64(), c_double(), c_int64(), c_int64()
-        check(lib().mdx_rdf_stats(self.handle, byref(n), byref(ms), byref(pe), byref(px)))
+        n, ms, pe, px, pc = c_int64(), c_double(), c_int64(), c_int64(), c_int64()
+        check(lib().mdx_rdf_stats(self.handle, byref(n), byref(ms), byref(pe), byref(px), byref(pc)))
+        raw = np.zeros(4, dtype=np.int64)
+        check(lib().mdx_rdf_debug_counters(self.handle, _ptr(raw)))
         return {"launches": n.value, "kernel_ms": ms.value, "pairs_evaluated": pe.value,
-                "pairs_exact": px.value}
+                "pairs_exact": px.value, "pairs_computed": pc.value,
+                "cell_units": int(raw[1]), "cell_units_general": int(raw[2])}
 
 
 def radial_histogram_device(pos1, pos2, n_bins, edges, dims, exclusion=None, dev=0):

@@ -60,8 +60,10 @@ _SIGNATURES = {
     "mdx_rdf_counts": (c_int, [_vp, _vp]),
     "mdx_rdf_synchronize": (c_int, [_vp]),
     "mdx_rdf_allreduce": (c_int, [_vp, _vp]),
-    "mdx_rdf_stats": (c_int, [_vp, POINTER(c_int64), POINTER(c_double), POINTER(c_int64), POINTER(c_int64)]),
+    "mdx_rdf_stats": (c_int, [_vp, POINTER(c_int64), POINTER(c_double), POINTER(c_int64), POINTER(c_int64),
+                              POINTER(c_int64)]),
     "mdx_rdf_enable_timing": (c_int, [_vp, c_int]),
+    "mdx_rdf_debug_counters": (c_int, [_vp, _vp]),
     "mdx_radial_histogram": (c_int, [c_int, _vp, c_int64, _vp, c_int64, c_int, _vp, _vp, c_int64, c_int64, _vp]),
     # structure factor
     "mdx_sq_create": (c_int, [POINTER(_vp), c_int, _vp, c_int64, _vp, c_int, _vp, c_int]),

@@ -30,6 +30,7 @@
 #include "mdx_common.hpp"
 #include "mdx_internal.hpp"
 #include "mdx_rdf_device.hpp"
+#include "mdx_rdf_cell.hpp"
 
 #include <cmath>
 
@@ -226,8 +227,11 @@ struct mdx_rdf {
     int algo = MDX_RDF_ALGO_AUTO;
     int n_rep = 32;
     DeviceBuffer d_thresh, d_counts, d_total, d_pack1, d_pack2, d_stage1, d_stage2, d_boxes, d_misc;
+    DeviceBuffer d_pw1, d_po1, d_bb1, d_pw2, d_po2, d_bb2;   // cell path: sorted copies + tile boxes
+    DeviceBuffer d_bb16_1, d_bb16_2;                         // boxes of the 16-particle chunks
     StreamTimer timer;
-    int64_t pairs_evaluated = 0;
+    int64_t pairs_evaluated = 0;    // ordered pair space covered: frames * n1 * n2
+    int64_t pairs_bruteforce = 0;   // distance evaluations executed by the brute-force tiles
     bool reduced_global = false;   // counts replica 0 holds an all-reduced total
 };
 
@@ -281,6 +285,98 @@ static int launch_tiles(mdx_rdf *h, RdfArgs &a, int mode, int ipt, bool pbc, boo
     return MDX_OK;
 }
 
+// Cell-sorted path (mdx_rdf_cell.hpp): sort + tile boxes per frame, then the culled pair kernel.
+static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const float *d_pos2,
+                           int64_t n2, const float *d_boxes, int64_t n_frames, bool self, bool excl)
+{
+    const int64_t n1p = ceil_div(n1, 128) * 128, n2p = ceil_div(n2, 128) * 128;
+    // per frame: wrapped + original float4 copies and one box per 64 particles
+    const int64_t per_frame = (32 + 3) * (n1p + (self ? 0 : n2p));
+    int64_t slab = std::max<int64_t>(1, (int64_t(1) << 30) / per_frame);
+    slab = std::min<int64_t>(std::min<int64_t>(slab, 32768), n_frames);
+    MDX_TRY(h->d_pw1.ensure(size_t(16) * n1p * slab));
+    MDX_TRY(h->d_po1.ensure(size_t(16) * n1p * slab));
+    MDX_TRY(h->d_bb1.ensure(size_t(32) * (n1p / 64) * slab));
+    MDX_TRY(h->d_bb16_1.ensure(size_t(32) * (n1p / 16) * slab));
+    if (!self) {
+        MDX_TRY(h->d_bb16_2.ensure(size_t(32) * (n2p / 16) * slab));
+        MDX_TRY(h->d_pw2.ensure(size_t(16) * n2p * slab));
+        MDX_TRY(h->d_po2.ensure(size_t(16) * n2p * slab));
+        MDX_TRY(h->d_bb2.ensure(size_t(32) * (n2p / 64) * slab));
+    }
+    unsigned *d_misc = h->d_misc.as<unsigned>();
+    hipLaunchKernelGGL(rdf_check_boxes_kernel, dim3((unsigned)ceil_div(n_frames, 256)), dim3(256), 0,
+                       h->stream, d_boxes, n_frames, d_misc + 1);
+
+    // LDS of the pair kernel: 4 wave slabs + thresholds + per-wave histograms
+    size_t base = sizeof(float4) * 256 + sizeof(double) * (h->n_bins + 1);
+    const size_t lds_budget = 64 * 1024;
+    int n_hist = 4;
+    while (n_hist > 1 && base + size_t(n_hist) * h->n_bins * 4 > lds_budget)
+        n_hist >>= 1;
+    size_t lds = base + size_t(n_hist) * h->n_bins * 4;
+    const bool gh = lds > lds_budget;
+    if (gh)
+        lds = sizeof(float4) * 256;
+    const bool lower = h->edges.front() > 0.0;
+    void (*kern)(CellArgs) = nullptr;
+#define MDX_CELL_PICK(E, L)                                               \
+    kern = gh ? rdf_cell_pair_kernel<E, L, true> : rdf_cell_pair_kernel<E, L, false>
+    if (excl && lower) MDX_CELL_PICK(true, true);
+    else if (excl) MDX_CELL_PICK(true, false);
+    else if (lower) MDX_CELL_PICK(false, true);
+    else MDX_CELL_PICK(false, false);
+#undef MDX_CELL_PICK
+
+    for (int64_t f0 = 0; f0 < n_frames; f0 += slab) {
+        const int64_t nf = std::min(slab, n_frames - f0);
+        hipLaunchKernelGGL(rdf_cell_sort_kernel, dim3((unsigned)nf), dim3(SORT_THREADS), 0, h->stream,
+                           d_pos1 + f0 * n1 * 3, d_boxes + f0 * 6, (int)n1, (int)n1p,
+                           excl ? h->excl1 : 0, h->d_pw1.as<float4>(), h->d_po1.as<float4>(),
+                           h->d_bb1.as<float4>(), h->d_bb16_1.as<float4>(), d_misc);
+        if (!self)
+            hipLaunchKernelGGL(rdf_cell_sort_kernel, dim3((unsigned)nf), dim3(SORT_THREADS), 0,
+                               h->stream, d_pos2 + f0 * n2 * 3, d_boxes + f0 * 6, (int)n2, (int)n2p,
+                               excl ? h->excl2 : 0, h->d_pw2.as<float4>(), h->d_po2.as<float4>(),
+                               h->d_bb2.as<float4>(), h->d_bb16_2.as<float4>(), d_misc);
+        CellArgs a{};
+        a.pw1 = h->d_pw1.as<float4>();
+        a.po1 = h->d_po1.as<float4>();
+        a.bb1 = h->d_bb1.as<float4>();
+        a.pw2 = self ? a.pw1 : h->d_pw2.as<float4>();
+        a.po2 = self ? a.po1 : h->d_po2.as<float4>();
+        a.bb2 = self ? a.bb1 : h->d_bb2.as<float4>();
+        a.bb16_2 = self ? h->d_bb16_1.as<float4>() : h->d_bb16_2.as<float4>();
+        a.tags_everywhere = (self && h->excl1 == 1 && h->excl2 == 1) ? 0 : 1;
+        a.boxes = d_boxes + f0 * 6;
+        a.thresh = h->d_thresh.as<double>();
+        a.counts = h->d_counts.as<unsigned long long>();
+        a.maxabs_bits = d_misc;
+        a.exact_counter = reinterpret_cast<unsigned long long *>(d_misc + 2);
+        a.tilepair_counter = reinterpret_cast<unsigned long long *>(d_misc + 4);
+        a.t_lo = h->t_lo;
+        a.t_hi = h->t_hi;
+        a.r0 = h->edges.front();
+        a.r1 = h->edges.back();
+        a.n1p = (int)n1p;
+        a.n2p = (int)n2p;
+        a.n_bins = h->n_bins;
+        a.n_hist = n_hist;
+        a.n_rep = h->n_rep;
+        a.self = self ? 1 : 0;
+        hipEvent_t ev = h->timer.begin();
+        for (int64_t g0 = 0; g0 < nf; g0 += 32768) {
+            a.frame0 = (int)g0;
+            dim3 grid((unsigned)(n1p / 128), (unsigned)std::min<int64_t>(32768, nf - g0));
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, h->stream, a);
+        }
+        h->timer.end(ev);
+        MDX_HIP(hipGetLastError());
+    }
+    h->pairs_evaluated += n_frames * n1 * n2;
+    return MDX_OK;
+}
+
 static int accumulate_device(mdx_rdf *h, const float *d_pos1, int64_t n1, const float *d_pos2,
                              int64_t n2, const float *d_boxes, int64_t n_frames)
 {
@@ -297,9 +393,15 @@ static int accumulate_device(mdx_rdf *h, const float *d_pos1, int64_t n1, const 
     const bool self = same && (!excl || h->excl1 == h->excl2);
     MDX_REQUIRE(n1 < (int64_t(1) << 30) && n2 < (int64_t(1) << 30), "too many particles");
 
-    int algo = h->algo == MDX_RDF_ALGO_AUTO ? MDX_RDF_ALGO_FILTER_F32 : h->algo;
+    // AUTO: cell-sorted culled tiles whenever there is a periodic box and enough particles
+    // for tiles to be compact; otherwise the brute-force tiles with the float32 filter.
+    int algo = h->algo;
+    if (algo == MDX_RDF_ALGO_AUTO)
+        algo = (d_boxes && std::max(n1, n2) >= 1024) ? MDX_RDF_ALGO_CELL : MDX_RDF_ALGO_FILTER_F32;
+    if (algo == MDX_RDF_ALGO_CELL && !d_boxes)
+        algo = MDX_RDF_ALGO_FILTER_F32;   // the cell grid is defined by the periodic box
     if (algo == MDX_RDF_ALGO_CELL)
-        algo = MDX_RDF_ALGO_FILTER_F32;   // cell path lives in mdx_rdf_cell.hip (round 1: same tiles)
+        return accumulate_cell(h, d_pos1, n1, d_pos2, n2, d_boxes, n_frames, self, excl);
     const int ipt = (std::max(n1, n2) >= 2048) ? 2 : 1;
     const int T = 256 * ipt;
     const int64_t n1p = ceil_div(n1, T) * T, n2p = ceil_div(n2, T) * T;
@@ -346,6 +448,8 @@ static int accumulate_device(mdx_rdf *h, const float *d_pos1, int64_t n1, const 
         a.maxabs_bits = d_misc;
         a.exact_counter = reinterpret_cast<unsigned long long *>(d_misc + 2);
         MDX_TRY(launch_tiles(h, a, algo, ipt, d_boxes != nullptr, excl, nf));
+        const int64_t tile_pairs = self ? int64_t(a.nt1) * (a.nt1 + 1) / 2 : int64_t(a.nt1) * a.nt2;
+        h->pairs_bruteforce += nf * tile_pairs * T * T;
     }
     h->pairs_evaluated += n_frames * n1 * n2;
     return MDX_OK;
@@ -414,7 +518,9 @@ int mdx_rdf_destroy(mdx_rdf_t h)
         (void)hipStreamSynchronize(h->stream);
     h->timer.destroy();
     for (DeviceBuffer *b : {&h->d_thresh, &h->d_counts, &h->d_total, &h->d_pack1, &h->d_pack2,
-                            &h->d_stage1, &h->d_stage2, &h->d_boxes, &h->d_misc})
+                            &h->d_stage1, &h->d_stage2, &h->d_boxes, &h->d_misc, &h->d_pw1,
+                            &h->d_po1, &h->d_bb1, &h->d_pw2, &h->d_po2, &h->d_bb2, &h->d_bb16_1,
+                            &h->d_bb16_2})
         b->release();
     if (h->stream)
         (void)hipStreamDestroy(h->stream);
@@ -433,6 +539,7 @@ int mdx_rdf_reset(mdx_rdf_t h)
     MDX_HIP(hipStreamSynchronize(h->stream));
     h->timer.reset();
     h->pairs_evaluated = 0;
+    h->pairs_bruteforce = 0;
     h->reduced_global = false;
     return MDX_OK;
 }
@@ -533,8 +640,15 @@ int mdx_rdf_counts(mdx_rdf_t h, int64_t *counts)
 }
 
 int mdx_rdf_stats(mdx_rdf_t h, int64_t *launches, double *kernel_ms, int64_t *pairs_evaluated,
-                  int64_t *pairs_exact)
+                  int64_t *pairs_exact, int64_t *pairs_computed)
 {
+    if (pairs_computed && h) {
+        // distance evaluations actually executed: brute-force tiles + culled cell tiles
+        unsigned long long tp = 0;
+        if (set_device(h->dev) == MDX_OK && hipStreamSynchronize(h->stream) == hipSuccess &&
+            hipMemcpy(&tp, h->d_misc.as<unsigned>() + 4, 8, hipMemcpyDeviceToHost) == hipSuccess)
+            *pairs_computed = h->pairs_bruteforce + (int64_t)tp * 64 * 16;
+    }
     MDX_REQUIRE(h, "NULL handle");
     MDX_TRY(set_device(h->dev));
     MDX_HIP(hipStreamSynchronize(h->stream));
@@ -547,6 +661,20 @@ int mdx_rdf_stats(mdx_rdf_t h, int64_t *launches, double *kernel_ms, int64_t *pa
         MDX_HIP(hipMemcpy(&v, h->d_misc.as<unsigned>() + 2, 8, hipMemcpyDeviceToHost));
         *pairs_exact = (int64_t)v;
     }
+    return MDX_OK;
+}
+
+int mdx_rdf_debug_counters(mdx_rdf_t h, int64_t out[4])
+{
+    MDX_REQUIRE(h && out, "NULL argument");
+    MDX_TRY(set_device(h->dev));
+    MDX_HIP(hipStreamSynchronize(h->stream));
+    unsigned long long raw[3] = {0, 0, 0};
+    MDX_HIP(hipMemcpy(raw, h->d_misc.as<unsigned>() + 2, sizeof(raw), hipMemcpyDeviceToHost));
+    out[0] = (int64_t)raw[0];   // pairs re-evaluated exactly
+    out[1] = (int64_t)raw[1];   // (64 i) x (16 j) units evaluated by the cell kernel
+    out[2] = (int64_t)raw[2];   // ... of which on the per-pair image-search path
+    out[3] = h->pairs_bruteforce;
     return MDX_OK;
 }
 

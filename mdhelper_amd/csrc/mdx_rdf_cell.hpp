@@ -1,0 +1,513 @@
+// mdx_rdf_cell.hpp — cell-sorted, tile-culled pair histogram (RDF algo "cell").
+//
+// Same result contract as mdx_rdf.hip (bin decisions bit-exact with the contract
+// arithmetic); what changes is which pairs are looked at and how cheaply.
+//
+//   rdf_cell_sort_kernel   one 1024-thread block per frame: wraps the particles into
+//        the box, counting-sorts them by cell (cells ~8 particles, ordered in 2x2x2
+//        bricks so that 64 consecutive particles form a compact blob), writes
+//        the sorted wrapped coordinates Pw (float4, w = exclusion tag), the sorted
+//        ORIGINAL coordinates Po (the contract arithmetic needs those) and one
+//        bounding box per 64-particle tile.  Everything in LDS, no global atomics.
+//   rdf_cell_pair_kernel   one 256-thread block per (frame, 128-particle i tile);
+//        each WAVE walks its share of the 64-particle j tiles on its own (no block
+//        barrier in the loop): 64 candidate j tiles are tested per instruction
+//        against the i tile's bounding box (minimum-image gap > r_max + error bound
+//        -> culled), survivors are staged into a wave-private LDS slab — already
+//        shifted by the tile pair's periodic image, so the inner loop has NO
+//        per-pair image search — and read back by broadcast, two i particles per
+//        lane.  Inner loop per pair: 3 sub, 1 mul, 2 fma, 1 compare (float32).
+//        Candidates take the same float32-filter / exact-fallback path as the
+//        FILTER kernel; the rare exact evaluation re-reads the original coordinates.
+//
+// Why the culled pairs can be skipped: the bounding boxes are those of the very
+// float32 wrapped coordinates the filter distance is computed from, the filter
+// distance is within `margin_d` of the contract distance, and a
+// tile pair is dropped only if its box gap exceeds r_max + margin_d + slack.
+#pragma once
+
+#include "mdx_rdf_device.hpp"
+
+struct CellArgs {
+    // per set (1 = i side, 2 = j side; identical pointers for a self histogram)
+    const float4 *pw1, *po1, *bb1;
+    const float4 *pw2, *po2, *bb2;
+    const float4 *bb16_2;        // boxes of the 16-particle chunks of the j side
+    const float *boxes;          // [frames][6]
+    const double *thresh;        // [n_bins+1]
+    unsigned long long *counts;  // [n_rep][n_bins]
+    const unsigned *maxabs_bits;
+    unsigned long long *exact_counter;
+    unsigned long long *tilepair_counter;   // (64 i) x (16 j) units actually evaluated
+    double t_lo, t_hi, r0, r1;
+    int n1p, n2p;                // padded particle counts (multiples of 128)
+    int n_bins, n_hist, n_rep;
+    int self, frame0;
+    int tags_everywhere;         // 0: exclusion tags can only collide inside the diagonal tiles
+};
+
+constexpr int CELL_MAX = 16384;   // cells per frame (64 KiB of LDS counters)
+constexpr int SORT_THREADS = 1024;
+constexpr int CELL_QCAP = 2048;   // surviving j tiles queued per round of the pair kernel
+
+struct CellGrid {
+    int nc[3];
+    float Lf[3];
+    double Ld[3], invLd[3];
+    __device__ inline void init(const float *box, int n)
+    {
+        double vol = 1.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            Lf[k] = box[k];
+            Ld[k] = (double)box[k];
+            invLd[k] = 1.0 / Ld[k];
+            vol *= Ld[k];
+        }
+        // ~8 particles per cell, an even number of cells per dimension (2x2x2 bricks)
+        double cell = cbrt(8.0 * vol / (double)max(n, 1));
+        int total = 1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            int c = 2 * (int)rint(0.5 * Ld[k] / cell);
+            nc[k] = min(max(c, 2), 64);
+            total *= nc[k];
+        }
+        while (total > CELL_MAX) {   // shrink the largest dimension until the table fits
+            int k = (nc[0] >= nc[1] && nc[0] >= nc[2]) ? 0 : (nc[1] >= nc[2] ? 1 : 2);
+            total = total / nc[k] * (nc[k] - 2);
+            nc[k] -= 2;
+        }
+    }
+    __device__ inline int n_cells() const { return nc[0] * nc[1] * nc[2]; }
+    // wrapped coordinate in [0, L] (one float32 rounding of the exact wrap) and its cell
+    __device__ inline float wrap(float x, int k, int &c) const
+    {
+        double xd = (double)x;
+        double wd = xd - Ld[k] * floor(xd * invLd[k]);
+        float w = (float)wd;
+        c = min(max((int)(wd * invLd[k] * nc[k]), 0), nc[k] - 1);
+        return w;
+    }
+    __device__ inline int key(int cx, int cy, int cz) const
+    {
+        // bricks of 2x2x2 cells; the bricks follow a serpentine (boustrophedon) path through
+        // the grid so that consecutive bricks are always face neighbours — no jump from the
+        // end of one column to the start of the next, which would give a tile a box-long extent
+        int bx = cx >> 1, by = cy >> 1, bz = cz >> 1;
+        const int nby = nc[1] >> 1, nbz = nc[2] >> 1;
+        if (bx & 1)
+            by = nby - 1 - by;
+        if ((bx * nby + by) & 1)
+            bz = nbz - 1 - bz;
+        int brick = (bx * nby + by) * nbz + bz;
+        return (brick << 3) | ((cx & 1) << 2) | ((cy & 1) << 1) | (cz & 1);
+    }
+};
+
+__global__ __launch_bounds__(SORT_THREADS) void rdf_cell_sort_kernel(
+    const float *__restrict__ pos, const float *__restrict__ boxes, int n, int n_pad, int64_t excl,
+    float4 *__restrict__ pw, float4 *__restrict__ po, float4 *__restrict__ bb,
+    float4 *__restrict__ bb16, unsigned *maxabs_bits)
+{
+    __shared__ unsigned cnt[CELL_MAX];
+    __shared__ unsigned part[SORT_THREADS];
+    const int tid = threadIdx.x;
+    const int frame = blockIdx.x;
+    const float *P = pos + int64_t(frame) * n * 3;
+    float4 *PW = pw + int64_t(frame) * n_pad;
+    float4 *PO = po + int64_t(frame) * n_pad;
+    CellGrid g;
+    g.init(boxes + int64_t(frame) * 6, n);
+    const int ncell = g.n_cells();
+
+    for (int c = tid; c < ncell; c += SORT_THREADS)
+        cnt[c] = 0u;
+    __syncthreads();
+
+    float m = 0.0f;
+    for (int a = tid; a < n; a += SORT_THREADS) {
+        float x = P[3 * a], y = P[3 * a + 1], z = P[3 * a + 2];
+        int cx, cy, cz;
+        g.wrap(x, 0, cx);
+        g.wrap(y, 1, cy);
+        g.wrap(z, 2, cz);
+        atomicAdd(&cnt[g.key(cx, cy, cz)], 1u);
+        float am = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+        m = fmaxf(m, am == am ? am : __int_as_float(0x7f800000));
+    }
+    {
+        unsigned bits = __float_as_uint(m);
+        for (int off = 32; off > 0; off >>= 1)
+            bits = max(bits, (unsigned)__shfl_xor((int)bits, off));
+        if ((tid & 63) == 0 && bits)
+            atomicMax(maxabs_bits, bits);
+    }
+    __syncthreads();
+
+    // exclusive scan of cnt[0..ncell): each thread owns a contiguous run
+    const int per = (ncell + SORT_THREADS - 1) / SORT_THREADS;
+    const int c0 = tid * per, c1 = min(c0 + per, ncell);
+    unsigned local = 0;
+    for (int c = c0; c < c1; ++c)
+        local += cnt[c];
+    part[tid] = local;
+    __syncthreads();
+    for (int off = 1; off < SORT_THREADS; off <<= 1) {
+        unsigned v = (tid >= off) ? part[tid - off] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    unsigned run = part[tid] - local;
+    for (int c = c0; c < c1; ++c) {
+        unsigned v = cnt[c];
+        cnt[c] = run;
+        run += v;
+    }
+    __syncthreads();
+
+    // scatter: the cursor of a cell hands out its slots
+    for (int a = tid; a < n; a += SORT_THREADS) {
+        float x = P[3 * a], y = P[3 * a + 1], z = P[3 * a + 2];
+        int cx, cy, cz;
+        float wx = g.wrap(x, 0, cx), wy = g.wrap(y, 1, cy), wz = g.wrap(z, 2, cz);
+        unsigned slot = atomicAdd(&cnt[g.key(cx, cy, cz)], 1u);
+        float tag = __int_as_float(excl > 0 ? int(int64_t(a) / excl) : a);
+        PW[slot] = make_float4(wx, wy, wz, tag);
+        PO[slot] = make_float4(x, y, z, tag);
+    }
+    const float qnan = __int_as_float(0x7fc00000);
+    for (int a = n + tid; a < n_pad; a += SORT_THREADS) {
+        PW[a] = make_float4(qnan, qnan, qnan, __int_as_float(-1));
+        PO[a] = make_float4(qnan, qnan, qnan, __int_as_float(-1));
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // bounding boxes (of the float32 wrapped coordinates): one per 16-particle chunk,
+    // one per 64-particle tile
+    const int lane = tid & 63, wave = tid >> 6;
+    const int n_tiles = n_pad / 64;
+    float4 *BB = bb + int64_t(frame) * n_tiles * 2;
+    float4 *BB16 = bb16 + int64_t(frame) * n_tiles * 8;
+    for (int t = wave; t < n_tiles; t += SORT_THREADS / 64) {
+        float4 v = PW[t * 64 + lane];
+        const float inf = __int_as_float(0x7f800000);
+        bool ok = v.x == v.x;
+        float lo[3] = {ok ? v.x : inf, ok ? v.y : inf, ok ? v.z : inf};
+        float hi[3] = {ok ? v.x : -inf, ok ? v.y : -inf, ok ? v.z : -inf};
+        for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
+                hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
+            }
+            if (off == 8 && (lane & 15) == 0) {
+                BB16[(t * 4 + (lane >> 4)) * 2] = make_float4(lo[0], lo[1], lo[2], 0.f);
+                BB16[(t * 4 + (lane >> 4)) * 2 + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+            }
+        }
+        if (lane == 0) {
+            BB[2 * t] = make_float4(lo[0], lo[1], lo[2], 0.f);
+            BB[2 * t + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+        }
+    }
+}
+
+// Exact re-evaluation of one pair with the contract arithmetic on the ORIGINAL coordinates.
+template <typename Hist>
+__device__ inline void cell_pair_exact(const PairCtx<true> &c, const CellArgs &a,
+                                             const double *sT, const Hist &hist, const float4 *po_i,
+                                             const float4 *po_j, unsigned w)
+{
+    double rsq = rdf_rsq_contract<true>(c, *po_i, *po_j);
+    if ((rsq >= a.t_lo) && (rsq < a.t_hi))
+        hist.add(rdf_bin_exact(rsq, sT, a.n_bins, c.r0f, c.inv_wf), w);
+}
+
+// One float32 distance evaluation + binning.  The bin arithmetic is unconditional (after
+// culling nearly every wave step holds a candidate, so a branch around it would always be
+// taken); only the histogram add is predicated and only the rare uncertain pair branches.
+// TAGS: 0 no exclusion, 1 compare exclusion tags.
+template <bool LOWER, int TAGS, typename Hist>
+__device__ inline void cell_step(const PairCtx<true> &c, const CellArgs &a, const double *sT,
+                                 const Hist &hist, float fx, float fy, float fz, int tag_i,
+                                 int tag_j, float pos0, float sure_half, const float4 *po_i,
+                                 const float4 *po_j, unsigned w, unsigned &n_exact)
+{
+    float r2 = __fmaf_rn(fz, fz, __fmaf_rn(fy, fy, fx * fx));
+    // pos = (sqrt(r2) - r0) / width; raw v_sqrt_f32 (a denormal r2 ends on the exact path)
+    float pos = __fmaf_rn(__builtin_amdgcn_sqrtf(r2), c.inv_wf, pos0);
+    float kf = floorf(pos);
+    bool cand = LOWER ? (r2 < c.cand_hi && r2 >= c.cand_lo) : (r2 < c.cand_hi);
+    // farther than eta from both neighbouring edges (covers both range ends)
+    bool sure = fabsf((pos - kf) - 0.5f) < sure_half;
+    if (TAGS)
+        cand = cand && (tag_i != tag_j);
+    // wave-uniform test first: the cold block then sits out of line and the hot path falls through
+    if (__builtin_expect(__ballot(cand && !sure) != 0ull, 0)) {
+        if (cand && !sure) {
+            ++n_exact;
+            cell_pair_exact(c, a, sT, hist, po_i, po_j, w);
+        }
+    }
+    if (cand && sure)
+        hist.add((int)kf, w);
+}
+
+template <bool EXCL, bool LOWER, bool GH>
+__global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    float4 *sJ = reinterpret_cast<float4 *>(smem_raw);                        // [4 waves][64]
+    double *sT = reinterpret_cast<double *>(smem_raw + sizeof(float4) * 256); // [n_bins+1]
+    unsigned *sh = reinterpret_cast<unsigned *>(sT + (a.n_bins + 1));         // [n_hist][n_bins]
+    __shared__ unsigned s_exact, s_units, s_general, s_qn, s_qnext;
+    __shared__ unsigned sQ[CELL_QCAP];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frame = blockIdx.y + a.frame0;
+    const int I = blockIdx.x;                       // 128-particle i tile = two 64-particle halves
+    const int t64_2 = a.n2p / 64;
+
+    if (!GH) {
+        for (int b = tid; b <= a.n_bins; b += 256)
+            sT[b] = a.thresh[b];
+        for (int b = tid; b < a.n_hist * a.n_bins; b += 256)
+            sh[b] = 0u;
+    }
+    if (tid == 0) {
+        s_exact = 0u;
+        s_units = 0u;
+        s_general = 0u;
+    }
+    __syncthreads();
+
+    PairCtx<true> ctx;
+    const float *box = a.boxes + int64_t(frame) * 6;
+    ctx.init(box, a.maxabs_bits, a.r0, a.r1, a.n_bins);
+    unsigned long long *out =
+        a.counts + int64_t((blockIdx.x + 7 * blockIdx.y) % a.n_rep) * a.n_bins;
+    const double *thr = GH ? a.thresh : sT;
+    HistLds hl{sh + (GH ? 0 : (wave % a.n_hist) * a.n_bins)};
+    HistGlobal hg{out};
+    const float pos0 = -ctx.r0f * ctx.inv_wf;
+    const float sure_half = 0.5f - ctx.eta;
+
+    const float4 *PW1 = a.pw1 + int64_t(frame) * a.n1p + int64_t(I) * 128;
+    const float4 *PO1 = a.po1 + int64_t(frame) * a.n1p + int64_t(I) * 128;
+    const float4 *PW2 = a.pw2 + int64_t(frame) * a.n2p;
+    const float4 *PO2 = a.po2 + int64_t(frame) * a.n2p;
+    const float4 *BB2 = a.bb2 + int64_t(frame) * t64_2 * 2;
+    const float4 *BB16 = a.bb16_2 + int64_t(frame) * t64_2 * 8;
+    const float4 p0 = PW1[lane], p1 = PW1[64 + lane];
+
+    // boxes of the two i halves and of their union
+    float cH[2][3], hH[2][3], cI[3], hI[3];
+    {
+        const float4 *BB1 = a.bb1 + int64_t(frame) * (a.n1p / 64) * 2 + int64_t(I) * 4;
+        float4 l0 = BB1[0], h0 = BB1[1], l1 = BB1[2], h1 = BB1[3];
+        const float lo0[3] = {l0.x, l0.y, l0.z}, hi0[3] = {h0.x, h0.y, h0.z};
+        const float lo1[3] = {l1.x, l1.y, l1.z}, hi1[3] = {h1.x, h1.y, h1.z};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            cH[0][k] = 0.5f * (lo0[k] + hi0[k]);
+            hH[0][k] = 0.5f * (hi0[k] - lo0[k]);
+            cH[1][k] = 0.5f * (lo1[k] + hi1[k]);
+            hH[1][k] = 0.5f * (hi1[k] - lo1[k]);
+            float lo = fminf(lo0[k], lo1[k]), hi = fmaxf(hi0[k], hi1[k]);
+            cI[k] = 0.5f * (lo + hi);
+            hI[k] = 0.5f * (hi - lo);
+        }
+    }
+    // a tile pair is culled when its box gap exceeds r1 + error bound + slack
+    const float Lmax = fmaxf(ctx.Lf[0], fmaxf(ctx.Lf[1], ctx.Lf[2]));
+    const float cut = sqrtf(ctx.cand_hi) + 1e-5f * Lmax;
+    const float cut2 = cut * cut;
+
+    float4 *sJw = sJ + wave * 64;
+    unsigned n_exact = 0, n_units = 0, n_general = 0;
+    const int Jbeg = a.self ? 2 * I : 0;
+    // Rounds of up to CELL_QCAP candidate j tiles: all four waves test candidates and append
+    // the survivors to one LDS queue, then pull tiles from it one at a time (LDS atomic), so
+    // the waves of a block stay evenly loaded whatever the spatial distribution of survivors.
+    for (int round0 = Jbeg; round0 < t64_2; round0 += CELL_QCAP) {
+        if (tid == 0) {
+            s_qn = 0u;
+            s_qnext = 0u;
+        }
+        __syncthreads();
+        const int round1 = min(t64_2, round0 + CELL_QCAP);
+        for (int Jb = round0; Jb < round1; Jb += 256) {
+            const int J = Jb + tid;
+            float g2 = __int_as_float(0x7f800000);
+            unsigned code = 0u;
+            if (J < round1) {
+                const float4 lo = BB2[2 * J], hi = BB2[2 * J + 1];
+                const float cJ[3] = {0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)};
+                const float hJ[3] = {0.5f * (hi.x - lo.x), 0.5f * (hi.y - lo.y), 0.5f * (hi.z - lo.z)};
+                g2 = 0.f;
+                int general = 0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    float d = cJ[k] - cI[k];
+                    float sft = rintf(d * ctx.invf[k]);
+                    d = __fmaf_rn(-sft, ctx.Lf[k], d);
+                    code |= unsigned((int)sft + 1) << (22 + 2 * k);
+                    float ext = hI[k] + hJ[k];
+                    float reach = fabsf(d) + ext;
+                    float gap = fmaxf(0.f, fabsf(d) - ext);
+                    g2 = __fmaf_rn(gap, gap, g2);
+                    // The shifted separation equals the minimum image for every pair whose
+                    // |separation| stays below L/2 (all of them when reach < L/2).  A pair beyond
+                    // L/2 is rejected by the filter (|sep| >= L/2 >= cut) and its true image
+                    // component is L - |sep| >= L - reach: when that exceeds the cut it is out
+                    // of range under the contract too, so the shifted value is harmless.
+                    const float halfL = 0.4999f * ctx.Lf[k];
+                    general |= !(reach < halfL) &&
+                               !(cut < halfL && reach < ctx.Lf[k] - cut - 1e-4f * ctx.Lf[k]);
+                }
+                code |= unsigned(J) | (unsigned(general) << 28);
+            }
+            const bool keep = g2 <= cut2;
+            const unsigned long long mask = __ballot(keep);
+            if (mask) {
+                unsigned base = 0;
+                if (lane == 0)
+                    base = atomicAdd(&s_qn, (unsigned)__popcll(mask));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (keep)
+                    sQ[base + __popcll(mask & ((1ull << lane) - 1ull))] = code;
+            }
+        }
+        __syncthreads();
+        const unsigned nq = s_qn;
+        while (true) {
+            unsigned e = 0;
+            if (lane == 0)
+                e = atomicAdd(&s_qnext, 1u);
+            e = __builtin_amdgcn_readfirstlane(e);
+            if (e >= nq)
+                break;
+            const unsigned code = sQ[e];
+            const int Jt = int(code & 0x3fffffu);
+            const int gen = int(code >> 28) & 1;
+            const float sx = float(int((code >> 22) & 3u) - 1) * ctx.Lf[0];
+            const float sy = float(int((code >> 24) & 3u) - 1) * ctx.Lf[1];
+            const float sz = float(int((code >> 26) & 3u) - 1) * ctx.Lf[2];
+            float4 pj = PW2[int64_t(Jt) * 64 + lane];
+            if (!gen) {
+                pj.x -= sx;
+                pj.y -= sy;
+                pj.z -= sz;
+            }
+            // second-level cull: lane l < 8 tests (16-particle chunk l>>1) x (i half l&1)
+            unsigned sub = 0xffu;
+            if (!gen) {
+                float sg2 = __int_as_float(0x7f800000);
+                if (lane < 8) {
+                    const int s = lane >> 1, h = lane & 1;
+                    const float4 lo = BB16[(Jt * 4 + s) * 2], hi = BB16[(Jt * 4 + s) * 2 + 1];
+                    const float cJ[3] = {0.5f * (lo.x + hi.x) - sx, 0.5f * (lo.y + hi.y) - sy,
+                                         0.5f * (lo.z + hi.z) - sz};
+                    const float hJ[3] = {0.5f * (hi.x - lo.x), 0.5f * (hi.y - lo.y), 0.5f * (hi.z - lo.z)};
+                    sg2 = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        float gap = fmaxf(0.f, fabsf(cJ[k] - cH[h][k]) - (hH[h][k] + hJ[k]));
+                        sg2 = __fmaf_rn(gap, gap, sg2);
+                    }
+                }
+                sub = (unsigned)__ballot(sg2 <= cut2) & 0xffu;
+            }
+            // wave-private slab: LDS operations of one wave execute in order
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            sJw[lane] = pj;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const bool diag = a.self && Jt <= 2 * I + 1;
+            const unsigned w = (a.self && !diag) ? 2u : 1u;
+            const float4 *POJ = PO2 + int64_t(Jt) * 64;
+            // exclusion tags can only collide inside the diagonal tiles when exclusion == (1, 1)
+            const bool tags = EXCL && (a.tags_everywhere || diag);
+            if (!gen) {
+                for (int s = 0; s < 4; ++s) {
+                    const unsigned bits = (sub >> (2 * s)) & 3u;
+                    if (!bits)
+                        continue;
+                    n_units += (bits & 1u) + (bits >> 1);
+#define MDX_CELL_ONE(TG, U0, U1, Q, JJ)                                                            \
+    if (GH) {                                                                                      \
+        if (U0) cell_step<LOWER, TG>(ctx, a, thr, hg, Q.x - p0.x, Q.y - p0.y, Q.z - p0.z, __float_as_int(p0.w), __float_as_int(Q.w), pos0, sure_half, PO1 + lane, POJ + (JJ), w, n_exact); \
+        if (U1) cell_step<LOWER, TG>(ctx, a, thr, hg, Q.x - p1.x, Q.y - p1.y, Q.z - p1.z, __float_as_int(p1.w), __float_as_int(Q.w), pos0, sure_half, PO1 + 64 + lane, POJ + (JJ), w, n_exact); \
+    } else {                                                                                       \
+        if (U0) cell_step<LOWER, TG>(ctx, a, thr, hl, Q.x - p0.x, Q.y - p0.y, Q.z - p0.z, __float_as_int(p0.w), __float_as_int(Q.w), pos0, sure_half, PO1 + lane, POJ + (JJ), w, n_exact); \
+        if (U1) cell_step<LOWER, TG>(ctx, a, thr, hl, Q.x - p1.x, Q.y - p1.y, Q.z - p1.z, __float_as_int(p1.w), __float_as_int(Q.w), pos0, sure_half, PO1 + 64 + lane, POJ + (JJ), w, n_exact); \
+    }
+// four slab entries are fetched ahead of their use so the LDS latency overlaps the arithmetic
+#define MDX_CELL_RUN(TG, U0, U1)                                                                   \
+    for (int jj = 16 * s; jj < 16 * s + 16; jj += 4) {                                             \
+        const float4 q0 = sJw[jj], q1 = sJw[jj + 1], q2 = sJw[jj + 2], q3 = sJw[jj + 3];           \
+        MDX_CELL_ONE(TG, U0, U1, q0, jj)                                                           \
+        MDX_CELL_ONE(TG, U0, U1, q1, jj + 1)                                                       \
+        MDX_CELL_ONE(TG, U0, U1, q2, jj + 2)                                                       \
+        MDX_CELL_ONE(TG, U0, U1, q3, jj + 3)                                                       \
+    }
+                    if (tags) {
+                        if (bits == 3u) { MDX_CELL_RUN(1, true, true) }
+                        else if (bits == 1u) { MDX_CELL_RUN(1, true, false) }
+                        else { MDX_CELL_RUN(1, false, true) }
+                    } else {
+                        if (bits == 3u) { MDX_CELL_RUN(0, true, true) }
+                        else if (bits == 1u) { MDX_CELL_RUN(0, true, false) }
+                        else { MDX_CELL_RUN(0, false, true) }
+                    }
+#undef MDX_CELL_RUN
+#undef MDX_CELL_ONE
+                }
+            } else {
+                // tile pair that straddles half a box: per-pair image search (float32), rare
+                n_units += 8;
+                n_general += 8;
+#pragma unroll 2
+                for (int jj = 0; jj < 64; ++jj) {
+                    float4 q = sJw[jj];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const float4 &p = u ? p1 : p0;
+                        float fx = q.x - p.x, fy = q.y - p.y, fz = q.z - p.z;
+                        fx = __fmaf_rn(-rintf(fx * ctx.invf[0]), ctx.Lf[0], fx);
+                        fy = __fmaf_rn(-rintf(fy * ctx.invf[1]), ctx.Lf[1], fy);
+                        fz = __fmaf_rn(-rintf(fz * ctx.invf[2]), ctx.Lf[2], fz);
+                        if (GH) cell_step<LOWER, EXCL ? 1 : 0>(ctx, a, thr, hg, fx, fy, fz, __float_as_int(p.w), __float_as_int(q.w), pos0, sure_half, PO1 + 64 * u + lane, POJ + jj, w, n_exact);
+                        else cell_step<LOWER, EXCL ? 1 : 0>(ctx, a, thr, hl, fx, fy, fz, __float_as_int(p.w), __float_as_int(q.w), pos0, sure_half, PO1 + 64 * u + lane, POJ + jj, w, n_exact);
+                    }
+                }
+            }
+        }
+        __syncthreads();   // the queue is reset by the next round
+    }
+    for (int off = 32; off > 0; off >>= 1)
+        n_exact += __shfl_xor((int)n_exact, off);
+    if (lane == 0) {
+        if (n_exact) atomicAdd(&s_exact, n_exact);
+        if (n_units) atomicAdd(&s_units, n_units);
+        if (n_general) atomicAdd(&s_general, n_general);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (s_exact) atomicAdd(a.exact_counter, (unsigned long long)s_exact);
+        if (s_units) atomicAdd(a.tilepair_counter, (unsigned long long)s_units);
+        if (s_general) atomicAdd(a.tilepair_counter + 1, (unsigned long long)s_general);
+    }
+    if (!GH) {
+        for (int b = tid; b < a.n_bins; b += 256) {
+            unsigned long long s = 0;
+            for (int h = 0; h < a.n_hist; ++h)
+                s += sh[h * a.n_bins + b];
+            if (s)
+                atomicAdd(out + b, s);
+        }
+    }
+}

@@ -44,9 +44,16 @@ template <bool PBC> struct PairCtx {
 
     __device__ inline void init(const RdfArgs &a, int frame)
     {
+        init(PBC ? a.boxes + int64_t(frame) * 6 : nullptr, a.maxabs_bits, a.r0, a.r1, a.n_bins);
+    }
+
+    // b: the frame's box (lx, ly, lz, ...) or nullptr without periodic boundaries
+    __device__ inline void init(const float *b, const unsigned *maxabs_bits, double r0, double r1,
+                                int n_bins)
+    {
+        struct { double r0, r1; int n_bins; const unsigned *maxabs_bits; } a{r0, r1, n_bins, maxabs_bits};
         double Lmax = 0.0;
         if (PBC) {
-            const float *b = a.boxes + int64_t(frame) * 6;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 Lf[k] = b[k];

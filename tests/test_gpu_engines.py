@@ -15,7 +15,7 @@ from oracle import fourier as of  # noqa: E402
 from oracle import rdf as orf  # noqa: E402
 from oracle.cbind import c_radial_histogram  # noqa: E402
 
-ALGOS = ["exact", "filter"]
+ALGOS = ["exact", "filter", "cell"]
 
 
 def _edges(n_bins, rng):
@@ -115,6 +115,46 @@ def test_rdf_half_box_separations(algo):
     want = c_radial_histogram(pos, pos, 50, (0.0, 10.0), dims)
     got = _gpu_hist(pos, None, 50, (0.0, 10.0), dims, None, algo)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("exclusion", [None, (1, 1), (4, 4)])
+def test_rdf_cell_culling_regime(exclusion):
+    """Enough particles and a short range: tiles are culled and take the shifted fast path."""
+    rng = np.random.default_rng(18)
+    dims = np.array([52.0, 47.5, 61.25, 90, 90, 90], dtype=np.float32)
+    pos = (rng.random((7000, 3)) * dims[:3]).astype(np.float32)
+    pos[:500] += dims[:3] * np.array([3, -2, 1], dtype=np.float32)     # unwrapped images
+    for rng_range, nb in [((0.0, 7.5), 201), ((1.0, 9.0), 64)]:
+        want = c_radial_histogram(pos, pos, nb, rng_range, dims, exclusion=exclusion)
+        eng = _core.RdfEngine(_edges(nb, rng_range), exclusion, algo="cell", timing=True)
+        eng.accumulate(pos, None, dims)
+        got = eng.counts()
+        st = eng.stats()
+        eng.close()
+        assert np.array_equal(got, want), (rng_range, nb)
+        # culling actually happened: far fewer distance evaluations than the pair space
+        assert 0 < st["pairs_computed"] < 0.5 * st["pairs_evaluated"]
+    # two different groups through the cell path
+    p2 = (rng.random((3000, 3)) * dims[:3]).astype(np.float32)
+    want = c_radial_histogram(pos, p2, 100, (0.0, 8.0), dims, exclusion=exclusion)
+    assert np.array_equal(_gpu_hist(pos, p2, 100, (0.0, 8.0), dims, exclusion, "cell"), want)
+
+
+def test_rdf_cell_random_walk_frames_match_filter():
+    """Synthetic bench-like frames: cell == filter == oracle on a few frames."""
+    L = 40.0
+    d = _core.synth_random_walk(4, 6400, [L, L, L], 0.3, seed=5)
+    frames = d.to_host()
+    d.free()
+    dims = np.array([L, L, L, 90, 90, 90], dtype=np.float32)
+    want = np.zeros(201, dtype=np.int64)
+    for f in range(4):
+        want += c_radial_histogram(frames[f], frames[f], 201, (0.0, 15.0), dims, exclusion=(1, 1))
+    for algo in ("cell", "filter", "auto"):
+        eng = _core.RdfEngine(_edges(201, (0.0, 15.0)), (1, 1), algo=algo)
+        eng.accumulate(frames, None, dims)
+        assert np.array_equal(eng.counts(), want), algo
+        eng.close()
 
 
 def test_rdf_reference_test_geometry():
