@@ -137,6 +137,15 @@ def bench_rdf(args, world, wide=False):
     alg_bytes_per_launch = F * (12 * N + 24)
     achieved = alg_bytes_per_launch * launches / kernel_s / 1e9 if kernel_s > 0 else 0.0
     pairs_eval_rate = st["pairs_evaluated"] / kernel_s if kernel_s > 0 else 0.0
+    # HBM bytes from the PMC counters come from a separate rocprofv3 run (profiles/traffic.json)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            per_frame = json.load(fh)["rdf_cell_pair_kernel"]["hbm_bytes_per_frame"]
+        if N == 32768 and not wide and args.algo in ("auto", "cell"):
+            traffic = per_frame * F * args.steps / launches
+    except (OSError, KeyError, ValueError):
+        pass
     out = {
         "metric": "pair-distances binned/sec",
         "value": binned / dt,
@@ -155,7 +164,7 @@ def bench_rdf(args, world, wide=False):
         "pairs_binned_per_frame": binned / max(frames_total, 1),
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "kernel": "rdf_cell_pair_kernel (algo cell/auto) or rdf_tile_kernel (exact/filter)",
             "kernel_ms_per_launch": st["kernel_ms"] / launches,
             "algorithmic_bytes_per_launch": alg_bytes_per_launch,

@@ -239,21 +239,27 @@ __device__ inline void cell_step(const PairCtx<true> &c, const CellArgs &a, cons
     float r2 = __fmaf_rn(fz, fz, __fmaf_rn(fy, fy, fx * fx));
     // pos = (sqrt(r2) - r0) / width; raw v_sqrt_f32 (a denormal r2 ends on the exact path)
     float pos = __fmaf_rn(__builtin_amdgcn_sqrtf(r2), c.inv_wf, pos0);
-    float kf = floorf(pos);
+    // v_fract_f32 = pos - floor(pos).  A sure candidate has pos > eta > 0 (the candidate window
+    // keeps pos > -eta and such a pos has fract > 1 - eta, i.e. is not sure), so truncation
+    // by v_cvt_i32_f32 is its floor.
+    float fr = __builtin_amdgcn_fractf(pos);
     bool cand = LOWER ? (r2 < c.cand_hi && r2 >= c.cand_lo) : (r2 < c.cand_hi);
     // farther than eta from both neighbouring edges (covers both range ends)
-    bool sure = fabsf((pos - kf) - 0.5f) < sure_half;
+    bool sure = fabsf(fr - 0.5f) < sure_half;
     if (TAGS)
         cand = cand && (tag_i != tag_j);
-    // wave-uniform test first: the cold block then sits out of line and the hot path falls through
-    if (__builtin_expect(__ballot(cand && !sure) != 0ull, 0)) {
+    // Scalar mask arithmetic (no extra VALU compare for the negation); the wave-uniform test
+    // puts the cold block out of line so the hot path falls through.
+    const unsigned long long m_cand = __builtin_amdgcn_ballot_w64(cand);
+    const unsigned long long m_sure = __builtin_amdgcn_ballot_w64(sure);
+    if (__builtin_expect((m_cand & ~m_sure) != 0ull, 0)) {
         if (cand && !sure) {
             ++n_exact;
             cell_pair_exact(c, a, sT, hist, po_i, po_j, w);
         }
     }
     if (cand && sure)
-        hist.add((int)kf, w);
+        hist.add((int)pos, w);
 }
 
 template <bool EXCL, bool LOWER, bool GH>

@@ -303,3 +303,44 @@ def test_synth_walk_is_deterministic_and_wrapped():
     assert 0.25 < step.std() < 0.35
     d.free()
     d2.free()
+
+
+def test_rccl_comm_single_rank_paths():
+    """RCCL communicator with one rank: the all-reduce entry points run and leave results unchanged."""
+    comm = _core.RcclComm(0, 1, _core.RcclComm.unique_id())
+    comm.barrier()
+    assert np.array_equal(comm.allreduce(np.arange(5, dtype=np.int64)), np.arange(5))
+    assert np.allclose(comm.allreduce(np.array([1.5, -2.0]), op="max"), [1.5, -2.0])
+    rng = np.random.default_rng(30)
+    L = np.float32(20.0)
+    pos = (rng.random((2, 1500, 3)) * L).astype(np.float32)
+    dims = np.array([L, L, L, 90, 90, 90], dtype=np.float32)
+    eng = _core.RdfEngine(_edges(50, (0.0, 8.0)), (1, 1))
+    eng.accumulate(pos, None, dims)
+    before = eng.counts()
+    eng.allreduce(comm)
+    assert np.array_equal(eng.counts(), before)
+    with pytest.raises(RuntimeError):
+        eng.accumulate(pos, None, dims)          # all-reduced handle must be reset first
+    eng.reset()
+    eng.accumulate(pos, None, dims)
+    assert np.array_equal(eng.counts(), before)
+    eng.close()
+    q = of.grid_wavevectors([20.0, 20.0, 20.0], 3)
+    sq = _core.SqEngine(q, [1500], ((None, None),))
+    sq.accumulate(pos)
+    ref = sq.result()
+    sq.allreduce(comm)
+    assert np.array_equal(sq.result(), ref)
+    sq.close()
+    walk = np.cumsum(rng.normal(size=(64, 6, 3)), axis=0)
+    m = _core.MsdEngine(64, 1, 1)
+    m.push(0, walk, 0, 6)
+    a0, t0 = m.result()
+    m.reset()
+    m.push(0, walk, 0, 6)
+    m.allreduce(comm)
+    a1, t1 = m.result()
+    assert np.allclose(a0, a1) and np.allclose(t0, t1)
+    m.close()
+    comm.close()
