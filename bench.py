@@ -66,7 +66,9 @@ class World:
                     f"127.0.0.1 --master-port 29500 bench.py --gpus {n_gpus} ...")
             raise SystemExit(f"WORLD_SIZE={self.world} does not match --gpus {n_gpus}")
         self.comm = None
-        if self.world > 1:
+        # MDX_FORCE_COMM=1 builds the communicator for a single rank too (exercises the
+        # rendezvous + RCCL path on a one-GPU box)
+        if self.world > 1 or os.environ.get("MDX_FORCE_COMM") == "1":
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             from mdhelper_amd.comm import rccl_comm_from_env
             self.comm = rccl_comm_from_env(self.local_rank)
@@ -330,6 +332,11 @@ def bench_msd(args, world):
 
 def main():
     args = parse()
+    # Libraries underneath (gloo, RCCL) print banners on stdout; keep stdout clean for the
+    # one JSON line by pointing fd 1 at stderr until the result is ready.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = World(args.gpus)
     from mdhelper_amd import _lib
     _lib.require_device(world.local_rank)
@@ -339,10 +346,20 @@ def main():
         out = bench_sq(args, world)
     else:
         out = bench_msd(args, world)
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
     if world.rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    os.dup2(2, 1)          # teardown chatter goes to stderr as well
     if world.comm is not None:
         world.comm.close()
+        try:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.destroy_process_group()
+        except ImportError:
+            pass
 
 
 if __name__ == "__main__":

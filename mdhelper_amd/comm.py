@@ -79,7 +79,7 @@ def rccl_comm_from_env(device: int | None = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1:
+    if world == 1 and "MASTER_ADDR" not in os.environ:
         return RcclComm(0, 1, RcclComm.unique_id(), device)
     import torch.distributed as dist
     if not dist.is_initialized():
