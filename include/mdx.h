@@ -165,6 +165,24 @@ int mdx_sq_enable_timing(mdx_sq_t h, int on);
 int mdx_fourier_sum(int dev, const double *wavevectors, int64_t n_q, const double *positions,
                     int64_t n, double *out_re_im);
 
+/* ------------------------------------------------- intermediate scattering function
+ * Replaces IntermediateScatteringFunction._single_frame (structure.py:1956-2083): the
+ * coherent part from lagged products of rho_g(q, f) and, optionally, the incoherent
+ * part sum_j cos(q . (r_j(f) - r_j(f - lag))) for lags 0 .. n_lags-1.  Arguments as for
+ * mdx_sq_create; frames must be fed in analysis order (consecutive calls continue). */
+typedef struct mdx_isf *mdx_isf_t;
+int mdx_isf_create(mdx_isf_t *out, int dev, const double *wavevectors, int64_t n_q,
+                   const int64_t *group_offsets, int n_groups, const int32_t *pairs, int n_pairs,
+                   int n_lags, int incoherent);
+int mdx_isf_destroy(mdx_isf_t h);
+int mdx_isf_reset(mdx_isf_t h);
+int mdx_isf_accumulate(mdx_isf_t h, const float *pos, int64_t n, int64_t n_frames);
+/* cisf: float64[n_lags][n_pairs][n_q]; iisf (may be NULL): float64[n_lags][n_slots][n_q] with
+ * n_slots = 1 for mode=None (pairs = (-1,-1)) and n_groups otherwise; un-normalised sums. */
+int mdx_isf_result(mdx_isf_t h, double *cisf, double *iisf);
+int mdx_isf_stats(mdx_isf_t h, int64_t *launches, double *kernel_ms, int64_t *frames);
+int mdx_isf_enable_timing(mdx_isf_t h, int on);
+
 /* ------------------------------------------------------------- time correlation
  * Replaces algorithm.correlation.correlation_fft / msd_fft
  * (src/mdhelper/algorithm/correlation.py:17-226, :461-668) as called from

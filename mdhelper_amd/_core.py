@@ -274,6 +274,51 @@ class SqEngine(_Engine):
         return {"launches": n.value, "kernel_ms": ms.value}
 
 
+class IsfEngine(_Engine):
+    """``mdx_isf_*``: coherent / incoherent intermediate scattering functions."""
+
+    _destroy = "mdx_isf_destroy"
+
+    def __init__(self, wavevectors, group_sizes, pairs, n_lags, incoherent=False, *, dev=0,
+                 timing=False):
+        self.q = np.ascontiguousarray(wavevectors, dtype=np.float64).reshape(-1, 3)
+        self.offsets = np.concatenate(([0], np.cumsum(group_sizes))).astype(np.int64)
+        self.pairs = np.ascontiguousarray(
+            [(-1, -1) if p[0] is None else (int(p[0]), int(p[1])) for p in pairs], dtype=np.int32)
+        self.n_lags = int(n_lags)
+        self.incoherent = bool(incoherent)
+        self.n_slots = 1 if self.pairs[0, 0] < 0 else len(group_sizes)
+        h = c_void_p()
+        check(lib().mdx_isf_create(byref(h), dev, _ptr(self.q), self.q.shape[0], _ptr(self.offsets),
+                                   len(group_sizes), _ptr(self.pairs), self.pairs.shape[0],
+                                   self.n_lags, int(self.incoherent)))
+        self.handle = h
+        self.dev = dev
+        if timing:
+            check(lib().mdx_isf_enable_timing(h, 1))
+
+    def accumulate(self, pos):
+        """pos: float32[F, N, 3], frames in analysis order."""
+        p = np.ascontiguousarray(pos, dtype=np.float32)
+        if p.ndim == 2:
+            p = p[None]
+        check(lib().mdx_isf_accumulate(self.handle, _ptr(p), p.shape[1], p.shape[0]))
+
+    def result(self):
+        cisf = np.zeros((self.n_lags, self.pairs.shape[0], self.q.shape[0]))
+        iisf = np.zeros((self.n_lags, self.n_slots, self.q.shape[0])) if self.incoherent else None
+        check(lib().mdx_isf_result(self.handle, _ptr(cisf), _ptr(iisf)))
+        return cisf, iisf
+
+    def reset(self):
+        check(lib().mdx_isf_reset(self.handle))
+
+    def stats(self):
+        n, ms, fr = c_int64(), c_double(), c_int64()
+        check(lib().mdx_isf_stats(self.handle, byref(n), byref(ms), byref(fr)))
+        return {"launches": n.value, "kernel_ms": ms.value, "frames": fr.value}
+
+
 def fourier_sum_device(wavevectors, positions, dev=0):
     """``mdx_fourier_sum``: complex128[N_q] = sum_j exp(i q.r_j), float64 positions."""
     q = np.ascontiguousarray(wavevectors, dtype=np.float64).reshape(-1, 3)

@@ -76,6 +76,14 @@ _SIGNATURES = {
     "mdx_sq_stats": (c_int, [_vp, POINTER(c_int64), POINTER(c_double)]),
     "mdx_sq_enable_timing": (c_int, [_vp, c_int]),
     "mdx_fourier_sum": (c_int, [c_int, _vp, c_int64, _vp, c_int64, _vp]),
+    # intermediate scattering function
+    "mdx_isf_create": (c_int, [POINTER(_vp), c_int, _vp, c_int64, _vp, c_int, _vp, c_int, c_int, c_int]),
+    "mdx_isf_destroy": (c_int, [_vp]),
+    "mdx_isf_reset": (c_int, [_vp]),
+    "mdx_isf_accumulate": (c_int, [_vp, _vp, c_int64, c_int64]),
+    "mdx_isf_result": (c_int, [_vp, _vp, _vp]),
+    "mdx_isf_stats": (c_int, [_vp, POINTER(c_int64), POINTER(c_double), POINTER(c_int64)]),
+    "mdx_isf_enable_timing": (c_int, [_vp, c_int]),
     # time correlation
     "mdx_msd_create": (c_int, [POINTER(_vp), c_int, c_int64, c_int, c_int]),
     "mdx_msd_destroy": (c_int, [_vp]),

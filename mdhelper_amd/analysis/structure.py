@@ -519,3 +519,100 @@ class StructureFactor(NumbaAnalysisBase):
             self.results.wavenumbers = self.results.wavenumbers[order]
             self.results.ssf = self.results.ssf[:, order]
         del self._positions
+
+
+class IntermediateScatteringFunction(StructureFactor):
+    r"""
+    Coherent and incoherent (self) intermediate scattering functions and their
+    partial versions (reference structure.py:1552-2127):
+
+    .. math::
+
+       F_{\alpha\beta}(q,t)=\frac{1}{N}\left\langle\mathrm{Re}\,
+       \rho_\alpha(\mathbf q,t_0)\rho_\beta^*(\mathbf q,t_0+t)\right\rangle_{t_0}
+       \;(+\,\alpha\leftrightarrow\beta),\qquad
+       F_{\mathrm s,\alpha}(q,t)=\frac{1}{N}\left\langle\sum_{j\in\alpha}
+       \cos\mathbf q\cdot[\mathbf r_j(t_0+t)-\mathbf r_j(t_0)]\right\rangle_{t_0}
+
+    Parameters as for :class:`StructureFactor` plus ``dt`` (time between frames),
+    ``n_lags`` (number of time lags, default: all analysed frames) and
+    ``incoherent``.  Results: ``results.times``, ``results.wavenumbers``,
+    ``results.pairs``, ``results.cisf`` ``[N_t, N_pairs or 1, N_q]`` and, when
+    ``incoherent=True``, ``results.iisf`` ``[N_t, N_g or 1, N_q]``.
+
+    The reference keeps a ring of ``n_lags`` frames on the host and re-evaluates a
+    Fourier sum per (frame, lag) for the incoherent part; here both rings and all
+    sums live on the GPU (``mdx_isf_*``).  Frames are consumed in order, so this
+    analysis does not shard over frames.
+    """
+
+    def __init__(self, groups, groupings: Union[str, tuple] = "atoms", *, mode: str = None,
+                 form: str = "exp", dimensions=None, dt=None, n_points: int = 32,
+                 n_surfaces: int = None, n_surface_points: int = 8, q_max=None, wavevectors=None,
+                 sort: bool = True, unique: bool = True, n_lags: int = None,
+                 incoherent: bool = False, parallel: bool = False, verbose: bool = True,
+                 **kwargs) -> None:
+        super().__init__(groups, groupings, mode=mode, form=form, dimensions=dimensions,
+                         n_points=n_points, n_surfaces=n_surfaces,
+                         n_surface_points=n_surface_points, q_max=q_max, wavevectors=wavevectors,
+                         sort=sort, unique=unique, parallel=parallel, verbose=verbose, **kwargs)
+        self._dt = strip_unit(dt or self._trajectory.dt, "picosecond")[0]
+        self._n_lags = n_lags
+        self._incoherent = incoherent
+
+    def _prepare(self) -> None:
+        self._n_lags = self._n_lags or self.n_frames
+        st = self._sliced_trajectory
+        if hasattr(st, "frames"):
+            df = np.diff(st.frames)
+            if len(df) and (df[0] <= 0 or not np.allclose(df, df[0])):
+                raise ValueError("The selected frames must be evenly spaced and proceed "
+                                 "forward in time.")
+            df = df[0] if len(df) else 1
+        else:
+            if st.step is not None and st.step <= 0:
+                raise ValueError("The analysis must proceed forward in time.")
+            df = st.step if st.step is not None else 1
+        self.results.pairs = (
+            tuple(combinations_with_replacement(range(self._n_groups), 2))
+            if self._mode == "partial"
+            else ((0, self._n_groups - 1),) if self._mode == "pair"
+            else ((None, None),))
+        self.results.times = df * self._dt * np.arange(self._n_lags)
+        self.results.wavenumbers = (np.unique(self._wavenumbers.round(11))
+                                    if self._unique else self._wavenumbers)
+        self.results.units = {"results.times": "picosecond", "results.wavenumbers": "angstrom^-1"}
+        self._engine = _core.IsfEngine(self._wavevectors, self._Ns, self.results.pairs,
+                                       self._n_lags, self._incoherent, dev=self._device)
+        self._batch = FrameBatcher(int(self._N), lambda p, b: self._engine.accumulate(p[0]),
+                                   with_box=False, max_bytes=64 << 20)
+        self._positions = np.empty((self._N, 3), dtype=np.float32)
+
+    def _single_frame(self) -> None:
+        for g, gr, s in zip(self._groups, self._groupings, self._slices):
+            self._positions[s] = _group_positions(g, gr)
+        self._batch.add([self._positions])
+
+    def _conclude(self) -> None:
+        self._batch.flush()
+        cisf, iisf = self._engine.result()
+        self._engine.close()
+        normalization = (self._N * np.arange(self.n_frames, self.n_frames - self._n_lags, -1)
+                         [:, None, None])
+        self.results.cisf = cisf / normalization
+        if self._incoherent:
+            self.results.iisf = iisf / normalization
+        if self._unique:
+            def combine(x):
+                return np.stack([x[:, :, np.isclose(q, self._wavenumbers)].mean(axis=2)
+                                 for q in self.results.wavenumbers], axis=-1)
+            self.results.cisf = combine(self.results.cisf)
+            if self._incoherent:
+                self.results.iisf = combine(self.results.iisf)
+        if self._sort:
+            order = np.argsort(self.results.wavenumbers)
+            self.results.wavenumbers = self.results.wavenumbers[order]
+            self.results.cisf = self.results.cisf[:, :, order]
+            if self._incoherent:
+                self.results.iisf = self.results.iisf[:, :, order]
+        del self._positions

@@ -1,0 +1,382 @@
+// mdx_isf.hip — coherent / incoherent intermediate scattering functions on gfx950.
+//
+// Carries IntermediateScatteringFunction._single_frame (reference
+// src/mdhelper/analysis/structure.py:1956-2083):
+//
+//   rho_g(q, f) = sum_{j in g} exp(i q . r_j(f))                          (sq_rho_kernel)
+//   cisf[lag][p](q) += Re rho_j(f-lag) rho_j(f)^*                          p = (j, j)
+//                   += Re rho_j(f-lag) rho_k(f)^* + Re rho_k(f-lag) rho_j(f)^*   p = (j, k)
+//                   += Re rho(f-lag) rho(f)^*  with rho = sum_g rho_g      mode=None
+//   iisf[lag][g](q) += sum_{j in g} cos(q . (r_j(f) - r_j(f-lag)))         (:1991-1996)
+//
+// for every analysed frame f and every lag <= min(n_lags - 1, f).  The reference
+// keeps a ring of n_lags frames of positions and of rho on the host; here the rings
+// live in HBM (2 n_lags slots, so a chunk of new frames never overwrites history a
+// frame of the same chunk still needs) and both forms ("exp", "trig") map onto the
+// same fp64 kernels.  The incoherent part is n_lags x the work of a structure
+// factor per frame and dominates; it runs as one fused kernel over
+// (wavevector block, group x particle split, lag) with the frames of a chunk
+// looped inside, so sums are formed in a fixed order (run-to-run reproducible).
+#include "mdx_common.hpp"
+#include "mdx_internal.hpp"
+
+using namespace mdx;
+
+#include "mdx_sq_device.hpp"
+
+using namespace mdx_sq_dev;
+
+namespace {
+
+// cisf[lag][p][q] += sum over the chunk's frames f of the lagged products
+__global__ __launch_bounds__(256) void isf_coherent_kernel(
+    const double2 *__restrict__ ring, int ring_slots, int n_groups, int n_q,
+    const int *__restrict__ pairs, int n_pairs, int n_lags, long long f_first, int n_new,
+    double *__restrict__ cisf)
+{
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    const int p = blockIdx.y, lag = blockIdx.z;
+    if (qi >= n_q)
+        return;
+    const int j = pairs[2 * p], k = pairs[2 * p + 1];
+    auto rho = [&](long long f, int g) {
+        return ring[(int64_t(f % ring_slots) * n_groups + g) * n_q + qi];
+    };
+    auto total = [&](long long f) {
+        double2 r = make_double2(0.0, 0.0);
+        for (int g = 0; g < n_groups; ++g) {
+            double2 v = rho(f, g);
+            r.x += v.x;
+            r.y += v.y;
+        }
+        return r;
+    };
+    double sum = 0.0;
+    for (int i = 0; i < n_new; ++i) {
+        const long long f = f_first + i;
+        if (f < lag)
+            continue;
+        if (j < 0) {
+            double2 a = total(f - lag), b = total(f);
+            sum += a.x * b.x + a.y * b.y;
+        } else if (j == k) {
+            double2 a = rho(f - lag, j), b = rho(f, j);
+            sum += a.x * b.x + a.y * b.y;
+        } else {
+            double2 aj = rho(f - lag, j), bk = rho(f, k), ak = rho(f - lag, k), bj = rho(f, j);
+            sum += (aj.x * bk.x + aj.y * bk.y) + (ak.x * bj.x + ak.y * bj.y);
+        }
+    }
+    cisf[(int64_t(lag) * n_pairs + p) * n_q + qi] += sum;
+}
+
+// part[split][lag][slot][q] = sum over the chunk's frames and the split's particles of
+// cos(q . (r(f) - r(f - lag)));  `slot` indexes the groups that have an incoherent part
+__global__ __launch_bounds__(SQ_THREADS) void isf_incoherent_kernel(
+    const float *__restrict__ pos_ring, int ring_slots, int64_t n_atoms,
+    const double *__restrict__ qv, int n_q, const int64_t *__restrict__ ranges /*[n_slots][2]*/,
+    int n_slots, int n_split, int n_lags, long long f_first, int n_new, double *__restrict__ part)
+{
+    __shared__ float cx[SQ_TILE / 2], cy[SQ_TILE / 2], cz[SQ_TILE / 2];
+    __shared__ float px[SQ_TILE / 2], py[SQ_TILE / 2], pz[SQ_TILE / 2];
+    constexpr int TILE = SQ_TILE / 2;
+    const int tid = threadIdx.x;
+    const int qb = blockIdx.x;
+    const int slot = blockIdx.y / n_split, sp = blockIdx.y % n_split;
+    const int lag = blockIdx.z;
+
+    double q0[SQ_QPT], q1[SQ_QPT], q2[SQ_QPT], ac[SQ_QPT];
+#pragma unroll
+    for (int u = 0; u < SQ_QPT; ++u) {
+        int qi = qb * SQ_QPB + u * SQ_THREADS + tid;
+        bool ok = qi < n_q;
+        q0[u] = ok ? qv[3 * int64_t(qi) + 0] : 0.0;
+        q1[u] = ok ? qv[3 * int64_t(qi) + 1] : 0.0;
+        q2[u] = ok ? qv[3 * int64_t(qi) + 2] : 0.0;
+        ac[u] = 0.0;
+    }
+    const int64_t g_lo = ranges[2 * slot], g_hi = ranges[2 * slot + 1];
+    const int64_t per = (g_hi - g_lo + n_split - 1) / n_split;
+    const int64_t lo = g_lo + sp * per, hi = min(g_hi, lo + per);
+
+    for (int i = 0; i < n_new; ++i) {
+        const long long f = f_first + i;
+        if (f < lag)
+            continue;
+        const float *C = pos_ring + int64_t(f % ring_slots) * n_atoms * 3;
+        const float *P = pos_ring + int64_t((f - lag) % ring_slots) * n_atoms * 3;
+        for (int64_t base = lo; base < hi; base += TILE) {
+            const int cnt = (int)min<int64_t>(TILE, hi - base);
+            __syncthreads();
+            for (int e = tid; e < cnt * 3; e += SQ_THREADS) {
+                float vc = C[base * 3 + e], vp = P[base * 3 + e];
+                int a = e / 3, k = e - 3 * a;
+                (k == 0 ? cx : k == 1 ? cy : cz)[a] = vc;
+                (k == 0 ? px : k == 1 ? py : pz)[a] = vp;
+            }
+            __syncthreads();
+            for (int a = 0; a < cnt; ++a) {
+                // float32 coordinates widened first: the difference is exact in fp64
+                const double dx = (double)cx[a] - (double)px[a], dy = (double)cy[a] - (double)py[a],
+                             dz = (double)cz[a] - (double)pz[a];
+#pragma unroll
+                for (int u = 0; u < SQ_QPT; ++u) {
+                    double ph = fma(q2[u], dz, fma(q1[u], dy, q0[u] * dx));
+                    double s, c;
+                    sincos_f64(ph, s, c);
+                    ac[u] += c;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < SQ_QPT; ++u) {
+        int qi = qb * SQ_QPB + u * SQ_THREADS + tid;
+        if (qi < n_q)
+            part[((int64_t(sp) * n_lags + lag) * n_slots + slot) * n_q + qi] = ac[u];
+    }
+}
+
+// iisf[lag][slot][q] += sum over splits (fixed order)
+__global__ void isf_reduce_kernel(const double *__restrict__ part, int n_split, int64_t n,
+                                  double *__restrict__ iisf)
+{
+    int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    double s = 0.0;
+    for (int sp = 0; sp < n_split; ++sp)
+        s += part[int64_t(sp) * n + i];
+    iisf[i] += s;
+}
+
+}  // namespace
+
+struct mdx_isf {
+    int dev = 0;
+    hipStream_t stream = nullptr;
+    int64_t n_q = 0, n_total = 0;
+    int n_groups = 0, n_pairs = 0, n_lags = 0, n_slots = 0, ring_slots = 0;
+    bool incoherent = false;
+    long long frames_seen = 0;
+    std::vector<int64_t> offsets;
+    std::vector<int64_t> ranges;      // particle range of every incoherent slot
+    DeviceBuffer d_q, d_offsets, d_pairs, d_ranges, d_rho_ring, d_pos_ring, d_cisf, d_iisf, d_part,
+        d_rho_tmp;
+    StreamTimer timer;
+};
+
+extern "C" {
+
+int mdx_isf_create(mdx_isf_t *out, int dev, const double *wavevectors, int64_t n_q,
+                   const int64_t *group_offsets, int n_groups, const int32_t *pairs, int n_pairs,
+                   int n_lags, int incoherent)
+{
+    MDX_REQUIRE(out && wavevectors && group_offsets && pairs, "NULL argument");
+    MDX_REQUIRE(n_q >= 1 && n_q < (int64_t(1) << 30), "n_q out of range");
+    MDX_REQUIRE(n_groups >= 1 && n_groups <= 1024, "n_groups out of range");
+    MDX_REQUIRE(n_pairs >= 1 && n_pairs <= 65535, "n_pairs out of range");
+    MDX_REQUIRE(n_lags >= 1 && n_lags <= 32768, "n_lags out of range");
+    for (int g = 0; g < n_groups; ++g)
+        MDX_REQUIRE(group_offsets[g + 1] >= group_offsets[g] && group_offsets[0] >= 0,
+                    "group offsets must be non-negative and non-decreasing");
+    for (int p = 0; p < n_pairs; ++p) {
+        int j = pairs[2 * p], k = pairs[2 * p + 1];
+        MDX_REQUIRE((j == -1 && k == -1) || (j >= 0 && j < n_groups && k >= 0 && k < n_groups),
+                    "pair %d = (%d, %d) is not a pair of groups", p, j, k);
+    }
+    MDX_TRY(set_device(dev));
+    mdx_isf *h = new mdx_isf();
+    h->dev = dev;
+    h->n_q = n_q;
+    h->n_groups = n_groups;
+    h->n_pairs = n_pairs;
+    h->n_lags = n_lags;
+    h->ring_slots = 2 * n_lags;
+    h->incoherent = incoherent != 0;
+    h->offsets.assign(group_offsets, group_offsets + n_groups + 1);
+    h->n_total = group_offsets[n_groups];
+    // incoherent slots: all particles for mode=None, else one per group (structure.py:1933-1938);
+    // a group without a (g, g) pair keeps zeros, as in the reference
+    const bool total_mode = pairs[0] == -1;
+    h->n_slots = total_mode ? 1 : n_groups;
+    h->ranges.assign(size_t(2) * h->n_slots, 0);
+    if (total_mode) {
+        h->ranges[0] = group_offsets[0];
+        h->ranges[1] = group_offsets[n_groups];
+    } else {
+        for (int p = 0; p < n_pairs; ++p)
+            if (pairs[2 * p] == pairs[2 * p + 1]) {
+                int g = pairs[2 * p];
+                h->ranges[2 * g] = group_offsets[g];
+                h->ranges[2 * g + 1] = group_offsets[g + 1];
+            }
+    }
+    int rc = MDX_OK;
+    do {
+        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+            rc = fail(MDX_ERR_HIP, "hipStreamCreate failed");
+            break;
+        }
+        h->timer.stream = h->stream;
+        if ((rc = h->d_q.ensure(size_t(24) * n_q)) != MDX_OK) break;
+        if ((rc = h->d_offsets.ensure(size_t(8) * (n_groups + 1))) != MDX_OK) break;
+        if ((rc = h->d_pairs.ensure(size_t(8) * n_pairs)) != MDX_OK) break;
+        if ((rc = h->d_ranges.ensure(size_t(16) * h->n_slots)) != MDX_OK) break;
+        if ((rc = h->d_rho_ring.ensure(size_t(16) * h->ring_slots * n_groups * n_q)) != MDX_OK) break;
+        if ((rc = h->d_cisf.ensure(size_t(8) * n_lags * n_pairs * n_q)) != MDX_OK) break;
+        if (h->incoherent &&
+            (rc = h->d_iisf.ensure(size_t(8) * n_lags * h->n_slots * n_q)) != MDX_OK) break;
+        if (hipMemcpy(h->d_q.ptr, wavevectors, size_t(24) * n_q, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(h->d_offsets.ptr, group_offsets, size_t(8) * (n_groups + 1),
+                      hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(h->d_pairs.ptr, pairs, size_t(8) * n_pairs, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(h->d_ranges.ptr, h->ranges.data(), size_t(16) * h->n_slots,
+                      hipMemcpyHostToDevice) != hipSuccess) {
+            rc = fail(MDX_ERR_HIP, "upload failed");
+            break;
+        }
+    } while (0);
+    if (rc != MDX_OK) {
+        mdx_isf_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return mdx_isf_reset(h);
+}
+
+int mdx_isf_destroy(mdx_isf_t h)
+{
+    if (!h)
+        return MDX_OK;
+    (void)hipSetDevice(h->dev);
+    if (h->stream)
+        (void)hipStreamSynchronize(h->stream);
+    h->timer.destroy();
+    for (DeviceBuffer *b : {&h->d_q, &h->d_offsets, &h->d_pairs, &h->d_ranges, &h->d_rho_ring,
+                            &h->d_pos_ring, &h->d_cisf, &h->d_iisf, &h->d_part, &h->d_rho_tmp})
+        b->release();
+    if (h->stream)
+        (void)hipStreamDestroy(h->stream);
+    delete h;
+    return MDX_OK;
+}
+
+int mdx_isf_reset(mdx_isf_t h)
+{
+    MDX_REQUIRE(h, "NULL handle");
+    MDX_TRY(set_device(h->dev));
+    MDX_HIP(hipMemsetAsync(h->d_cisf.ptr, 0, size_t(8) * h->n_lags * h->n_pairs * h->n_q, h->stream));
+    if (h->incoherent)
+        MDX_HIP(hipMemsetAsync(h->d_iisf.ptr, 0, size_t(8) * h->n_lags * h->n_slots * h->n_q,
+                               h->stream));
+    MDX_HIP(hipStreamSynchronize(h->stream));
+    h->frames_seen = 0;
+    h->timer.reset();
+    return MDX_OK;
+}
+
+// Frames must arrive in analysis order; consecutive calls continue the same series.
+int mdx_isf_accumulate(mdx_isf_t h, const float *pos, int64_t n, int64_t n_frames)
+{
+    MDX_REQUIRE(h && pos, "NULL argument");
+    MDX_REQUIRE(n >= h->n_total && n_frames >= 0, "bad size");
+    MDX_TRY(set_device(h->dev));
+    if (h->incoherent)
+        MDX_TRY(h->d_pos_ring.ensure(size_t(12) * n * h->ring_slots));
+    const int qblocks = (int)ceil_div(h->n_q, SQ_QPB);
+    int64_t done = 0;
+    while (done < n_frames) {
+        // a chunk: at most n_lags new frames, contiguous in the ring
+        const long long f0 = h->frames_seen;
+        const int slot0 = int(f0 % h->ring_slots);
+        const int64_t nf = std::min<int64_t>(std::min<int64_t>(h->n_lags, h->ring_slots - slot0),
+                                             n_frames - done);
+        const float *src = pos + done * n * 3;
+        const float *d_new = nullptr;
+        if (h->incoherent) {
+            float *dst = h->d_pos_ring.as<float>() + int64_t(slot0) * n * 3;
+            MDX_HIP(hipMemcpyAsync(dst, src, size_t(12) * n * nf, hipMemcpyHostToDevice, h->stream));
+            d_new = dst;
+        } else {
+            MDX_TRY(h->d_rho_tmp.ensure(size_t(12) * n * nf));
+            MDX_HIP(hipMemcpyAsync(h->d_rho_tmp.ptr, src, size_t(12) * n * nf, hipMemcpyHostToDevice,
+                                   h->stream));
+            d_new = h->d_rho_tmp.as<float>();
+        }
+        hipEvent_t ev = h->timer.begin();
+        hipLaunchKernelGGL(sq_rho_kernel, dim3(qblocks, h->n_groups, (unsigned)nf), dim3(SQ_THREADS),
+                           0, h->stream, d_new, n, h->d_q.as<double>(), (int)h->n_q,
+                           h->d_offsets.as<int64_t>(), h->n_groups, 1,
+                           h->d_rho_ring.as<double2>() + int64_t(slot0) * h->n_groups * h->n_q);
+        hipLaunchKernelGGL(isf_coherent_kernel,
+                           dim3((unsigned)ceil_div(h->n_q, 256), h->n_pairs, h->n_lags), dim3(256), 0,
+                           h->stream, h->d_rho_ring.as<double2>(), h->ring_slots, h->n_groups,
+                           (int)h->n_q, h->d_pairs.as<int>(), h->n_pairs, h->n_lags, f0, (int)nf,
+                           h->d_cisf.as<double>());
+        if (h->incoherent) {
+            int64_t max_range = 0;
+            for (int s = 0; s < h->n_slots; ++s)
+                max_range = std::max(max_range, h->ranges[2 * s + 1] - h->ranges[2 * s]);
+            int n_split = 1;
+            while (int64_t(qblocks) * h->n_slots * n_split * h->n_lags < 1024 && n_split < 64 &&
+                   max_range / (n_split * 2) >= SQ_TILE)
+                n_split *= 2;
+            const int64_t n_out = int64_t(h->n_lags) * h->n_slots * h->n_q;
+            MDX_TRY(h->d_part.ensure(size_t(8) * n_out * n_split));
+            hipLaunchKernelGGL(isf_incoherent_kernel,
+                               dim3(qblocks, h->n_slots * n_split, h->n_lags), dim3(SQ_THREADS), 0,
+                               h->stream, h->d_pos_ring.as<float>(), h->ring_slots, n,
+                               h->d_q.as<double>(), (int)h->n_q, h->d_ranges.as<int64_t>(),
+                               h->n_slots, n_split, h->n_lags, f0, (int)nf, h->d_part.as<double>());
+            hipLaunchKernelGGL(isf_reduce_kernel, dim3((unsigned)ceil_div(n_out, 256)), dim3(256), 0,
+                               h->stream, h->d_part.as<double>(), n_split, n_out,
+                               h->d_iisf.as<double>());
+        }
+        h->timer.end(ev);
+        MDX_HIP(hipGetLastError());
+        // the host buffer may be reused by the caller; the staging copy must have left it
+        MDX_HIP(hipStreamSynchronize(h->stream));
+        h->frames_seen += nf;
+        done += nf;
+    }
+    return MDX_OK;
+}
+
+int mdx_isf_result(mdx_isf_t h, double *cisf, double *iisf)
+{
+    MDX_REQUIRE(h && cisf, "NULL argument");
+    MDX_TRY(set_device(h->dev));
+    MDX_HIP(hipStreamSynchronize(h->stream));
+    h->timer.collect();
+    MDX_HIP(hipMemcpy(cisf, h->d_cisf.ptr, size_t(8) * h->n_lags * h->n_pairs * h->n_q,
+                      hipMemcpyDeviceToHost));
+    if (iisf) {
+        if (!h->incoherent)
+            return fail(MDX_ERR_STATE, "the engine was created without the incoherent part");
+        MDX_HIP(hipMemcpy(iisf, h->d_iisf.ptr, size_t(8) * h->n_lags * h->n_slots * h->n_q,
+                          hipMemcpyDeviceToHost));
+    }
+    return MDX_OK;
+}
+
+int mdx_isf_stats(mdx_isf_t h, int64_t *launches, double *kernel_ms, int64_t *frames)
+{
+    MDX_REQUIRE(h, "NULL handle");
+    MDX_TRY(set_device(h->dev));
+    MDX_HIP(hipStreamSynchronize(h->stream));
+    h->timer.collect();
+    if (launches) *launches = h->timer.launches;
+    if (kernel_ms) *kernel_ms = h->timer.total_ms;
+    if (frames) *frames = h->frames_seen;
+    return MDX_OK;
+}
+
+int mdx_isf_enable_timing(mdx_isf_t h, int on)
+{
+    MDX_REQUIRE(h, "NULL handle");
+    h->timer.enabled = on != 0;
+    return MDX_OK;
+}
+
+}  // extern "C"

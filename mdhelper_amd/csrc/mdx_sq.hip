@@ -26,104 +26,11 @@
 
 using namespace mdx;
 
+#include "mdx_sq_device.hpp"
+
+using namespace mdx_sq_dev;
+
 namespace {
-
-constexpr int SQ_THREADS = 256;
-constexpr int SQ_QPT = 2;            // wavevectors per thread
-constexpr int SQ_QPB = SQ_THREADS * SQ_QPT;
-constexpr int SQ_TILE = 1024;        // particles per LDS stage
-
-// sin and cos of x in fp64: Cody-Waite reduction by pi/2 (three-term, FMA), then the
-// fdlibm minimax kernels on [-pi/4, pi/4].  |x| up to ~1e9 keeps ~1e-15 absolute error.
-__device__ inline void sincos_f64(double x, double &s, double &c)
-{
-    const double TWO_OVER_PI = 6.36619772367581382433e-01;
-    const double PIO2_1 = 1.57079632679489655800e+00;   // pi/2 rounded to double
-    const double PIO2_2 = 6.12323399573676603587e-17;   // pi/2 - PIO2_1
-    const double PIO2_3 = -1.49738490485916983e-33;     // next 53 bits
-    double kd = rint(x * TWO_OVER_PI);
-    double r = fma(-kd, PIO2_1, x);
-    r = fma(-kd, PIO2_2, r);
-    r = fma(-kd, PIO2_3, r);
-    int q = (int)(long long)kd;
-    double z = r * r;
-    // sin kernel
-    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
-                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
-                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-    double ps = fma(z, fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2), S1);
-    double sn = fma(z * r, ps, r);
-    // cos kernel
-    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
-                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
-                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    double pc = fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1);
-    double cs = fma(z * z, pc, fma(-0.5, z, 1.0));
-    // quadrant
-    double so = (q & 1) ? cs : sn;
-    double co = (q & 1) ? sn : cs;
-    s = (q & 2) ? -so : so;
-    c = ((q + 1) & 2) ? -co : co;
-}
-
-// rho[frame][group][split][q] (re, im)
-__global__ __launch_bounds__(SQ_THREADS) void sq_rho_kernel(
-    const float *__restrict__ pos, int64_t n_atoms, const double *__restrict__ qv, int n_q,
-    const int64_t *__restrict__ group_offsets, int n_groups, int n_split,
-    double2 *__restrict__ rho)
-{
-    __shared__ float sx[SQ_TILE], sy[SQ_TILE], sz[SQ_TILE];
-    const int tid = threadIdx.x;
-    const int qb = blockIdx.x;
-    const int g = blockIdx.y / n_split, sp = blockIdx.y % n_split;
-    const int frame = blockIdx.z;
-
-    double q0[SQ_QPT], q1[SQ_QPT], q2[SQ_QPT], ac[SQ_QPT], as[SQ_QPT];
-#pragma unroll
-    for (int u = 0; u < SQ_QPT; ++u) {
-        int qi = qb * SQ_QPB + u * SQ_THREADS + tid;
-        bool ok = qi < n_q;
-        q0[u] = ok ? qv[3 * int64_t(qi) + 0] : 0.0;
-        q1[u] = ok ? qv[3 * int64_t(qi) + 1] : 0.0;
-        q2[u] = ok ? qv[3 * int64_t(qi) + 2] : 0.0;
-        ac[u] = 0.0;
-        as[u] = 0.0;
-    }
-    const int64_t g_lo = group_offsets[g], g_hi = group_offsets[g + 1];
-    const int64_t per = (g_hi - g_lo + n_split - 1) / n_split;
-    const int64_t lo = g_lo + sp * per, hi = min(g_hi, lo + per);
-    const float *P = pos + int64_t(frame) * n_atoms * 3;
-
-    for (int64_t base = lo; base < hi; base += SQ_TILE) {
-        const int cnt = (int)min<int64_t>(SQ_TILE, hi - base);
-        __syncthreads();
-        for (int e = tid; e < cnt * 3; e += SQ_THREADS) {
-            float v = P[base * 3 + e];
-            int a = e / 3, k = e - 3 * a;
-            (k == 0 ? sx : k == 1 ? sy : sz)[a] = v;
-        }
-        __syncthreads();
-        for (int a = 0; a < cnt; ++a) {
-            const double x = (double)sx[a], y = (double)sy[a], z = (double)sz[a];
-#pragma unroll
-            for (int u = 0; u < SQ_QPT; ++u) {
-                // a[0]*b[0] + a[1]*b[1] + a[2]*b[2]   (accelerated.py:43; fastmath there)
-                double ph = fma(q2[u], z, fma(q1[u], y, q0[u] * x));
-                double s, c;
-                sincos_f64(ph, s, c);
-                ac[u] += c;
-                as[u] += s;
-            }
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < SQ_QPT; ++u) {
-        int qi = qb * SQ_QPB + u * SQ_THREADS + tid;
-        if (qi < n_q)
-            rho[((int64_t(frame) * n_groups + g) * n_split + sp) * n_q + qi] =
-                make_double2(ac[u], as[u]);
-    }
-}
 
 __global__ __launch_bounds__(256) void sq_pair_kernel(const double2 *__restrict__ rho, int n_frames,
                                                       int n_groups, int n_split, int n_q,

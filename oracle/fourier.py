@@ -126,3 +126,72 @@ def ssf_run_ref(frames, group_sizes, wavevectors, *, mode=None, form="exp",
         out_q = out_q[order]
         ssf = ssf[:, order]
     return {"pairs": pairs, "wavenumbers": out_q, "ssf": ssf}
+
+
+def isf_run_ref(frames, group_sizes, wavevectors, n_lags=None, *, mode=None, incoherent=False,
+                sort=True, unique=True):
+    """
+    Intermediate scattering functions, restating
+    ``IntermediateScatteringFunction._prepare/_single_frame/_conclude``
+    (reference structure.py:1904-2127, form="exp"; the "trig" form computes the same numbers).
+
+    frames : float[F, N, 3] with the groups laid out consecutively.
+    Returns cisf[n_lags, n_pairs or 1, N_q'], iisf[n_lags, n_groups or 1, N_q'] (or None).
+    """
+    frames = np.asarray(frames, dtype=np.float64)
+    n_frames = len(frames)
+    n_lags = n_lags or n_frames
+    wavevectors = np.asarray(wavevectors, dtype=np.float64)
+    wavenumbers = np.linalg.norm(wavevectors, axis=1)
+    slices, idx = [], 0
+    for n in group_sizes:
+        slices.append(slice(idx, idx + n))
+        idx += n
+    n_total = idx
+    n_groups = len(group_sizes)
+    pairs = ssf_pairs(n_groups, mode)
+    n_q = len(wavevectors)
+    cisf = np.zeros((n_lags, 1 if mode is None else len(pairs), n_q))
+    iisf = np.zeros((n_lags, 1 if mode is None else n_groups, n_q)) if incoherent else None
+    ring_pos = np.zeros((n_lags, n_total, 3))
+    ring_rho = np.empty((n_lags, 1 if mode is None else n_groups, n_q), dtype=complex)
+    for f in range(n_frames):
+        cur = f % n_lags
+        ring_pos[cur] = frames[f][:n_total]
+        if mode is None:
+            ring_rho[cur, 0] = fourier_sum_ref(wavevectors, ring_pos[cur])
+        else:
+            for g in range(n_groups):
+                ring_rho[cur, g] = fourier_sum_ref(wavevectors, ring_pos[cur, slices[g]])
+        for lag in range(min(n_lags, f + 1)):
+            old = (f - lag) % n_lags
+            if mode is None:
+                cisf[lag, 0] += (ring_rho[old, 0] * ring_rho[cur, 0].conj()).real
+                if incoherent:
+                    iisf[lag, 0] += fourier_sum_ref(wavevectors, ring_pos[cur] - ring_pos[old]).real
+            else:
+                for i, (j, k) in enumerate(pairs):
+                    if j == k:
+                        cisf[lag, i] += (ring_rho[old, j] * ring_rho[cur, j].conj()).real
+                        if incoherent:
+                            iisf[lag, j] += fourier_sum_ref(
+                                wavevectors, ring_pos[cur, slices[j]] - ring_pos[old, slices[j]]).real
+                    else:
+                        cisf[lag, i] += ((ring_rho[old, j] * ring_rho[cur, k].conj()).real
+                                         + (ring_rho[old, k] * ring_rho[cur, j].conj()).real)
+    norm = n_total * np.arange(n_frames, n_frames - n_lags, -1)[:, None, None]
+    cisf /= norm
+    if incoherent:
+        iisf /= norm
+    out_q = np.unique(wavenumbers.round(11)) if unique else wavenumbers
+    if unique:
+        cisf = np.stack([cisf[:, :, np.isclose(q, wavenumbers)].mean(axis=2) for q in out_q], axis=-1)
+        if incoherent:
+            iisf = np.stack([iisf[:, :, np.isclose(q, wavenumbers)].mean(axis=2) for q in out_q], axis=-1)
+    if sort:
+        order = np.argsort(out_q)
+        out_q = out_q[order]
+        cisf = cisf[:, :, order]
+        if incoherent:
+            iisf = iisf[:, :, order]
+    return {"pairs": pairs, "wavenumbers": out_q, "cisf": cisf, "iisf": iisf}

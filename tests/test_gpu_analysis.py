@@ -283,3 +283,36 @@ def test_save_roundtrip(tmp_path):
     rdf.save(str(tmp_path / "rdf"))
     data = np.load(tmp_path / "rdf.npz")
     assert np.array_equal(data["counts"], rdf.results.counts)
+
+
+@pytest.mark.parametrize("mode", [None, "pair", "partial"])
+def test_intermediate_scattering_function(mode):
+    """ISF vs the restated reference driver (ring buffer semantics, normalisation)."""
+    from mdhelper_amd.analysis import IntermediateScatteringFunction
+    rng = np.random.default_rng(31)
+    L = 16.0
+    F, sizes = 23, (90, 60)
+    N = sum(sizes)
+    pos = np.mod(8.0 + np.cumsum(rng.normal(scale=0.15, size=(F, N, 3)), axis=0), L).astype(np.float32)
+    u = mdhelper_amd.ArrayUniverse(pos, [L, L, L, 90, 90, 90], dt=0.5)
+    groups = (u.atoms[:90], u.atoms[90:])
+    q = of.grid_wavevectors([L, L, L], 3)
+    for n_lags in (7, None):
+        isf = IntermediateScatteringFunction(groups, mode=mode, n_points=3, n_lags=n_lags,
+                                             incoherent=True).run()
+        ref = of.isf_run_ref(pos, sizes, q, n_lags, mode=mode, incoherent=True)
+        assert isf.results.pairs == ref["pairs"]
+        assert np.allclose(isf.results.wavenumbers, ref["wavenumbers"])
+        assert np.allclose(isf.results.times, 0.5 * np.arange(n_lags or F))
+        scale = np.abs(ref["cisf"]).max()
+        assert np.allclose(isf.results.cisf, ref["cisf"], rtol=1e-6, atol=1e-9 * scale)
+        assert np.allclose(isf.results.iisf, ref["iisf"], rtol=1e-6, atol=1e-9)
+    # lag 0 of the coherent part is the static structure factor of the same frames
+    ssf = StructureFactor(groups, mode=mode, n_points=3).run()
+    assert np.allclose(isf.results.cisf[0], ssf.results.ssf, rtol=1e-6, atol=1e-9)
+    # trig form and coherent-only run give the same coherent part; strided selection works
+    raw = IntermediateScatteringFunction(groups, mode=mode, form="trig", n_points=3, n_lags=5,
+                                         sort=False, unique=False).run(step=2)
+    ref = of.isf_run_ref(pos[::2], sizes, q, 5, mode=mode, sort=False, unique=False)
+    assert np.allclose(raw.results.cisf, ref["cisf"], rtol=1e-6, atol=1e-9 * np.abs(ref["cisf"]).max())
+    assert "iisf" not in raw.results and np.allclose(raw.results.times, np.arange(5))
