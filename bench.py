@@ -262,9 +262,11 @@ def bench_sq(args, world):
         "config": {"workload": f"C3 partial S(q) {N} atoms, {len(q)} wavevectors, 2 groups, {F} frames/GPU/step"},
         "frames_per_sec": args.steps * F * world.world / dt,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "sq_rho_kernel",
-                     "note": "fp64 sincos bound (~40 fp64 instr per evaluation)",
-                     "valu": {"fp64_instr_tflops_est": evals / max(kernel_s, 1e-9) / args.steps * args.steps * 40 / 1e12}},
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "sq_rho_lattice_kernel (grid wavevectors: separable phase tables in LDS)",
+                     "note": "fp64 VALU / LDS bound: two complex multiplies + three 16-B LDS reads per "
+                             "evaluation; non-lattice wavevector sets take sq_rho_kernel (~40 fp64 instr each)",
+                     "valu": {"evaluations_per_sec_kernel": evals / max(kernel_s, 1e-9)}},
         "checksum": float(ssf.sum()),
     }
     if world.rank == 0 and world.world == 1 and not args.no_cpu_baseline:

@@ -118,9 +118,52 @@ struct mdx_sq {
     int n_groups = 0, n_pairs = 0;
     int64_t n_total = 0;
     std::vector<int64_t> offsets;
-    DeviceBuffer d_q, d_offsets, d_pairs, d_acc, d_rho, d_stage;
+    DeviceBuffer d_q, d_offsets, d_pairs, d_acc, d_rho, d_stage, d_mtrip;
     StreamTimer timer;
+    bool lattice = false;        // wavevectors are integer multiples of one base per axis
+    SqLattice lat{};
+    size_t lat_lds = 0;
 };
+
+// Detects the lattice structure of the wavevector set (see mdx_sq_device.hpp).
+static bool sq_detect_lattice(const double *q, int64_t n_q, SqLattice &lat, std::vector<short> &trip)
+{
+    if (getenv("MDX_SQ_NO_LATTICE"))
+        return false;
+    trip.assign(size_t(4) * n_q, 0);
+    int total = 0;
+    for (int k = 0; k < 3; ++k) {
+        double g = 0.0, big = 0.0;
+        for (int64_t i = 0; i < n_q; ++i)
+            big = std::max(big, std::fabs(q[3 * i + k]));
+        for (int64_t i = 0; i < n_q; ++i) {
+            double v = std::fabs(q[3 * i + k]);
+            if (v > 1e-12 * std::max(big, 1e-300) && (g == 0.0 || v < g))
+                g = v;
+        }
+        int mmin = 0, mmax = 0;
+        if (g > 0.0) {
+            for (int64_t i = 0; i < n_q; ++i) {
+                double m = q[3 * i + k] / g, r = std::nearbyint(m);
+                if (std::fabs(m - r) > 1e-9 * std::max(1.0, std::fabs(r)) || std::fabs(r) > 512)
+                    return false;
+                trip[4 * i + k] = (short)r;
+                mmin = std::min(mmin, (int)r);
+                mmax = std::max(mmax, (int)r);
+            }
+        }
+        lat.base[k] = g;
+        lat.mmin[k] = mmin;
+        lat.R[k] = mmax - mmin + 1;
+        total += lat.R[k];
+    }
+    // particles per LDS stage: as many as fit ~96 KiB of tables, between 8 and 64
+    int tile = int((96 * 1024) / (size_t(16) * total));
+    if (tile < 8)
+        return false;
+    lat.tile = std::min(tile, 64);
+    return true;
+}
 
 static int sq_accumulate_device(mdx_sq *h, const float *d_pos, int64_t n, int64_t n_frames)
 {
@@ -145,10 +188,17 @@ static int sq_accumulate_device(mdx_sq *h, const float *d_pos, int64_t n, int64_
     hipEvent_t ev = h->timer.begin();
     for (int64_t f0 = 0; f0 < n_frames; f0 += slab) {
         const int64_t nf = std::min(slab, n_frames - f0);
-        hipLaunchKernelGGL(sq_rho_kernel, dim3(qblocks, h->n_groups * n_split, (unsigned)nf),
-                           dim3(SQ_THREADS), 0, h->stream, d_pos + f0 * n * 3, n,
-                           h->d_q.as<double>(), (int)h->n_q, h->d_offsets.as<int64_t>(),
-                           h->n_groups, n_split, h->d_rho.as<double2>());
+        if (h->lattice)
+            hipLaunchKernelGGL(sq_rho_lattice_kernel, dim3(qblocks, h->n_groups * n_split, (unsigned)nf),
+                               dim3(SQ_THREADS), h->lat_lds, h->stream, d_pos + f0 * n * 3, n,
+                               h->d_mtrip.as<short4>(), (int)h->n_q, h->lat,
+                               h->d_offsets.as<int64_t>(), h->n_groups, n_split,
+                               h->d_rho.as<double2>());
+        else
+            hipLaunchKernelGGL(sq_rho_kernel, dim3(qblocks, h->n_groups * n_split, (unsigned)nf),
+                               dim3(SQ_THREADS), 0, h->stream, d_pos + f0 * n * 3, n,
+                               h->d_q.as<double>(), (int)h->n_q, h->d_offsets.as<int64_t>(),
+                               h->n_groups, n_split, h->d_rho.as<double2>());
         hipLaunchKernelGGL(sq_pair_kernel, dim3((unsigned)ceil_div(h->n_q, 256), h->n_pairs),
                            dim3(256), 0, h->stream, h->d_rho.as<double2>(), (int)nf, h->n_groups,
                            n_split, (int)h->n_q, h->d_pairs.as<int>(), h->n_pairs,
@@ -202,6 +252,21 @@ int mdx_sq_create(mdx_sq_t *out, int dev, const double *wavevectors, int64_t n_q
             rc = fail(MDX_ERR_HIP, "upload failed");
             break;
         }
+        std::vector<short> trip;
+        h->lattice = sq_detect_lattice(wavevectors, n_q, h->lat, trip);
+        if (h->lattice) {
+            h->lat_lds = size_t(16) * h->lat.tile * (h->lat.R[0] + h->lat.R[1] + h->lat.R[2]);
+            if ((rc = h->d_mtrip.ensure(size_t(8) * n_q)) != MDX_OK) break;
+            if (hipMemcpy(h->d_mtrip.ptr, trip.data(), size_t(8) * n_q, hipMemcpyHostToDevice) !=
+                    hipSuccess ||
+                (h->lat_lds > 48 * 1024 &&
+                 hipFuncSetAttribute(reinterpret_cast<const void *>(sq_rho_lattice_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)h->lat_lds) != hipSuccess)) {
+                rc = fail(MDX_ERR_HIP, "lattice table setup failed");
+                break;
+            }
+        }
     } while (0);
     if (rc != MDX_OK) {
         mdx_sq_destroy(h);
@@ -219,7 +284,8 @@ int mdx_sq_destroy(mdx_sq_t h)
     if (h->stream)
         (void)hipStreamSynchronize(h->stream);
     h->timer.destroy();
-    for (DeviceBuffer *b : {&h->d_q, &h->d_offsets, &h->d_pairs, &h->d_acc, &h->d_rho, &h->d_stage})
+    for (DeviceBuffer *b : {&h->d_q, &h->d_offsets, &h->d_pairs, &h->d_acc, &h->d_rho, &h->d_stage,
+                            &h->d_mtrip})
         b->release();
     if (h->stream)
         (void)hipStreamDestroy(h->stream);

@@ -107,5 +107,102 @@ __global__ __launch_bounds__(SQ_THREADS) void sq_rho_kernel(
 }
 
 
+// ---------------------------------------------------------------------------------------
+// Lattice fast path.  When every wavevector is an integer combination q = (m_x g_x, m_y g_y,
+// m_z g_z) of one base vector per axis — the reference's default reciprocal grid
+// 2 pi n / L (structure.py:1376-1381, 1404-1409) and any q_max-filtered subset of it —
+//     exp(i q . r) = E_x(m_x) E_y(m_y) E_z(m_z),   E_k(m) = exp(i m g_k r_k)
+// so one fp64 sincos per (particle, axis) and a complex recurrence fill small LDS tables,
+// and each (q, particle) term costs two complex multiplies (8 fp64 FMA-class ops) instead of a
+// sincos (~40).  Tables: tab_k[a][m - m_min_k], complex double.
+struct SqLattice {
+    double base[3];
+    int mmin[3];
+    int R[3];      // table length per axis
+    int tile;      // particles per LDS stage
+};
+
+__global__ __launch_bounds__(SQ_THREADS) void sq_rho_lattice_kernel(
+    const float *__restrict__ pos, int64_t n_atoms, const short4 *__restrict__ mtrip, int n_q,
+    SqLattice lat, const int64_t *__restrict__ group_offsets, int n_groups, int n_split,
+    double2 *__restrict__ rho)
+{
+    extern __shared__ double2 lat_tab[];
+    const int tid = threadIdx.x;
+    const int qb = blockIdx.x;
+    const int g = blockIdx.y / n_split, sp = blockIdx.y % n_split;
+    const int frame = blockIdx.z;
+    const int A = lat.tile;
+    double2 *tab[3] = {lat_tab, lat_tab + size_t(A) * lat.R[0],
+                       lat_tab + size_t(A) * (lat.R[0] + lat.R[1])};
+
+    int i0[SQ_QPT], i1[SQ_QPT], i2[SQ_QPT];
+    double ac[SQ_QPT], as[SQ_QPT];
+#pragma unroll
+    for (int u = 0; u < SQ_QPT; ++u) {
+        int qi = qb * SQ_QPB + u * SQ_THREADS + tid;
+        short4 m = mtrip[min(qi, n_q - 1)];
+        i0[u] = m.x - lat.mmin[0];
+        i1[u] = m.y - lat.mmin[1];
+        i2[u] = m.z - lat.mmin[2];
+        ac[u] = 0.0;
+        as[u] = 0.0;
+    }
+    const int64_t g_lo = group_offsets[g], g_hi = group_offsets[g + 1];
+    const int64_t per = (g_hi - g_lo + n_split - 1) / n_split;
+    const int64_t lo = g_lo + sp * per, hi = min(g_hi, lo + per);
+    const float *P = pos + int64_t(frame) * n_atoms * 3;
+
+    for (int64_t base = lo; base < hi; base += A) {
+        const int cnt = (int)min<int64_t>(A, hi - base);
+        __syncthreads();
+        // one (particle, axis) per thread: E(1) by sincos, the rest by recurrence
+        for (int t = tid; t < cnt * 3; t += SQ_THREADS) {
+            const int a = t / 3, k = t - 3 * a;
+            const double theta = lat.base[k] * (double)P[(base + a) * 3 + k];
+            double s1, c1;
+            sincos_f64(theta, s1, c1);
+            double2 *row = tab[k] + size_t(a) * lat.R[k];
+            const int mmin = lat.mmin[k], mmax = mmin + lat.R[k] - 1;
+            double er = 1.0, ei = 0.0;                 // E(0)
+            for (int m = 0; m <= mmax; ++m) {
+                if (m >= mmin)
+                    row[m - mmin] = make_double2(er, ei);
+                const double nr = fma(er, c1, -ei * s1), ni = fma(er, s1, ei * c1);
+                er = nr;
+                ei = ni;
+            }
+            er = c1;
+            ei = -s1;                                  // E(-1)
+            for (int m = -1; m >= mmin; --m) {
+                if (m <= mmax)
+                    row[m - mmin] = make_double2(er, ei);
+                const double nr = fma(er, c1, ei * s1), ni = fma(ei, c1, -er * s1);
+                er = nr;
+                ei = ni;
+            }
+        }
+        __syncthreads();
+        for (int a = 0; a < cnt; ++a) {
+            const double2 *r0 = tab[0] + size_t(a) * lat.R[0], *r1 = tab[1] + size_t(a) * lat.R[1],
+                          *r2 = tab[2] + size_t(a) * lat.R[2];
+#pragma unroll
+            for (int u = 0; u < SQ_QPT; ++u) {
+                const double2 ex = r0[i0[u]], ey = r1[i1[u]], ez = r2[i2[u]];
+                const double tr = fma(ex.x, ey.x, -ex.y * ey.y), ti = fma(ex.x, ey.y, ex.y * ey.x);
+                ac[u] += fma(tr, ez.x, -ti * ez.y);
+                as[u] += fma(tr, ez.y, ti * ez.x);
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < SQ_QPT; ++u) {
+        int qi = qb * SQ_QPB + u * SQ_THREADS + tid;
+        if (qi < n_q)
+            rho[((int64_t(frame) * n_groups + g) * n_split + sp) * n_q + qi] =
+                make_double2(ac[u], as[u]);
+    }
+}
+
 }  // namespace
 }  // namespace mdx_sq_dev

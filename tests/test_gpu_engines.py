@@ -344,3 +344,47 @@ def test_rccl_comm_single_rank_paths():
     assert np.allclose(a0, a1) and np.allclose(t0, t1)
     m.close()
     comm.close()
+
+
+def test_sq_lattice_and_general_paths_agree(monkeypatch):
+    """Wavevectors on a (non-cubic, signed) reciprocal lattice take the separable-table kernel;
+    arbitrary wavevectors take the sincos kernel; both within 1e-6 of the oracle."""
+    rng = np.random.default_rng(32)
+    dims = np.array([21.0, 17.5, 26.0])
+    pos = (rng.random((2, 3000, 3)) * dims * 3 - dims).astype(np.float32)     # unwrapped too
+    m = rng.integers(-9, 10, size=(300, 3))
+    m[0] = 0
+    q_lat = 2 * np.pi * m / dims
+    q_gen = q_lat + rng.normal(scale=1e-3, size=q_lat.shape)                  # off the lattice
+    sizes = [1800, 1200]
+    slices = [slice(0, 1800), slice(1800, 3000)]
+    pairs = of.ssf_pairs(2, "partial")
+    for q in (q_lat, q_gen):
+        want = sum(of.ssf_frame_ref(q, pos[f].astype(np.float64), slices, pairs, "partial") for f in range(2))
+        eng = _core.SqEngine(q, sizes, pairs)
+        eng.accumulate(pos)
+        got = eng.result()
+        eng.close()
+        assert np.allclose(got, want, rtol=1e-6, atol=1e-9 * np.abs(want).max())
+    # the lattice detector can be switched off; same numbers from the general kernel
+    eng = _core.SqEngine(q_lat, sizes, pairs)
+    eng.accumulate(pos)
+    fast = eng.result()
+    eng.close()
+    monkeypatch.setenv("MDX_SQ_NO_LATTICE", "1")
+    eng = _core.SqEngine(q_lat, sizes, pairs)
+    eng.accumulate(pos)
+    slow = eng.result()
+    eng.close()
+    assert np.allclose(fast, slow, rtol=1e-9, atol=1e-9 * np.abs(slow).max())
+    # the reference's default grid size: 32^3 wavevectors (tables of 32 entries per axis)
+    monkeypatch.delenv("MDX_SQ_NO_LATTICE")
+    L = 30.0
+    p = (rng.random((1, 500, 3)) * L).astype(np.float32)
+    q = of.grid_wavevectors([L, L, L], 32)
+    eng = _core.SqEngine(q, [500], ((None, None),))
+    eng.accumulate(p)
+    got = eng.result()[0]
+    eng.close()
+    rho = of.fourier_sum_ref(q[::97], p[0].astype(np.float64))
+    assert np.allclose(got[::97], (rho * rho.conj()).real, rtol=1e-6, atol=1e-6)
