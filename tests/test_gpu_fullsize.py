@@ -1,0 +1,117 @@
+"""
+GPU tests at BASELINE.json's full sizes through size-independent properties (the oracle
+cannot finish these sizes in seconds): conservation of the pair count, bit-exact
+agreement of the three RDF algorithms, permutation invariance, frame additivity and
+group decomposition of the integer histogram; lattice sums for S(q); FFT MSD against the
+direct definition at a few lags and the free-walk slope at long trajectories.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from mdhelper_amd import _core  # noqa: E402
+
+N = 32768
+L = np.float32(68.94)
+DIMS = np.array([L, L, L, 90, 90, 90], dtype=np.float32)
+
+
+def _frames(n_frames, seed=2):
+    d = _core.synth_random_walk(n_frames, N, [L, L, L], 0.3, seed=seed)
+    out = d.to_host()
+    d.free()
+    return out
+
+
+def _hist(pos1, pos2, edges, exclusion, algo):
+    eng = _core.RdfEngine(edges, exclusion, algo=algo)
+    eng.accumulate(pos1, pos2, DIMS)
+    out = eng.counts()
+    eng.close()
+    return out
+
+
+def test_c2_algorithms_agree_bit_for_bit():
+    """32 768 atoms: contract arithmetic on every pair == float32 filter == cell-sorted path."""
+    frames = _frames(2)
+    for rng_range in [(0.0, 15.0), (0.0, float(L) / 2)]:
+        edges = np.linspace(*rng_range, 202)
+        ref = _hist(frames, None, edges, (1, 1), "exact")
+        assert np.array_equal(_hist(frames, None, edges, (1, 1), "filter"), ref)
+        assert np.array_equal(_hist(frames, None, edges, (1, 1), "cell"), ref)
+        assert ref.sum() > 0
+
+
+def test_c2_every_pair_is_counted_once():
+    """A range beyond the largest minimum-image distance bins all N(N-1) ordered pairs."""
+    frames = _frames(1, seed=3)
+    edges = np.linspace(0.0, 60.0, 121)            # L * sqrt(3) / 2 = 59.7
+    for algo in ("cell", "filter"):
+        counts = _hist(frames, None, edges, (1, 1), algo)
+        assert counts.sum() == N * (N - 1), algo
+    # without the exclusion the N self pairs (d = 0) join bin 0
+    counts0 = _hist(frames, None, edges, None, "cell")
+    assert counts0.sum() == N * N and counts0[0] - counts[0] == N
+
+
+def test_c2_permutation_additivity_and_group_decomposition():
+    frames = _frames(3, seed=4)
+    edges = np.linspace(0.0, 15.0, 202)
+    whole = _hist(frames, None, edges, (1, 1), "cell")
+    # frame additivity
+    parts = sum(_hist(frames[f:f + 1], None, edges, (1, 1), "cell") for f in range(3))
+    assert np.array_equal(whole, parts)
+    # permutation invariance of the particle order (self pairs excluded by identity)
+    perm = np.random.default_rng(0).permutation(N)
+    assert np.array_equal(_hist(frames[:, perm], None, edges, (1, 1), "cell"), whole)
+    # g(A+B, A+B) = g(A,A) + g(B,B) + g(A,B) + g(B,A)
+    a, b = np.ascontiguousarray(frames[:, :20000]), np.ascontiguousarray(frames[:, 20000:])
+    total = (_hist(a, None, edges, (1, 1), "cell") + _hist(b, None, edges, (1, 1), "cell")
+             + _hist(a, b, edges, None, "cell") + _hist(b, a, edges, None, "cell"))
+    assert np.array_equal(total, whole)
+    # the same histogram whatever images the coordinates are given in
+    shifted = frames + (np.float32(2) * L)        # exact in float32 for these magnitudes? no:
+    # rounding moves coordinates by < 1e-5 A, so only near-edge pairs may change bins
+    moved = _hist(shifted.astype(np.float32), None, edges, (1, 1), "cell")
+    assert np.abs(moved - whole).sum() <= 1e-4 * whole.sum()
+
+
+def test_c3_structure_factor_of_a_lattice_at_full_size():
+    """32 768 = 32^3 particles on a simple-cubic lattice: N at Bragg points, 0 elsewhere."""
+    n = 32
+    a = float(L) / n
+    idx = np.arange(n)
+    pos = (a * np.stack(np.meshgrid(idx, idx, idx, indexing="ij"), -1).reshape(-1, 3)).astype(np.float32)
+    grid = 2 * np.pi * np.arange(8) / float(L)
+    q = np.stack(np.meshgrid(grid, grid, grid), -1).reshape(-1, 3)       # 512 wavevectors
+    q_bragg = 2 * np.pi / a * np.array([[1, 0, 0], [0, 1, 1], [1, 1, 1]], dtype=float)
+    for wavevectors in (q, np.vstack((q, q_bragg))):
+        eng = _core.SqEngine(wavevectors, [N // 2, N // 2], ((None, None),))
+        eng.accumulate(pos[None])
+        ssf = eng.result()[0] / N
+        eng.close()
+        assert np.isclose(ssf[0], N)                      # q = 0
+        assert np.allclose(ssf[1:512], 0.0, atol=1e-5)    # no Bragg point below 2 pi / a on this grid
+        if len(wavevectors) > 512:
+            assert np.allclose(ssf[512:], N, rtol=1e-6)
+
+
+def test_c4_long_trajectory_msd():
+    """T = 100 000 frames: FFT MSD equals the direct definition at chosen lags; free-walk slope."""
+    T, n = 100_000, 64
+    d = _core.synth_random_walk(T, n, [1.0, 1.0, 1.0], 0.1, seed=7, dtype=np.float64)
+    eng = _core.MsdEngine(T, 1, 1)
+    eng.push_device(0, d.ptr, n, 0, n)
+    msd_sum, traj = eng.result()
+    eng.close()
+    pos = d.to_host()
+    d.free()
+    msd = msd_sum[0, 0] / n
+    for m in (1, 7, 1000, 50_000, 99_999):
+        direct = ((pos[m:] - pos[:-m]) ** 2).sum(axis=-1).mean()
+        assert np.isclose(msd[m], direct, rtol=1e-6), m
+    assert abs(msd[0]) < 1e-6
+    m = np.arange(1, 2000)
+    assert np.allclose(msd[1:2000] / (3 * 0.01 * m), 1.0, atol=0.05)
+    assert np.allclose(traj[0, 0], pos.sum(axis=1), rtol=1e-12, atol=1e-9)
