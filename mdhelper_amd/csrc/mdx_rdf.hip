@@ -286,11 +286,12 @@ static int launch_tiles(mdx_rdf *h, RdfArgs &a, int mode, int ipt, bool pbc, boo
 }
 
 // Cell-sorted path (mdx_rdf_cell.hpp): sort + tile boxes per frame, then the culled pair kernel.
+// Cell-sorted path (mdx_rdf_cell.hpp): sort + tile boxes per frame, then the culled pair kernel.
 static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const float *d_pos2,
                            int64_t n2, const float *d_boxes, int64_t n_frames, bool self, bool excl)
 {
     const int64_t n1p = ceil_div(n1, 128) * 128, n2p = ceil_div(n2, 128) * 128;
-    // per frame: wrapped + original float4 copies and one box per 64 particles
+    // per frame: wrapped + original float4 copies, one box per 64 and per 16 particles
     const int64_t per_frame = (32 + 3) * (n1p + (self ? 0 : n2p));
     int64_t slab = std::max<int64_t>(1, (int64_t(1) << 30) / per_frame);
     slab = std::min<int64_t>(std::min<int64_t>(slab, 32768), n_frames);
@@ -320,8 +321,7 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
         lds = sizeof(float4) * 256;
     const bool lower = h->edges.front() > 0.0;
     void (*kern)(CellArgs) = nullptr;
-#define MDX_CELL_PICK(E, L)                                               \
-    kern = gh ? rdf_cell_pair_kernel<E, L, true> : rdf_cell_pair_kernel<E, L, false>
+#define MDX_CELL_PICK(E, L) kern = gh ? rdf_cell_pair_kernel<E, L, 1> : rdf_cell_pair_kernel<E, L, 0>
     if (excl && lower) MDX_CELL_PICK(true, true);
     else if (excl) MDX_CELL_PICK(true, false);
     else if (lower) MDX_CELL_PICK(false, true);

@@ -230,22 +230,37 @@ __device__ inline void cell_pair_exact(const PairCtx<true> &c, const CellArgs &a
 // culling nearly every wave step holds a candidate, so a branch around it would always be
 // taken); only the histogram add is predicated and only the rare uncertain pair branches.
 // TAGS: 0 no exclusion, 1 compare exclusion tags.
-template <bool LOWER, int TAGS, typename Hist>
-__device__ inline void cell_step(const PairCtx<true> &c, const CellArgs &a, const double *sT,
+// wave-uniform float constants of the hot loop, forced into SGPRs
+struct CellHot {
+    float cand_hi, cand_lo, inv_w, pos0, sure_half;
+};
+
+__device__ inline float cell_uniform(float v)
+{
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+
+// MODE: 0 per-wave LDS histograms, 1 global histogram (bin tables too large for LDS).
+// Register budget matters here: with the fp64 box constants live across the hot loop the
+// kernel needed 106 VGPRs (4 waves/SIMD); rebuilding them inside the cold block brings it
+// to 72 (7 waves/SIMD) and 17 % more throughput.  (Appending the undecided pairs to a global
+// list for a second kernel was measured too: the append atomics made it 10x slower.)
+template <bool LOWER, int TAGS, int MODE, typename Hist>
+__device__ inline void cell_step(const CellHot &c, const CellArgs &a, const double *sT,
                                  const Hist &hist, float fx, float fy, float fz, int tag_i,
-                                 int tag_j, float pos0, float sure_half, const float4 *po_i,
-                                 const float4 *po_j, unsigned w, unsigned &n_exact)
+                                 int tag_j, const float4 *po1f, const float4 *po2f, unsigned i_idx,
+                                 unsigned j_idx, unsigned frame, unsigned w, unsigned &n_exact)
 {
     float r2 = __fmaf_rn(fz, fz, __fmaf_rn(fy, fy, fx * fx));
     // pos = (sqrt(r2) - r0) / width; raw v_sqrt_f32 (a denormal r2 ends on the exact path)
-    float pos = __fmaf_rn(__builtin_amdgcn_sqrtf(r2), c.inv_wf, pos0);
+    float pos = __fmaf_rn(__builtin_amdgcn_sqrtf(r2), c.inv_w, c.pos0);
     // v_fract_f32 = pos - floor(pos).  A sure candidate has pos > eta > 0 (the candidate window
     // keeps pos > -eta and such a pos has fract > 1 - eta, i.e. is not sure), so truncation
     // by v_cvt_i32_f32 is its floor.
     float fr = __builtin_amdgcn_fractf(pos);
     bool cand = LOWER ? (r2 < c.cand_hi && r2 >= c.cand_lo) : (r2 < c.cand_hi);
     // farther than eta from both neighbouring edges (covers both range ends)
-    bool sure = fabsf(fr - 0.5f) < sure_half;
+    bool sure = fabsf(fr - 0.5f) < c.sure_half;
     if (TAGS)
         cand = cand && (tag_i != tag_j);
     // Scalar mask arithmetic (no extra VALU compare for the negation); the wave-uniform test
@@ -254,23 +269,38 @@ __device__ inline void cell_step(const PairCtx<true> &c, const CellArgs &a, cons
     const unsigned long long m_sure = __builtin_amdgcn_ballot_w64(sure);
     if (__builtin_expect((m_cand & ~m_sure) != 0ull, 0)) {
         if (cand && !sure) {
-            ++n_exact;
-            cell_pair_exact(c, a, sT, hist, po_i, po_j, w);
+            {
+                ++n_exact;
+                // the fp64 constants are rebuilt here, in the cold block, instead of living in
+                // registers across the hot loop
+                PairCtx<true> cx;
+                const float *box = a.boxes + int64_t(frame) * 6;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    cx.Ld[k] = (double)box[k];
+                    cx.invd[k] = (double)(float)(1.0 / (double)box[k]);
+                }
+                cx.r0f = (float)a.r0;
+                cx.inv_wf = c.inv_w;
+                cell_pair_exact(cx, a, sT, hist, po1f + i_idx, po2f + j_idx, w);
+            }
         }
     }
     if (cand && sure)
         hist.add((int)pos, w);
 }
 
-template <bool EXCL, bool LOWER, bool GH>
+template <bool EXCL, bool LOWER, int MODE>
 __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
 {
+    constexpr bool GH = MODE == 1;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float4 *sJ = reinterpret_cast<float4 *>(smem_raw);                        // [4 waves][64]
     double *sT = reinterpret_cast<double *>(smem_raw + sizeof(float4) * 256); // [n_bins+1]
     unsigned *sh = reinterpret_cast<unsigned *>(sT + (a.n_bins + 1));         // [n_hist][n_bins]
     __shared__ unsigned s_exact, s_units, s_general, s_qn, s_qnext;
     __shared__ unsigned sQ[CELL_QCAP];
+    __shared__ float s_geo[32];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frame = blockIdx.y + a.frame0;
@@ -290,47 +320,62 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
     }
     __syncthreads();
 
-    PairCtx<true> ctx;
-    const float *box = a.boxes + int64_t(frame) * 6;
-    ctx.init(box, a.maxabs_bits, a.r0, a.r1, a.n_bins);
+    // Per-block geometry and constants are derived once (fp64 error-bound arithmetic included)
+    // and parked in LDS; the hot loop keeps only five floats of them, in SGPRs.
+    //   s_geo: [0..2] L, [3..5] 1/L (float32), [6] cut, [7] cut^2,
+    //          [8..10] cI, [11..13] hI, [14..19] cH[2][3], [20..25] hH[2][3],
+    //          [26] cand_hi, [27] cand_lo, [28] inv_w, [29] pos0, [30] sure_half
     unsigned long long *out =
         a.counts + int64_t((blockIdx.x + 7 * blockIdx.y) % a.n_rep) * a.n_bins;
+    if (tid == 0) {
+        PairCtx<true> ctx;
+        ctx.init(a.boxes + int64_t(frame) * 6, a.maxabs_bits, a.r0, a.r1, a.n_bins);
+        const float Lmax = fmaxf(ctx.Lf[0], fmaxf(ctx.Lf[1], ctx.Lf[2]));
+        // a tile pair is culled when its box gap exceeds r1 + error bound + slack
+        const float cut = sqrtf(ctx.cand_hi) + 1e-5f * Lmax;
+        const float4 *BB1 = a.bb1 + int64_t(frame) * (a.n1p / 64) * 2 + int64_t(I) * 4;
+        const float4 l0 = BB1[0], h0 = BB1[1], l1 = BB1[2], h1 = BB1[3];
+        const float lo0[3] = {l0.x, l0.y, l0.z}, hi0[3] = {h0.x, h0.y, h0.z};
+        const float lo1[3] = {l1.x, l1.y, l1.z}, hi1[3] = {h1.x, h1.y, h1.z};
+        for (int k = 0; k < 3; ++k) {
+            s_geo[k] = ctx.Lf[k];
+            s_geo[3 + k] = ctx.invf[k];
+            const float lo = fminf(lo0[k], lo1[k]), hi = fmaxf(hi0[k], hi1[k]);
+            s_geo[8 + k] = 0.5f * (lo + hi);
+            s_geo[11 + k] = 0.5f * (hi - lo);
+            s_geo[14 + k] = 0.5f * (lo0[k] + hi0[k]);
+            s_geo[17 + k] = 0.5f * (lo1[k] + hi1[k]);
+            s_geo[20 + k] = 0.5f * (hi0[k] - lo0[k]);
+            s_geo[23 + k] = 0.5f * (hi1[k] - lo1[k]);
+        }
+        s_geo[6] = cut;
+        s_geo[7] = cut * cut;
+        s_geo[26] = ctx.cand_hi;
+        s_geo[27] = ctx.cand_lo;
+        s_geo[28] = ctx.inv_wf;
+        s_geo[29] = -ctx.r0f * ctx.inv_wf;
+        s_geo[30] = 0.5f - ctx.eta;
+    }
+    __syncthreads();
+    CellHot hot;
+    hot.cand_hi = cell_uniform(s_geo[26]);
+    hot.cand_lo = cell_uniform(s_geo[27]);
+    hot.inv_w = cell_uniform(s_geo[28]);
+    hot.pos0 = cell_uniform(s_geo[29]);
+    hot.sure_half = cell_uniform(s_geo[30]);
     const double *thr = GH ? a.thresh : sT;
     HistLds hl{sh + (GH ? 0 : (wave % a.n_hist) * a.n_bins)};
     HistGlobal hg{out};
-    const float pos0 = -ctx.r0f * ctx.inv_wf;
-    const float sure_half = 0.5f - ctx.eta;
 
     const float4 *PW1 = a.pw1 + int64_t(frame) * a.n1p + int64_t(I) * 128;
-    const float4 *PO1 = a.po1 + int64_t(frame) * a.n1p + int64_t(I) * 128;
+    const float4 *PO1f = a.po1 + int64_t(frame) * a.n1p;     // this frame's original coordinates
+    const unsigned i_idx0 = unsigned(I) * 128u + unsigned(lane);
+    const unsigned fslab = unsigned(frame);
     const float4 *PW2 = a.pw2 + int64_t(frame) * a.n2p;
     const float4 *PO2 = a.po2 + int64_t(frame) * a.n2p;
     const float4 *BB2 = a.bb2 + int64_t(frame) * t64_2 * 2;
     const float4 *BB16 = a.bb16_2 + int64_t(frame) * t64_2 * 8;
     const float4 p0 = PW1[lane], p1 = PW1[64 + lane];
-
-    // boxes of the two i halves and of their union
-    float cH[2][3], hH[2][3], cI[3], hI[3];
-    {
-        const float4 *BB1 = a.bb1 + int64_t(frame) * (a.n1p / 64) * 2 + int64_t(I) * 4;
-        float4 l0 = BB1[0], h0 = BB1[1], l1 = BB1[2], h1 = BB1[3];
-        const float lo0[3] = {l0.x, l0.y, l0.z}, hi0[3] = {h0.x, h0.y, h0.z};
-        const float lo1[3] = {l1.x, l1.y, l1.z}, hi1[3] = {h1.x, h1.y, h1.z};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            cH[0][k] = 0.5f * (lo0[k] + hi0[k]);
-            hH[0][k] = 0.5f * (hi0[k] - lo0[k]);
-            cH[1][k] = 0.5f * (lo1[k] + hi1[k]);
-            hH[1][k] = 0.5f * (hi1[k] - lo1[k]);
-            float lo = fminf(lo0[k], lo1[k]), hi = fmaxf(hi0[k], hi1[k]);
-            cI[k] = 0.5f * (lo + hi);
-            hI[k] = 0.5f * (hi - lo);
-        }
-    }
-    // a tile pair is culled when its box gap exceeds r1 + error bound + slack
-    const float Lmax = fmaxf(ctx.Lf[0], fmaxf(ctx.Lf[1], ctx.Lf[2]));
-    const float cut = sqrtf(ctx.cand_hi) + 1e-5f * Lmax;
-    const float cut2 = cut * cut;
 
     float4 *sJw = sJ + wave * 64;
     unsigned n_exact = 0, n_units = 0, n_general = 0;
@@ -357,11 +402,12 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
                 int general = 0;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    float d = cJ[k] - cI[k];
-                    float sft = rintf(d * ctx.invf[k]);
-                    d = __fmaf_rn(-sft, ctx.Lf[k], d);
+                    const float Lk = s_geo[k], cut = s_geo[6];
+                    float d = cJ[k] - s_geo[8 + k];
+                    float sft = rintf(d * s_geo[3 + k]);
+                    d = __fmaf_rn(-sft, Lk, d);
                     code |= unsigned((int)sft + 1) << (22 + 2 * k);
-                    float ext = hI[k] + hJ[k];
+                    float ext = s_geo[11 + k] + hJ[k];
                     float reach = fabsf(d) + ext;
                     float gap = fmaxf(0.f, fabsf(d) - ext);
                     g2 = __fmaf_rn(gap, gap, g2);
@@ -370,13 +416,12 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
                     // L/2 is rejected by the filter (|sep| >= L/2 >= cut) and its true image
                     // component is L - |sep| >= L - reach: when that exceeds the cut it is out
                     // of range under the contract too, so the shifted value is harmless.
-                    const float halfL = 0.4999f * ctx.Lf[k];
-                    general |= !(reach < halfL) &&
-                               !(cut < halfL && reach < ctx.Lf[k] - cut - 1e-4f * ctx.Lf[k]);
+                    const float halfL = 0.4999f * Lk;
+                    general |= !(reach < halfL) && !(cut < halfL && reach < Lk - cut - 1e-4f * Lk);
                 }
                 code |= unsigned(J) | (unsigned(general) << 28);
             }
-            const bool keep = g2 <= cut2;
+            const bool keep = g2 <= s_geo[7];
             const unsigned long long mask = __ballot(keep);
             if (mask) {
                 unsigned base = 0;
@@ -399,9 +444,9 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
             const unsigned code = sQ[e];
             const int Jt = int(code & 0x3fffffu);
             const int gen = int(code >> 28) & 1;
-            const float sx = float(int((code >> 22) & 3u) - 1) * ctx.Lf[0];
-            const float sy = float(int((code >> 24) & 3u) - 1) * ctx.Lf[1];
-            const float sz = float(int((code >> 26) & 3u) - 1) * ctx.Lf[2];
+            const float sx = float(int((code >> 22) & 3u) - 1) * s_geo[0];
+            const float sy = float(int((code >> 24) & 3u) - 1) * s_geo[1];
+            const float sz = float(int((code >> 26) & 3u) - 1) * s_geo[2];
             float4 pj = PW2[int64_t(Jt) * 64 + lane];
             if (!gen) {
                 pj.x -= sx;
@@ -421,11 +466,12 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
                     sg2 = 0.f;
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
-                        float gap = fmaxf(0.f, fabsf(cJ[k] - cH[h][k]) - (hH[h][k] + hJ[k]));
+                        float gap = fmaxf(0.f, fabsf(cJ[k] - s_geo[14 + 3 * h + k]) -
+                                                   (s_geo[20 + 3 * h + k] + hJ[k]));
                         sg2 = __fmaf_rn(gap, gap, sg2);
                     }
                 }
-                sub = (unsigned)__ballot(sg2 <= cut2) & 0xffu;
+                sub = (unsigned)__ballot(sg2 <= s_geo[7]) & 0xffu;
             }
             // wave-private slab: LDS operations of one wave execute in order
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -434,7 +480,7 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
             __builtin_amdgcn_wave_barrier();
             const bool diag = a.self && Jt <= 2 * I + 1;
             const unsigned w = (a.self && !diag) ? 2u : 1u;
-            const float4 *POJ = PO2 + int64_t(Jt) * 64;
+            const unsigned jbase = unsigned(Jt) * 64u;
             // exclusion tags can only collide inside the diagonal tiles when exclusion == (1, 1)
             const bool tags = EXCL && (a.tags_everywhere || diag);
             if (!gen) {
@@ -445,11 +491,11 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
                     n_units += (bits & 1u) + (bits >> 1);
 #define MDX_CELL_ONE(TG, U0, U1, Q, JJ)                                                            \
     if (GH) {                                                                                      \
-        if (U0) cell_step<LOWER, TG>(ctx, a, thr, hg, Q.x - p0.x, Q.y - p0.y, Q.z - p0.z, __float_as_int(p0.w), __float_as_int(Q.w), pos0, sure_half, PO1 + lane, POJ + (JJ), w, n_exact); \
-        if (U1) cell_step<LOWER, TG>(ctx, a, thr, hg, Q.x - p1.x, Q.y - p1.y, Q.z - p1.z, __float_as_int(p1.w), __float_as_int(Q.w), pos0, sure_half, PO1 + 64 + lane, POJ + (JJ), w, n_exact); \
+        if (U0) cell_step<LOWER, TG, MODE>(hot, a, thr, hg, Q.x - p0.x, Q.y - p0.y, Q.z - p0.z, __float_as_int(p0.w), __float_as_int(Q.w), PO1f, PO2, i_idx0, jbase + (JJ), fslab, w, n_exact); \
+        if (U1) cell_step<LOWER, TG, MODE>(hot, a, thr, hg, Q.x - p1.x, Q.y - p1.y, Q.z - p1.z, __float_as_int(p1.w), __float_as_int(Q.w), PO1f, PO2, i_idx0 + 64u, jbase + (JJ), fslab, w, n_exact); \
     } else {                                                                                       \
-        if (U0) cell_step<LOWER, TG>(ctx, a, thr, hl, Q.x - p0.x, Q.y - p0.y, Q.z - p0.z, __float_as_int(p0.w), __float_as_int(Q.w), pos0, sure_half, PO1 + lane, POJ + (JJ), w, n_exact); \
-        if (U1) cell_step<LOWER, TG>(ctx, a, thr, hl, Q.x - p1.x, Q.y - p1.y, Q.z - p1.z, __float_as_int(p1.w), __float_as_int(Q.w), pos0, sure_half, PO1 + 64 + lane, POJ + (JJ), w, n_exact); \
+        if (U0) cell_step<LOWER, TG, MODE>(hot, a, thr, hl, Q.x - p0.x, Q.y - p0.y, Q.z - p0.z, __float_as_int(p0.w), __float_as_int(Q.w), PO1f, PO2, i_idx0, jbase + (JJ), fslab, w, n_exact); \
+        if (U1) cell_step<LOWER, TG, MODE>(hot, a, thr, hl, Q.x - p1.x, Q.y - p1.y, Q.z - p1.z, __float_as_int(p1.w), __float_as_int(Q.w), PO1f, PO2, i_idx0 + 64u, jbase + (JJ), fslab, w, n_exact); \
     }
 // four slab entries are fetched ahead of their use so the LDS latency overlaps the arithmetic
 #define MDX_CELL_RUN(TG, U0, U1)                                                                   \
@@ -483,11 +529,11 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
                     for (int u = 0; u < 2; ++u) {
                         const float4 &p = u ? p1 : p0;
                         float fx = q.x - p.x, fy = q.y - p.y, fz = q.z - p.z;
-                        fx = __fmaf_rn(-rintf(fx * ctx.invf[0]), ctx.Lf[0], fx);
-                        fy = __fmaf_rn(-rintf(fy * ctx.invf[1]), ctx.Lf[1], fy);
-                        fz = __fmaf_rn(-rintf(fz * ctx.invf[2]), ctx.Lf[2], fz);
-                        if (GH) cell_step<LOWER, EXCL ? 1 : 0>(ctx, a, thr, hg, fx, fy, fz, __float_as_int(p.w), __float_as_int(q.w), pos0, sure_half, PO1 + 64 * u + lane, POJ + jj, w, n_exact);
-                        else cell_step<LOWER, EXCL ? 1 : 0>(ctx, a, thr, hl, fx, fy, fz, __float_as_int(p.w), __float_as_int(q.w), pos0, sure_half, PO1 + 64 * u + lane, POJ + jj, w, n_exact);
+                        fx = __fmaf_rn(-rintf(fx * s_geo[3]), s_geo[0], fx);
+                        fy = __fmaf_rn(-rintf(fy * s_geo[4]), s_geo[1], fy);
+                        fz = __fmaf_rn(-rintf(fz * s_geo[5]), s_geo[2], fz);
+                        if (GH) cell_step<LOWER, EXCL ? 1 : 0, MODE>(hot, a, thr, hg, fx, fy, fz, __float_as_int(p.w), __float_as_int(q.w), PO1f, PO2, i_idx0 + 64u * u, jbase + jj, fslab, w, n_exact);
+                        else cell_step<LOWER, EXCL ? 1 : 0, MODE>(hot, a, thr, hl, fx, fy, fz, __float_as_int(p.w), __float_as_int(q.w), PO1f, PO2, i_idx0 + 64u * u, jbase + jj, fslab, w, n_exact);
                     }
                 }
             }
