@@ -157,8 +157,8 @@ static bool sq_detect_lattice(const double *q, int64_t n_q, SqLattice &lat, std:
         lat.R[k] = mmax - mmin + 1;
         total += lat.R[k];
     }
-    // particles per LDS stage: as many as fit ~96 KiB of tables, between 8 and 64
-    int tile = int((96 * 1024) / (size_t(16) * total));
+    // particles per LDS stage: as many as fit ~26 KiB of tables (6 blocks per CU), between 8 and 64
+    int tile = int((26 * 1024) / (size_t(16) * total));
     if (tile < 8)
         return false;
     lat.tile = std::min(tile, 64);

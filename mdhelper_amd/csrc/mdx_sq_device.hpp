@@ -122,7 +122,8 @@ struct SqLattice {
     int tile;      // particles per LDS stage
 };
 
-__global__ __launch_bounds__(SQ_THREADS) void sq_rho_lattice_kernel(
+// 6 waves/SIMD: 78 VGPRs without spills (unbounded the table-build code takes 120 = 4 waves)
+__global__ __launch_bounds__(SQ_THREADS, 6) void sq_rho_lattice_kernel(
     const float *__restrict__ pos, int64_t n_atoms, const short4 *__restrict__ mtrip, int n_q,
     SqLattice lat, const int64_t *__restrict__ group_offsets, int n_groups, int n_split,
     double2 *__restrict__ rho)
