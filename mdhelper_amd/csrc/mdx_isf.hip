@@ -162,7 +162,7 @@ struct mdx_isf {
     std::vector<int64_t> offsets;
     std::vector<int64_t> ranges;      // particle range of every incoherent slot
     DeviceBuffer d_q, d_offsets, d_pairs, d_ranges, d_rho_ring, d_pos_ring, d_cisf, d_iisf, d_part,
-        d_rho_tmp;
+        d_pos_stage;
     StreamTimer timer;
 };
 
@@ -254,7 +254,7 @@ int mdx_isf_destroy(mdx_isf_t h)
         (void)hipStreamSynchronize(h->stream);
     h->timer.destroy();
     for (DeviceBuffer *b : {&h->d_q, &h->d_offsets, &h->d_pairs, &h->d_ranges, &h->d_rho_ring,
-                            &h->d_pos_ring, &h->d_cisf, &h->d_iisf, &h->d_part, &h->d_rho_tmp})
+                            &h->d_pos_ring, &h->d_cisf, &h->d_iisf, &h->d_part, &h->d_pos_stage})
         b->release();
     if (h->stream)
         (void)hipStreamDestroy(h->stream);
@@ -299,10 +299,10 @@ int mdx_isf_accumulate(mdx_isf_t h, const float *pos, int64_t n, int64_t n_frame
             MDX_HIP(hipMemcpyAsync(dst, src, size_t(12) * n * nf, hipMemcpyHostToDevice, h->stream));
             d_new = dst;
         } else {
-            MDX_TRY(h->d_rho_tmp.ensure(size_t(12) * n * nf));
-            MDX_HIP(hipMemcpyAsync(h->d_rho_tmp.ptr, src, size_t(12) * n * nf, hipMemcpyHostToDevice,
+            MDX_TRY(h->d_pos_stage.ensure(size_t(12) * n * nf));
+            MDX_HIP(hipMemcpyAsync(h->d_pos_stage.ptr, src, size_t(12) * n * nf, hipMemcpyHostToDevice,
                                    h->stream));
-            d_new = h->d_rho_tmp.as<float>();
+            d_new = h->d_pos_stage.as<float>();
         }
         hipEvent_t ev = h->timer.begin();
         hipLaunchKernelGGL(sq_rho_kernel, dim3(qblocks, h->n_groups, (unsigned)nf), dim3(SQ_THREADS),

@@ -51,7 +51,6 @@ template <bool PBC> struct PairCtx {
     __device__ inline void init(const float *b, const unsigned *maxabs_bits, double r0, double r1,
                                 int n_bins)
     {
-        struct { double r0, r1; int n_bins; const unsigned *maxabs_bits; } a{r0, r1, n_bins, maxabs_bits};
         double Lmax = 0.0;
         if (PBC) {
 #pragma unroll
@@ -64,19 +63,19 @@ template <bool PBC> struct PairCtx {
                 Lmax = fmax(Lmax, Ld[k]);
             }
         }
-        const double M = (double)__uint_as_float(*a.maxabs_bits);
+        const double M = (double)__uint_as_float(*maxabs_bits);
         // per-component bound on |w_contract - w_float32|, safety included
         const double delta = 0x1p-22 * (2.0 * M + Lmax);
-        const double width = (a.r1 - a.r0) / a.n_bins;
-        const double margin_d = 1.7320508075688772 * delta + a.r1 * 0x1p-21;
-        r0f = (float)a.r0;
+        const double width = (r1 - r0) / n_bins;
+        const double margin_d = 1.7320508075688772 * delta + r1 * 0x1p-21;
+        r0f = (float)r0;
         inv_wf = (float)(1.0 / width);
-        double e = margin_d / width + a.n_bins * 0x1p-21 + 0x1p-20;
+        double e = margin_d / width + n_bins * 0x1p-21 + 0x1p-20;
         eta = (float)fmin(e, 1.0);
-        posmax = (float)a.n_bins - eta;
-        double hi = (a.r1 + margin_d);
+        posmax = (float)n_bins - eta;
+        double hi = (r1 + margin_d);
         cand_hi = (float)(hi * hi * (1.0 + 0x1p-20));
-        double lo = a.r0 - margin_d;
+        double lo = r0 - margin_d;
         cand_lo = lo > 0.0 ? (float)(lo * lo * (1.0 - 0x1p-20)) : -1.0f;
         if (!(M < 3.0e38))   // inf/NaN coordinates: everything goes to the exact path
             eta = 1.0f;
