@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--atoms", type=int, default=None)
     ap.add_argument("--algo", default="auto", choices=["auto", "exact", "filter", "cell"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-path", action="store_true",
+                    help="rdf: feed host (pageable) buffers through mdx_rdf_accumulate, i.e. the "
+                         "PCIe-inclusive rate; never the headline value")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time")
     return ap.parse_args()
 
@@ -116,8 +119,15 @@ def bench_rdf(args, world, wide=False):
     d_boxes = _core.DeviceArray.from_host(np.tile(box, (F, 1)), dev)
     eng = _core.RdfEngine(edges, (1, 1), algo=args.algo, dev=dev, timing=True)
 
-    def step():
-        eng.accumulate_device(traj.ptr, N, None, N, d_boxes.ptr, F)
+    if args.host_path:
+        h_traj = traj.to_host()
+        h_boxes = np.tile(box, (F, 1))
+
+        def step():
+            eng.accumulate(h_traj, None, h_boxes)
+    else:
+        def step():
+            eng.accumulate_device(traj.ptr, N, None, N, d_boxes.ptr, F)
 
     for _ in range(args.warmup):
         step()
@@ -136,7 +146,8 @@ def bench_rdf(args, world, wide=False):
     frames_total = args.steps * F * world.world
     launches = max(st["launches"], 1)
     kernel_s = st["kernel_ms"] * 1e-3
-    alg_bytes_per_launch = F * (12 * N + 24)
+    # one launch = one slab of frames (sort + pair kernel); algorithmic bytes 12 N + 24 per frame
+    alg_bytes_per_launch = args.steps * F * (12 * N + 24) / launches
     achieved = alg_bytes_per_launch * launches / kernel_s / 1e9 if kernel_s > 0 else 0.0
     pairs_eval_rate = st["pairs_evaluated"] / kernel_s if kernel_s > 0 else 0.0
     # HBM bytes from the PMC counters come from a separate rocprofv3 run (profiles/traffic.json)
@@ -156,10 +167,11 @@ def bench_rdf(args, world, wide=False):
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 filter + f64 contract arithmetic, u64 counts",
-        "data": "synthetic",
+        "data": "synthetic" + (" (host buffers, PCIe copy inside the timed region)"
+                               if args.host_path else ""),
         "config": {"workload": ("C2(ii)" if wide else "C2(i)") + f" RDF {N} atoms x {F} frames/GPU/step, "
                    f"L={L:.2f} A, n_bins={n_bins}, range=({rng[0]:g},{rng[1]:.4g}), exclusion=(1,1), "
-                   f"algo={args.algo}",
+                   f"algo={args.algo}" + (", host path" if args.host_path else ""),
                    "atoms": N, "frames_per_step_per_gpu": F, "n_bins": n_bins},
         "frames_per_sec": frames_total / dt,
         "pair_distances_covered_per_sec": frames_total * float(N) * N / dt,

@@ -226,7 +226,13 @@ struct mdx_rdf {
     int64_t excl1 = 0, excl2 = 0;
     int algo = MDX_RDF_ALGO_AUTO;
     int n_rep = 32;
-    DeviceBuffer d_thresh, d_counts, d_total, d_pack1, d_pack2, d_stage1, d_stage2, d_boxes, d_misc;
+    DeviceBuffer d_thresh, d_counts, d_total, d_pack1, d_pack2, d_misc;
+    // host-buffer entry point: double-buffered staging, copy stream, hand-over events
+    DeviceBuffer d_stage1[2], d_stage2[2], d_boxes[2];
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
+    bool stage_busy[2] = {false, false};
+    int ensure_copy_pipeline();
     DeviceBuffer d_pw1, d_po1, d_bb1, d_pw2, d_po2, d_bb2;   // cell path: sorted copies + tile boxes
     DeviceBuffer d_bb16_1, d_bb16_2;                         // boxes of the 16-particle chunks
     StreamTimer timer;
@@ -234,6 +240,18 @@ struct mdx_rdf {
     int64_t pairs_bruteforce = 0;   // distance evaluations executed by the brute-force tiles
     bool reduced_global = false;   // counts replica 0 holds an all-reduced total
 };
+
+int mdx_rdf::ensure_copy_pipeline()
+{
+    if (copy_stream)
+        return MDX_OK;
+    MDX_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b) {
+        MDX_HIP(hipEventCreateWithFlags(&ev_copied[b], hipEventDisableTiming));
+        MDX_HIP(hipEventCreateWithFlags(&ev_consumed[b], hipEventDisableTiming));
+    }
+    return MDX_OK;
+}
 
 static int launch_tiles(mdx_rdf *h, RdfArgs &a, int mode, int ipt, bool pbc, bool excl,
                         int64_t n_frames)
@@ -285,7 +303,6 @@ static int launch_tiles(mdx_rdf *h, RdfArgs &a, int mode, int ipt, bool pbc, boo
     return MDX_OK;
 }
 
-// Cell-sorted path (mdx_rdf_cell.hpp): sort + tile boxes per frame, then the culled pair kernel.
 // Cell-sorted path (mdx_rdf_cell.hpp): sort + tile boxes per frame, then the culled pair kernel.
 static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const float *d_pos2,
                            int64_t n2, const float *d_boxes, int64_t n_frames, bool self, bool excl)
@@ -367,7 +384,8 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
         hipEvent_t ev = h->timer.begin();
         for (int64_t g0 = 0; g0 < nf; g0 += 32768) {
             a.frame0 = (int)g0;
-            dim3 grid((unsigned)(n1p / 128), (unsigned)std::min<int64_t>(32768, nf - g0));
+            a.n_frames = (int)std::min<int64_t>(32768, nf - g0);
+            dim3 grid((unsigned)(n1p / 128), (unsigned)(ceil_div(a.n_frames, 8) * 8));
             hipLaunchKernelGGL(kern, grid, dim3(256), lds, h->stream, a);
         }
         h->timer.end(ev);
@@ -517,8 +535,17 @@ int mdx_rdf_destroy(mdx_rdf_t h)
     if (h->stream)
         (void)hipStreamSynchronize(h->stream);
     h->timer.destroy();
+    if (h->copy_stream) {
+        (void)hipStreamSynchronize(h->copy_stream);
+        (void)hipStreamDestroy(h->copy_stream);
+        for (int b = 0; b < 2; ++b) {
+            (void)hipEventDestroy(h->ev_copied[b]);
+            (void)hipEventDestroy(h->ev_consumed[b]);
+        }
+    }
     for (DeviceBuffer *b : {&h->d_thresh, &h->d_counts, &h->d_total, &h->d_pack1, &h->d_pack2,
-                            &h->d_stage1, &h->d_stage2, &h->d_boxes, &h->d_misc, &h->d_pw1,
+                            &h->d_stage1[0], &h->d_stage2[0], &h->d_boxes[0], &h->d_stage1[1],
+                            &h->d_stage2[1], &h->d_boxes[1], &h->d_misc, &h->d_pw1,
                             &h->d_po1, &h->d_bb1, &h->d_pw2, &h->d_po2, &h->d_bb2, &h->d_bb16_1,
                             &h->d_bb16_2})
         b->release();
@@ -577,32 +604,44 @@ int mdx_rdf_accumulate(mdx_rdf_t h, const float *pos1, int64_t n1, const float *
                         "frame %lld: box lengths must be positive", (long long)f);
         }
     }
-    // stage through HBM in slabs of <= 256 MiB per group
+    // Stage through HBM in slabs, double-buffered: the copy of slab k+1 (copy stream) overlaps
+    // the kernels of slab k (compute stream).  A buffer is refilled only after the kernels that
+    // read it have finished (event), and the call returns once the last copy has completed, so
+    // no host pointer is retained; the kernels of the last slabs may still be in flight.
     const int64_t per_frame = 12 * std::max(n1, n2);
-    const int64_t slab = std::max<int64_t>(1, (int64_t(256) << 20) / per_frame);
-    for (int64_t f0 = 0; f0 < n_frames; f0 += slab) {
+    const int64_t slab = std::max<int64_t>(1, (int64_t(64) << 20) / per_frame);
+    MDX_TRY(h->ensure_copy_pipeline());
+    for (int64_t f0 = 0, k = 0; f0 < n_frames; f0 += slab, ++k) {
         const int64_t nf = std::min(slab, n_frames - f0);
-        MDX_TRY(h->d_stage1.ensure(size_t(12) * n1 * nf));
-        MDX_HIP(hipMemcpyAsync(h->d_stage1.ptr, pos1 + f0 * n1 * 3, size_t(12) * n1 * nf,
-                               hipMemcpyHostToDevice, h->stream));
+        const int b = int(k & 1);
+        if (h->stage_busy[b]) {
+            MDX_HIP(hipEventSynchronize(h->ev_consumed[b]));
+            h->stage_busy[b] = false;
+        }
+        MDX_TRY(h->d_stage1[b].ensure(size_t(12) * n1 * nf));
+        MDX_HIP(hipMemcpyAsync(h->d_stage1[b].ptr, pos1 + f0 * n1 * 3, size_t(12) * n1 * nf,
+                               hipMemcpyHostToDevice, h->copy_stream));
         const float *d2 = nullptr;
         if (!same) {
-            MDX_TRY(h->d_stage2.ensure(size_t(12) * n2 * nf));
-            MDX_HIP(hipMemcpyAsync(h->d_stage2.ptr, pos2 + f0 * n2 * 3, size_t(12) * n2 * nf,
-                                   hipMemcpyHostToDevice, h->stream));
-            d2 = h->d_stage2.as<float>();
+            MDX_TRY(h->d_stage2[b].ensure(size_t(12) * n2 * nf));
+            MDX_HIP(hipMemcpyAsync(h->d_stage2[b].ptr, pos2 + f0 * n2 * 3, size_t(12) * n2 * nf,
+                                   hipMemcpyHostToDevice, h->copy_stream));
+            d2 = h->d_stage2[b].as<float>();
         }
         const float *db = nullptr;
         if (boxes) {
-            MDX_TRY(h->d_boxes.ensure(size_t(24) * nf));
-            MDX_HIP(hipMemcpyAsync(h->d_boxes.ptr, boxes + f0 * 6, size_t(24) * nf,
-                                   hipMemcpyHostToDevice, h->stream));
-            db = h->d_boxes.as<float>();
+            MDX_TRY(h->d_boxes[b].ensure(size_t(24) * nf));
+            MDX_HIP(hipMemcpyAsync(h->d_boxes[b].ptr, boxes + f0 * 6, size_t(24) * nf,
+                                   hipMemcpyHostToDevice, h->copy_stream));
+            db = h->d_boxes[b].as<float>();
         }
-        MDX_TRY(accumulate_device(h, h->d_stage1.as<float>(), n1, d2, n2, db, nf));
-        // the staging buffers are reused by the next slab
-        MDX_HIP(hipStreamSynchronize(h->stream));
+        MDX_HIP(hipEventRecord(h->ev_copied[b], h->copy_stream));
+        MDX_HIP(hipStreamWaitEvent(h->stream, h->ev_copied[b], 0));
+        MDX_TRY(accumulate_device(h, h->d_stage1[b].as<float>(), n1, d2, n2, db, nf));
+        MDX_HIP(hipEventRecord(h->ev_consumed[b], h->stream));
+        h->stage_busy[b] = true;
     }
+    MDX_HIP(hipStreamSynchronize(h->copy_stream));
     return MDX_OK;
 }
 

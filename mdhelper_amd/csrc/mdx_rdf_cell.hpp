@@ -43,6 +43,7 @@ struct CellArgs {
     int n1p, n2p;                // padded particle counts (multiples of 128)
     int n_bins, n_hist, n_rep;
     int self, frame0;
+    int n_frames;                // frames of this launch (grid.y is padded to a multiple of 8)
     int tags_everywhere;         // 0: exclusion tags can only collide inside the diagonal tiles
 };
 
@@ -303,8 +304,16 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
     __shared__ float s_geo[32];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int frame = blockIdx.y + a.frame0;
-    const int I = blockIdx.x;                       // 128-particle i tile = two 64-particle halves
+    // Workgroups are dealt round-robin to the 8 XCDs in linear block order.  Blocks of one
+    // frame are therefore given linear ids of one residue mod 8, so that a frame's sorted
+    // copies are streamed through a single XCD's L2 instead of all eight.
+    const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x;
+    const unsigned per_xcd = lin >> 3;
+    const int frame_l = int(per_xcd / gridDim.x) * 8 + int(lin & 7u);
+    if (frame_l >= a.n_frames)
+        return;
+    const int frame = frame_l + a.frame0;
+    const int I = int(per_xcd % gridDim.x);         // 128-particle i tile = two 64-particle halves
     const int t64_2 = a.n2p / 64;
 
     if (!GH) {
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
     //          [8..10] cI, [11..13] hI, [14..19] cH[2][3], [20..25] hH[2][3],
     //          [26] cand_hi, [27] cand_lo, [28] inv_w, [29] pos0, [30] sure_half
     unsigned long long *out =
-        a.counts + int64_t((blockIdx.x + 7 * blockIdx.y) % a.n_rep) * a.n_bins;
+        a.counts + int64_t((I + 7 * frame_l) % a.n_rep) * a.n_bins;
     if (tid == 0) {
         PairCtx<true> ctx;
         ctx.init(a.boxes + int64_t(frame) * 6, a.maxabs_bits, a.r0, a.r1, a.n_bins);
