@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--host-path", action="store_true",
                     help="rdf: feed host (pageable) buffers through mdx_rdf_accumulate, i.e. the "
                          "PCIe-inclusive rate; never the headline value")
+    ap.add_argument("--traj-file", action="store_true",
+                    help="rdf: write the frames to an AMBER NetCDF file first and feed the engine "
+                         "through the native reader (file -> pinned -> HBM inside the timed region)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time")
     return ap.parse_args()
 
@@ -119,7 +122,38 @@ def bench_rdf(args, world, wide=False):
     d_boxes = _core.DeviceArray.from_host(np.tile(box, (F, 1)), dev)
     eng = _core.RdfEngine(edges, (1, 1), algo=args.algo, dev=dev, timing=True)
 
-    if args.host_path:
+    traj_file = None
+    if args.traj_file:
+        import tempfile
+        from scipy.io import netcdf_file
+        from mdhelper_amd.io import TrajectoryFile
+        h_traj = traj.to_host()
+        tmp = tempfile.NamedTemporaryFile(suffix=".nc", delete=False)
+        tmp.close()
+        with netcdf_file(tmp.name, "w", version=2) as nc:
+            nc.Conventions = "AMBER"
+            nc.createDimension("frame", None)
+            nc.createDimension("spatial", 3)
+            nc.createDimension("atom", N)
+            nc.createDimension("cell_spatial", 3)
+            nc.createDimension("cell_angular", 3)
+            v_t = nc.createVariable("time", "f", ("frame",))
+            v_x = nc.createVariable("coordinates", "f", ("frame", "atom", "spatial"))
+            v_l = nc.createVariable("cell_lengths", "d", ("frame", "cell_spatial"))
+            v_a = nc.createVariable("cell_angles", "d", ("frame", "cell_angular"))
+            for f in range(F):
+                v_t[f] = f
+                v_x[f] = h_traj[f]
+                v_l[f] = box[:3]
+                v_a[f] = box[3:]
+        del h_traj
+        traj_file = TrajectoryFile(tmp.name)
+        h_boxes = traj_file.read_boxes(np.arange(F))
+        all_frames = np.arange(F)
+
+        def step():
+            eng.accumulate_traj(traj_file, all_frames, h_boxes)
+    elif args.host_path:
         h_traj = traj.to_host()
         h_boxes = np.tile(box, (F, 1))
 
@@ -171,7 +205,8 @@ def bench_rdf(args, world, wide=False):
                                if args.host_path else ""),
         "config": {"workload": ("C2(ii)" if wide else "C2(i)") + f" RDF {N} atoms x {F} frames/GPU/step, "
                    f"L={L:.2f} A, n_bins={n_bins}, range=({rng[0]:g},{rng[1]:.4g}), exclusion=(1,1), "
-                   f"algo={args.algo}" + (", host path" if args.host_path else ""),
+                   f"algo={args.algo}" + (", host path" if args.host_path else "")
+                   + (", NetCDF file through the native reader" if args.traj_file else ""),
                    "atoms": N, "frames_per_step_per_gpu": F, "n_bins": n_bins},
         "frames_per_sec": frames_total / dt,
         "pair_distances_covered_per_sec": frames_total * float(N) * N / dt,
@@ -197,6 +232,9 @@ def bench_rdf(args, world, wide=False):
     }
     if world.rank == 0 and world.world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_rdf(args, traj, box, edges, rng, n_bins, N, eng)
+    if traj_file is not None:
+        traj_file.close()
+        os.unlink(tmp.name)
     eng.close()
     traj.free()
     d_boxes.free()

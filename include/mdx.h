@@ -41,6 +41,7 @@ extern "C" {
 #define MDX_ERR_RCCL (-6)          /* -> RuntimeError        */
 #define MDX_ERR_OUT_OF_MEMORY (-7) /* -> MemoryError         */
 #define MDX_ERR_STATE (-8)         /* -> RuntimeError        */
+#define MDX_ERR_IO (-9)            /* -> OSError             */
 
 /* ------------------------------------------------------------------ runtime */
 
@@ -129,6 +130,9 @@ int mdx_rdf_enable_timing(mdx_rdf_t h, int on);
 /* Raw device counters since reset: [0] exact re-evaluations, [1] (64 x 16)-pair units run by
  * the cell kernel, [2] units on its per-pair image-search path, [3] brute-force evaluations. */
 int mdx_rdf_debug_counters(mdx_rdf_t h, int64_t out[4]);
+/* Cell path: the sorted copies (wrapped and original float4 rows, n_pad rows) of one frame of
+ * the most recent slab — for debugging the tile logic on the host. */
+int mdx_rdf_debug_sorted(mdx_rdf_t h, int64_t frame, int64_t n_pad, float *pw, float *po);
 
 /* Function-level drop-in for structure.radial_histogram (structure.py:32-104):
  * one frame, host buffers, counts overwritten. */
@@ -219,6 +223,44 @@ int mdx_msd_enable_timing(mdx_msd_t h, int on);
  * negative lags sum_k a[k+m] b[k] are written there too. */
 int mdx_correlate(int dev, const double *a, const double *b, int64_t n_series, int64_t n_t,
                   double *out, double *neg_out);
+
+/* ------------------------------------------------------- trajectory ingest */
+
+/* Native readers for the files the reference's users analyse: AMBER NetCDF trajectories
+ * (the container and variables its own writer produces,
+ * src/mdhelper/openmm/file.py:49-52 `NETCDF3_64BIT_OFFSET`, :160-188 `coordinates`,
+ * `cell_lengths`, `cell_angles`, `time`) and CHARMM/NAMD DCD.  They replace the per-frame
+ * Python reader behind `universe.trajectory[frame]` (structure.py:796, transport.py:976-985)
+ * on the way to the GPU: raw records go through pinned buffers to HBM and are byte-swapped /
+ * transposed / gathered there.  format: 1 NetCDF, 2 DCD. */
+typedef struct mdx_traj *mdx_traj_t;
+int mdx_traj_open(mdx_traj_t *out, const char *path);
+int mdx_traj_close(mdx_traj_t h);
+int mdx_traj_info(mdx_traj_t h, int64_t *n_frames, int64_t *n_atoms, int *has_box, int *has_time,
+                  int *format);
+/* Host reads of the listed frames: float32[n][n_atoms][3] (ts.positions), float32[n][6]
+ * (ts.dimensions: lx ly lz alpha beta gamma), float64[n] times in ps. */
+int mdx_traj_read_positions(mdx_traj_t h, const int64_t *frames, int64_t n, float *out);
+int mdx_traj_read_boxes(mdx_traj_t h, const int64_t *frames, int64_t n, float *boxes6);
+int mdx_traj_read_times(mdx_traj_t h, const int64_t *frames, int64_t n, double *times);
+/* The listed frames into HBM: d_out float32[n][n_sel][3].  d_index: device int32[n_sel]
+ * particle indices, or NULL for the first n_sel particles (n_sel <= 0: all). */
+int mdx_traj_load_device(mdx_traj_t h, int dev, const int64_t *frames, int64_t n,
+                         const int32_t *d_index, int64_t n_sel, float *d_out);
+/* RDF over frames of a trajectory file.  boxes: host float32[n_frames][6] of those frames
+ * (mdx_traj_read_boxes) or NULL; index1/index2: host int32 particle selections (ag.indices),
+ * NULL = all particles; index2 == NULL with n2 == 0 = the same group twice. */
+int mdx_rdf_accumulate_traj(mdx_rdf_t h, mdx_traj_t traj, const int64_t *frames,
+                            int64_t n_frames, const float *boxes, const int32_t *index1,
+                            int64_t n1, const int32_t *index2, int64_t n2);
+/* S(q) / ISF over frames of a trajectory file.  index: host int32[n_index] particle indices
+ * in the order of the concatenated groups (the `self._positions[s] = g.positions` fill of
+ * structure.py:1484-1486), or NULL for the file's first n_index particles (<= 0: all).
+ * The ISF consumes the frames in the order listed. */
+int mdx_sq_accumulate_traj(mdx_sq_t h, mdx_traj_t traj, const int64_t *frames, int64_t n_frames,
+                           const int32_t *index, int64_t n_index);
+int mdx_isf_accumulate_traj(mdx_isf_t h, mdx_traj_t traj, const int64_t *frames,
+                            int64_t n_frames, const int32_t *index, int64_t n_index);
 
 #ifdef __cplusplus
 }

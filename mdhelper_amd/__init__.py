@@ -13,3 +13,4 @@ __version__ = "0.1.0"
 
 from . import algorithm, analysis  # noqa: E402,F401
 from .universe import ArrayUniverse  # noqa: E402,F401
+from .io import FileUniverse  # noqa: E402,F401

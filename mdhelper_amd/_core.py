@@ -191,6 +191,19 @@ class RdfEngine(_Engine):
     def accumulate_device(self, d_pos1, n1, d_pos2, n2, d_boxes, n_frames):
         check(lib().mdx_rdf_accumulate_device(self.handle, d_pos1, n1, d_pos2, n2, d_boxes, n_frames))
 
+    def accumulate_traj(self, traj_file, frames, boxes, index1=None, index2=None, same=True):
+        """Frames of a native trajectory file (``io.TrajectoryFile``); ``index``: particle
+        selections (None = all particles), ``same``: one group against itself."""
+        f = np.ascontiguousarray(frames, dtype=np.int64)
+        b = None if boxes is None else np.ascontiguousarray(boxes, dtype=np.float32)
+        i1 = None if index1 is None else np.ascontiguousarray(index1, dtype=np.int32)
+        i2 = None if (same or index2 is None) else np.ascontiguousarray(index2, dtype=np.int32)
+        n1 = 0 if i1 is None else len(i1)
+        # index2 NULL with n2 == 0 means "the same group twice"; n2 < 0 can never mean that
+        n2 = 0 if same else (traj_file.n_atoms if i2 is None else len(i2))
+        check(lib().mdx_rdf_accumulate_traj(self.handle, traj_file.handle, _ptr(f), len(f), _ptr(b),
+                                            _ptr(i1), n1, _ptr(i2), n2))
+
     def counts(self):
         out = np.zeros(self.n_bins, dtype=np.int64)
         check(lib().mdx_rdf_counts(self.handle, _ptr(out)))
@@ -257,6 +270,13 @@ class SqEngine(_Engine):
     def accumulate_device(self, d_pos, n, n_frames):
         check(lib().mdx_sq_accumulate_device(self.handle, d_pos, n, n_frames))
 
+    def accumulate_traj(self, traj_file, frames, index=None):
+        """Frames of a native trajectory file; ``index``: particles in concatenated-group order."""
+        f = np.ascontiguousarray(frames, dtype=np.int64)
+        i = None if index is None else np.ascontiguousarray(index, dtype=np.int32)
+        check(lib().mdx_sq_accumulate_traj(self.handle, traj_file.handle, _ptr(f), len(f), _ptr(i),
+                                           0 if i is None else len(i)))
+
     def result(self):
         out = np.zeros((self.pairs.shape[0], self.q.shape[0]), dtype=np.float64)
         check(lib().mdx_sq_result(self.handle, _ptr(out)))
@@ -303,6 +323,13 @@ class IsfEngine(_Engine):
         if p.ndim == 2:
             p = p[None]
         check(lib().mdx_isf_accumulate(self.handle, _ptr(p), p.shape[1], p.shape[0]))
+
+    def accumulate_traj(self, traj_file, frames, index=None):
+        """Frames (in analysis order) of a native trajectory file; ``index`` as for SqEngine."""
+        f = np.ascontiguousarray(frames, dtype=np.int64)
+        i = None if index is None else np.ascontiguousarray(index, dtype=np.int32)
+        check(lib().mdx_isf_accumulate_traj(self.handle, traj_file.handle, _ptr(f), len(f), _ptr(i),
+                                            0 if i is None else len(i)))
 
     def result(self):
         cisf = np.zeros((self.n_lags, self.pairs.shape[0], self.q.shape[0]))

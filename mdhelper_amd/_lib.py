@@ -25,6 +25,7 @@ _EXC = {
     -6: RuntimeError,          # MDX_ERR_RCCL
     -7: MemoryError,           # MDX_ERR_OUT_OF_MEMORY
     -8: RuntimeError,          # MDX_ERR_STATE
+    -9: OSError,               # MDX_ERR_IO
 }
 
 RDF_ALGO = {"auto": 0, "exact": 1, "filter": 2, "cell": 3}
@@ -64,6 +65,7 @@ _SIGNATURES = {
                               POINTER(c_int64)]),
     "mdx_rdf_enable_timing": (c_int, [_vp, c_int]),
     "mdx_rdf_debug_counters": (c_int, [_vp, _vp]),
+    "mdx_rdf_debug_sorted": (c_int, [_vp, c_int64, c_int64, _vp, _vp]),
     "mdx_radial_histogram": (c_int, [c_int, _vp, c_int64, _vp, c_int64, c_int, _vp, _vp, c_int64, c_int64, _vp]),
     # structure factor
     "mdx_sq_create": (c_int, [POINTER(_vp), c_int, _vp, c_int64, _vp, c_int, _vp, c_int]),
@@ -96,6 +98,18 @@ _SIGNATURES = {
     "mdx_msd_stats": (c_int, [_vp, POINTER(c_int64), POINTER(c_double), POINTER(c_int64)]),
     "mdx_msd_enable_timing": (c_int, [_vp, c_int]),
     "mdx_correlate": (c_int, [c_int, _vp, _vp, c_int64, c_int64, _vp, _vp]),
+    # trajectory ingest
+    "mdx_traj_open": (c_int, [POINTER(_vp), c_char_p]),
+    "mdx_traj_close": (c_int, [_vp]),
+    "mdx_traj_info": (c_int, [_vp, POINTER(c_int64), POINTER(c_int64), POINTER(c_int), POINTER(c_int),
+                              POINTER(c_int)]),
+    "mdx_traj_read_positions": (c_int, [_vp, _vp, c_int64, _vp]),
+    "mdx_traj_read_boxes": (c_int, [_vp, _vp, c_int64, _vp]),
+    "mdx_traj_read_times": (c_int, [_vp, _vp, c_int64, _vp]),
+    "mdx_traj_load_device": (c_int, [_vp, c_int, _vp, c_int64, _vp, c_int64, _vp]),
+    "mdx_rdf_accumulate_traj": (c_int, [_vp, _vp, _vp, c_int64, _vp, _vp, c_int64, _vp, c_int64]),
+    "mdx_sq_accumulate_traj": (c_int, [_vp, _vp, _vp, c_int64, _vp, c_int64]),
+    "mdx_isf_accumulate_traj": (c_int, [_vp, _vp, _vp, c_int64, _vp, c_int64]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

@@ -309,12 +309,20 @@ class RadialDistributionFunction(DynamicAnalysisBase):
         mine = numbers[lo:hi]
         block = self._batch.capacity
         i1, i2 = self.ag1.indices, self.ag2.indices
-        all1 = len(i1) == traj._positions.shape[1] and np.array_equal(i1, np.arange(len(i1)))
+        all1 = len(i1) == traj.n_atoms and np.array_equal(i1, np.arange(len(i1)))
+        native = getattr(traj, "native", None)
+        if native is not None:
+            # trajectory file: raw frames stream file -> pinned memory -> HBM inside the library
+            block = max(block, 4096)
         for b0 in np.arange(0, len(mine), block):
             sel = mine[b0:b0 + block]
-            pos = traj.frame_block(sel)
             boxes = traj.box_block(sel)
             self._area_or_volume += float(np.prod(boxes[:, :3].astype(np.float64), axis=1).sum())
+            if native is not None:
+                self._engine.accumulate_traj(native, sel, boxes, None if all1 else i1,
+                                             None if self._same else i2, same=self._same)
+                continue
+            pos = traj.frame_block(sel)
             p1 = pos if all1 else pos[:, i1]
             p2 = None if self._same else pos[:, i2]
             self._engine.accumulate(p1, p2, boxes)
@@ -499,6 +507,35 @@ class StructureFactor(NumbaAnalysisBase):
         for g, gr, s in zip(self._groups, self._groupings, self._slices):
             self._positions[s] = _group_positions(g, gr)
         self._batch.add([self._positions])
+
+    # batched fast path (in-memory and file trajectories, groupings="atoms"): whole blocks of
+    # frames go to the engine, gathered in concatenated-group order, instead of one Python
+    # iteration per frame.  Shared with IntermediateScatteringFunction.
+    def run(self, start=None, stop=None, step=None, frames=None, verbose=None, **kwargs):
+        traj = self._trajectory
+        if not (_is_array_trajectory(traj) and all(g == "atoms" for g in self._groupings)):
+            return super().run(start=start, stop=stop, step=step, frames=frames, verbose=verbose,
+                               **kwargs)
+        self._setup_frames(traj, start=start, stop=stop, step=step, frames=frames)
+        self._prepare()
+        numbers = self._frame_numbers()
+        self.frames[:] = numbers
+        self.times[:] = numbers * traj.dt
+        lo, hi = getattr(self, "_frames_mine", (0, len(numbers)))
+        mine = numbers[lo:hi]
+        index = np.concatenate([np.asarray(g.indices) for g in self._groups])
+        identity = len(index) == traj.n_atoms and np.array_equal(index, np.arange(len(index)))
+        native = getattr(traj, "native", None)
+        block = 4096 if native is not None else self._batch.capacity
+        for b0 in np.arange(0, len(mine), block):
+            sel = mine[b0:b0 + block]
+            if native is not None:
+                self._engine.accumulate_traj(native, sel, None if identity else index)
+            else:
+                pos = traj.frame_block(sel)
+                self._engine.accumulate(pos if identity else pos[:, index])
+        self._conclude()
+        return self
 
     def _conclude(self) -> None:
         self._batch.flush()

@@ -72,4 +72,41 @@ struct StreamTimer {
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Double-buffered staging between a producer on a copy stream and the kernels on a handle's
+// compute stream: the fill of slab k+1 overlaps the kernels of slab k.  A buffer is refilled
+// only after the kernels that read it have finished (event), and run() returns once the last
+// fill has completed — no host pointer is retained — while the kernels of the last slabs may
+// still be in flight on the compute stream.
+struct StagePipeline {
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_filled[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
+    bool busy[2] = {false, false};
+    int ensure();
+    void destroy();
+    // fill(b, f0, nf): queue on copy_stream what brings items [f0, f0+nf) into staging set b;
+    // consume(b, f0, nf): queue on `compute` the kernels that read staging set b.
+    template <typename Fill, typename Consume>
+    int run(hipStream_t compute, int64_t n_items, int64_t slab, Fill fill, Consume consume)
+    {
+        MDX_TRY(ensure());
+        slab = slab < 1 ? 1 : slab;
+        for (int64_t f0 = 0, k = 0; f0 < n_items; f0 += slab, ++k) {
+            const int64_t nf = n_items - f0 < slab ? n_items - f0 : slab;
+            const int b = int(k & 1);
+            if (busy[b]) {
+                MDX_HIP(hipEventSynchronize(ev_consumed[b]));
+                busy[b] = false;
+            }
+            MDX_TRY(fill(b, f0, nf));
+            MDX_HIP(hipEventRecord(ev_filled[b], copy_stream));
+            MDX_HIP(hipStreamWaitEvent(compute, ev_filled[b], 0));
+            MDX_TRY(consume(b, f0, nf));
+            MDX_HIP(hipEventRecord(ev_consumed[b], compute));
+            busy[b] = true;
+        }
+        MDX_HIP(hipStreamSynchronize(copy_stream));
+        return MDX_OK;
+    }
+};
+
 }  // namespace mdx

@@ -16,3 +16,9 @@ int mdx_sq_internal_buffer(mdx_sq_t h, double **d_acc, int64_t *n, hipStream_t *
 int mdx_msd_internal_buffers(mdx_msd_t h, double **d_a, int64_t *na, double **d_b, int64_t *nb,
                              hipStream_t *stream);
 }
+
+// trajectory ingest: the C++ object behind an mdx_traj_t (mdx_traj.hpp)
+namespace mdx {
+struct Trajectory;
+}
+mdx::Trajectory *mdx_traj_internal(mdx_traj_t h);

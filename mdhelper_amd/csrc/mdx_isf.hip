@@ -23,6 +23,7 @@
 using namespace mdx;
 
 #include "mdx_sq_device.hpp"
+#include "mdx_traj.hpp"
 
 using namespace mdx_sq_dev;
 
@@ -162,11 +163,114 @@ struct mdx_isf {
     std::vector<int64_t> offsets;
     std::vector<int64_t> ranges;      // particle range of every incoherent slot
     DeviceBuffer d_q, d_offsets, d_pairs, d_ranges, d_rho_ring, d_pos_ring, d_cisf, d_iisf, d_part,
-        d_pos_stage;
+        d_pos_stage, d_index;
     StreamTimer timer;
 };
 
+// Frames must arrive in analysis order; consecutive calls continue the same series.
+// source(d_dst, done, nf) queues on h->stream whatever brings frames [done, done+nf) of the
+// caller's series into d_dst (float32[nf][n][3]).
+template <typename Source>
+static int isf_accumulate(mdx_isf *h, int64_t n, int64_t n_frames, Source source)
+{
+    MDX_REQUIRE(n >= h->n_total && n_frames >= 0, "bad size");
+    MDX_TRY(set_device(h->dev));
+    if (h->incoherent)
+        MDX_TRY(h->d_pos_ring.ensure(size_t(12) * n * h->ring_slots));
+    const int qblocks = (int)ceil_div(h->n_q, SQ_QPB);
+    int64_t done = 0;
+    while (done < n_frames) {
+        // a chunk: at most n_lags new frames, contiguous in the ring
+        const long long f0 = h->frames_seen;
+        const int slot0 = int(f0 % h->ring_slots);
+        const int64_t nf = std::min<int64_t>(std::min<int64_t>(h->n_lags, h->ring_slots - slot0),
+                                             n_frames - done);
+        float *d_new = nullptr;
+        if (h->incoherent) {
+            d_new = h->d_pos_ring.as<float>() + int64_t(slot0) * n * 3;
+        } else {
+            MDX_TRY(h->d_pos_stage.ensure(size_t(12) * n * nf));
+            d_new = h->d_pos_stage.as<float>();
+        }
+        MDX_TRY(source(d_new, done, nf));
+        hipEvent_t ev = h->timer.begin();
+        hipLaunchKernelGGL(sq_rho_kernel, dim3(qblocks, h->n_groups, (unsigned)nf), dim3(SQ_THREADS),
+                           0, h->stream, d_new, n, h->d_q.as<double>(), (int)h->n_q,
+                           h->d_offsets.as<int64_t>(), h->n_groups, 1,
+                           h->d_rho_ring.as<double2>() + int64_t(slot0) * h->n_groups * h->n_q);
+        hipLaunchKernelGGL(isf_coherent_kernel,
+                           dim3((unsigned)ceil_div(h->n_q, 256), h->n_pairs, h->n_lags), dim3(256), 0,
+                           h->stream, h->d_rho_ring.as<double2>(), h->ring_slots, h->n_groups,
+                           (int)h->n_q, h->d_pairs.as<int>(), h->n_pairs, h->n_lags, f0, (int)nf,
+                           h->d_cisf.as<double>());
+        if (h->incoherent) {
+            int64_t max_range = 0;
+            for (int s = 0; s < h->n_slots; ++s)
+                max_range = std::max(max_range, h->ranges[2 * s + 1] - h->ranges[2 * s]);
+            int n_split = 1;
+            while (int64_t(qblocks) * h->n_slots * n_split * h->n_lags < 1024 && n_split < 64 &&
+                   max_range / (n_split * 2) >= SQ_TILE)
+                n_split *= 2;
+            const int64_t n_out = int64_t(h->n_lags) * h->n_slots * h->n_q;
+            MDX_TRY(h->d_part.ensure(size_t(8) * n_out * n_split));
+            hipLaunchKernelGGL(isf_incoherent_kernel,
+                               dim3(qblocks, h->n_slots * n_split, h->n_lags), dim3(SQ_THREADS), 0,
+                               h->stream, h->d_pos_ring.as<float>(), h->ring_slots, n,
+                               h->d_q.as<double>(), (int)h->n_q, h->d_ranges.as<int64_t>(),
+                               h->n_slots, n_split, h->n_lags, f0, (int)nf, h->d_part.as<double>());
+            hipLaunchKernelGGL(isf_reduce_kernel, dim3((unsigned)ceil_div(n_out, 256)), dim3(256), 0,
+                               h->stream, h->d_part.as<double>(), n_split, n_out,
+                               h->d_iisf.as<double>());
+        }
+        h->timer.end(ev);
+        MDX_HIP(hipGetLastError());
+        // the host buffer may be reused by the caller; the staging copy must have left it
+        MDX_HIP(hipStreamSynchronize(h->stream));
+        h->frames_seen += nf;
+        done += nf;
+    }
+    return MDX_OK;
+}
+
 extern "C" {
+
+int mdx_isf_accumulate(mdx_isf_t h, const float *pos, int64_t n, int64_t n_frames)
+{
+    MDX_REQUIRE(h && pos, "NULL argument");
+    return isf_accumulate(h, n, n_frames, [&](float *d_dst, int64_t done, int64_t nf) -> int {
+        MDX_HIP(hipMemcpyAsync(d_dst, pos + done * n * 3, size_t(12) * n * nf,
+                               hipMemcpyHostToDevice, h->stream));
+        return MDX_OK;
+    });
+}
+
+// Frames straight from a trajectory file, in the order listed; index as for
+// mdx_sq_accumulate_traj.
+int mdx_isf_accumulate_traj(mdx_isf_t h, mdx_traj_t traj, const int64_t *frames, int64_t n_frames,
+                            const int32_t *index, int64_t n_index)
+{
+    MDX_REQUIRE(h && traj, "NULL handle");
+    MDX_REQUIRE(n_frames >= 0 && (n_frames == 0 || frames), "bad frame list");
+    MDX_TRY(set_device(h->dev));
+    Trajectory *t = mdx_traj_internal(traj);
+    const int64_t n = index ? n_index : (n_index > 0 ? n_index : t->n_atoms);
+    MDX_REQUIRE(index || n <= t->n_atoms, "selection larger than the trajectory");
+    const int *d_index = nullptr;
+    if (index) {
+        for (int64_t i = 0; i < n; ++i)
+            if (index[i] < 0 || index[i] >= t->n_atoms)
+                return fail(MDX_ERR_INVALID_VALUE, "particle index %d out of range [0, %lld)",
+                            index[i], (long long)t->n_atoms);
+        MDX_HIP(hipStreamSynchronize(h->stream));
+        MDX_TRY(h->d_index.ensure(size_t(4) * n));
+        MDX_HIP(hipMemcpy(h->d_index.ptr, index, size_t(4) * n, hipMemcpyHostToDevice));
+        d_index = h->d_index.as<int>();
+    }
+    return isf_accumulate(h, n, n_frames, [&](float *d_dst, int64_t done, int64_t nf) -> int {
+        TrajSelection sel{d_index, n, d_dst};
+        return t->stage_async(h->dev, h->stream, frames + done, nf, &sel, 1);
+    });
+}
 
 int mdx_isf_create(mdx_isf_t *out, int dev, const double *wavevectors, int64_t n_q,
                    const int64_t *group_offsets, int n_groups, const int32_t *pairs, int n_pairs,
@@ -254,7 +358,8 @@ int mdx_isf_destroy(mdx_isf_t h)
         (void)hipStreamSynchronize(h->stream);
     h->timer.destroy();
     for (DeviceBuffer *b : {&h->d_q, &h->d_offsets, &h->d_pairs, &h->d_ranges, &h->d_rho_ring,
-                            &h->d_pos_ring, &h->d_cisf, &h->d_iisf, &h->d_part, &h->d_pos_stage})
+                            &h->d_pos_ring, &h->d_cisf, &h->d_iisf, &h->d_part, &h->d_pos_stage,
+                            &h->d_index})
         b->release();
     if (h->stream)
         (void)hipStreamDestroy(h->stream);
@@ -273,73 +378,6 @@ int mdx_isf_reset(mdx_isf_t h)
     MDX_HIP(hipStreamSynchronize(h->stream));
     h->frames_seen = 0;
     h->timer.reset();
-    return MDX_OK;
-}
-
-// Frames must arrive in analysis order; consecutive calls continue the same series.
-int mdx_isf_accumulate(mdx_isf_t h, const float *pos, int64_t n, int64_t n_frames)
-{
-    MDX_REQUIRE(h && pos, "NULL argument");
-    MDX_REQUIRE(n >= h->n_total && n_frames >= 0, "bad size");
-    MDX_TRY(set_device(h->dev));
-    if (h->incoherent)
-        MDX_TRY(h->d_pos_ring.ensure(size_t(12) * n * h->ring_slots));
-    const int qblocks = (int)ceil_div(h->n_q, SQ_QPB);
-    int64_t done = 0;
-    while (done < n_frames) {
-        // a chunk: at most n_lags new frames, contiguous in the ring
-        const long long f0 = h->frames_seen;
-        const int slot0 = int(f0 % h->ring_slots);
-        const int64_t nf = std::min<int64_t>(std::min<int64_t>(h->n_lags, h->ring_slots - slot0),
-                                             n_frames - done);
-        const float *src = pos + done * n * 3;
-        const float *d_new = nullptr;
-        if (h->incoherent) {
-            float *dst = h->d_pos_ring.as<float>() + int64_t(slot0) * n * 3;
-            MDX_HIP(hipMemcpyAsync(dst, src, size_t(12) * n * nf, hipMemcpyHostToDevice, h->stream));
-            d_new = dst;
-        } else {
-            MDX_TRY(h->d_pos_stage.ensure(size_t(12) * n * nf));
-            MDX_HIP(hipMemcpyAsync(h->d_pos_stage.ptr, src, size_t(12) * n * nf, hipMemcpyHostToDevice,
-                                   h->stream));
-            d_new = h->d_pos_stage.as<float>();
-        }
-        hipEvent_t ev = h->timer.begin();
-        hipLaunchKernelGGL(sq_rho_kernel, dim3(qblocks, h->n_groups, (unsigned)nf), dim3(SQ_THREADS),
-                           0, h->stream, d_new, n, h->d_q.as<double>(), (int)h->n_q,
-                           h->d_offsets.as<int64_t>(), h->n_groups, 1,
-                           h->d_rho_ring.as<double2>() + int64_t(slot0) * h->n_groups * h->n_q);
-        hipLaunchKernelGGL(isf_coherent_kernel,
-                           dim3((unsigned)ceil_div(h->n_q, 256), h->n_pairs, h->n_lags), dim3(256), 0,
-                           h->stream, h->d_rho_ring.as<double2>(), h->ring_slots, h->n_groups,
-                           (int)h->n_q, h->d_pairs.as<int>(), h->n_pairs, h->n_lags, f0, (int)nf,
-                           h->d_cisf.as<double>());
-        if (h->incoherent) {
-            int64_t max_range = 0;
-            for (int s = 0; s < h->n_slots; ++s)
-                max_range = std::max(max_range, h->ranges[2 * s + 1] - h->ranges[2 * s]);
-            int n_split = 1;
-            while (int64_t(qblocks) * h->n_slots * n_split * h->n_lags < 1024 && n_split < 64 &&
-                   max_range / (n_split * 2) >= SQ_TILE)
-                n_split *= 2;
-            const int64_t n_out = int64_t(h->n_lags) * h->n_slots * h->n_q;
-            MDX_TRY(h->d_part.ensure(size_t(8) * n_out * n_split));
-            hipLaunchKernelGGL(isf_incoherent_kernel,
-                               dim3(qblocks, h->n_slots * n_split, h->n_lags), dim3(SQ_THREADS), 0,
-                               h->stream, h->d_pos_ring.as<float>(), h->ring_slots, n,
-                               h->d_q.as<double>(), (int)h->n_q, h->d_ranges.as<int64_t>(),
-                               h->n_slots, n_split, h->n_lags, f0, (int)nf, h->d_part.as<double>());
-            hipLaunchKernelGGL(isf_reduce_kernel, dim3((unsigned)ceil_div(n_out, 256)), dim3(256), 0,
-                               h->stream, h->d_part.as<double>(), n_split, n_out,
-                               h->d_iisf.as<double>());
-        }
-        h->timer.end(ev);
-        MDX_HIP(hipGetLastError());
-        // the host buffer may be reused by the caller; the staging copy must have left it
-        MDX_HIP(hipStreamSynchronize(h->stream));
-        h->frames_seen += nf;
-        done += nf;
-    }
     return MDX_OK;
 }
 

@@ -31,6 +31,7 @@
 #include "mdx_internal.hpp"
 #include "mdx_rdf_device.hpp"
 #include "mdx_rdf_cell.hpp"
+#include "mdx_traj.hpp"
 
 #include <cmath>
 
@@ -228,11 +229,8 @@ struct mdx_rdf {
     int n_rep = 32;
     DeviceBuffer d_thresh, d_counts, d_total, d_pack1, d_pack2, d_misc;
     // host-buffer entry point: double-buffered staging, copy stream, hand-over events
-    DeviceBuffer d_stage1[2], d_stage2[2], d_boxes[2];
-    hipStream_t copy_stream = nullptr;
-    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
-    bool stage_busy[2] = {false, false};
-    int ensure_copy_pipeline();
+    DeviceBuffer d_stage1[2], d_stage2[2], d_boxes[2], d_index[2];
+    StagePipeline pipe;
     DeviceBuffer d_pw1, d_po1, d_bb1, d_pw2, d_po2, d_bb2;   // cell path: sorted copies + tile boxes
     DeviceBuffer d_bb16_1, d_bb16_2;                         // boxes of the 16-particle chunks
     StreamTimer timer;
@@ -240,18 +238,6 @@ struct mdx_rdf {
     int64_t pairs_bruteforce = 0;   // distance evaluations executed by the brute-force tiles
     bool reduced_global = false;   // counts replica 0 holds an all-reduced total
 };
-
-int mdx_rdf::ensure_copy_pipeline()
-{
-    if (copy_stream)
-        return MDX_OK;
-    MDX_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
-    for (int b = 0; b < 2; ++b) {
-        MDX_HIP(hipEventCreateWithFlags(&ev_copied[b], hipEventDisableTiming));
-        MDX_HIP(hipEventCreateWithFlags(&ev_consumed[b], hipEventDisableTiming));
-    }
-    return MDX_OK;
-}
 
 static int launch_tiles(mdx_rdf *h, RdfArgs &a, int mode, int ipt, bool pbc, bool excl,
                         int64_t n_frames)
@@ -330,9 +316,9 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
     size_t base = sizeof(float4) * 256 + sizeof(double) * (h->n_bins + 1);
     const size_t lds_budget = 64 * 1024;
     int n_hist = 4;
-    while (n_hist > 1 && base + size_t(n_hist) * h->n_bins * 4 > lds_budget)
+    while (n_hist > 1 && base + size_t(n_hist) * (h->n_bins + 1) * 4 > lds_budget)
         n_hist >>= 1;
-    size_t lds = base + size_t(n_hist) * h->n_bins * 4;
+    size_t lds = base + size_t(n_hist) * (h->n_bins + 1) * 4;
     const bool gh = lds > lds_budget;
     if (gh)
         lds = sizeof(float4) * 256;
@@ -473,6 +459,50 @@ static int accumulate_device(mdx_rdf *h, const float *d_pos1, int64_t n1, const 
     return MDX_OK;
 }
 
+static int check_host_boxes(const float *boxes, int64_t n_frames)
+{
+    for (int64_t f = 0; boxes && f < n_frames; ++f) {
+        const float *b = boxes + 6 * f;
+        if (!(b[3] == 90.f && b[4] == 90.f && b[5] == 90.f))
+            return fail(MDX_ERR_UNSUPPORTED,
+                        "frame %lld: only orthorhombic boxes are supported "
+                        "(angles %.4g %.4g %.4g)", (long long)f, b[3], b[4], b[5]);
+        MDX_REQUIRE(b[0] > 0.f && b[1] > 0.f && b[2] > 0.f,
+                    "frame %lld: box lengths must be positive", (long long)f);
+    }
+    return MDX_OK;
+}
+
+// Host-buffer and trajectory-file entry points: slabs of frames go through the double-buffered
+// staging sets (StagePipeline).  fill(b, f0, nf) queues on the copy stream whatever brings
+// frames [f0, f0+nf) into d_stage1[b] (and d_stage2[b] unless `same`).
+template <typename Fill>
+static int accumulate_pipelined(mdx_rdf *h, int64_t n1, int64_t n2, bool same, const float *boxes,
+                                int64_t n_frames, int64_t source_bytes_per_frame, Fill fill)
+{
+    const int64_t slab = std::min<int64_t>(
+        n_frames, std::max<int64_t>(1, (int64_t(64) << 20) / source_bytes_per_frame));
+    return h->pipe.run(
+        h->stream, n_frames, slab,
+        [&](int b, int64_t f0, int64_t nf) -> int {
+            MDX_TRY(h->d_stage1[b].ensure(size_t(12) * n1 * slab));
+            if (!same)
+                MDX_TRY(h->d_stage2[b].ensure(size_t(12) * n2 * slab));
+            MDX_TRY(fill(b, f0, nf));
+            if (boxes) {
+                MDX_TRY(h->d_boxes[b].ensure(size_t(24) * slab));
+                MDX_HIP(hipMemcpyAsync(h->d_boxes[b].ptr, boxes + f0 * 6, size_t(24) * nf,
+                                       hipMemcpyHostToDevice, h->pipe.copy_stream));
+            }
+            return MDX_OK;
+        },
+        [&](int b, int64_t, int64_t nf) -> int {
+            return accumulate_device(h, h->d_stage1[b].as<float>(), n1,
+                                     same ? nullptr : h->d_stage2[b].as<float>(), n2,
+                                     boxes ? h->d_boxes[b].as<float>() : nullptr, nf);
+        });
+}
+
 extern "C" {
 
 int mdx_rdf_create(mdx_rdf_t *out, int dev, int n_bins, const double *edges, int64_t excl1,
@@ -535,17 +565,10 @@ int mdx_rdf_destroy(mdx_rdf_t h)
     if (h->stream)
         (void)hipStreamSynchronize(h->stream);
     h->timer.destroy();
-    if (h->copy_stream) {
-        (void)hipStreamSynchronize(h->copy_stream);
-        (void)hipStreamDestroy(h->copy_stream);
-        for (int b = 0; b < 2; ++b) {
-            (void)hipEventDestroy(h->ev_copied[b]);
-            (void)hipEventDestroy(h->ev_consumed[b]);
-        }
-    }
+    h->pipe.destroy();
     for (DeviceBuffer *b : {&h->d_thresh, &h->d_counts, &h->d_total, &h->d_pack1, &h->d_pack2,
                             &h->d_stage1[0], &h->d_stage2[0], &h->d_boxes[0], &h->d_stage1[1],
-                            &h->d_stage2[1], &h->d_boxes[1], &h->d_misc, &h->d_pw1,
+                            &h->d_stage2[1], &h->d_boxes[1], &h->d_index[0], &h->d_index[1], &h->d_misc, &h->d_pw1,
                             &h->d_po1, &h->d_bb1, &h->d_pw2, &h->d_po2, &h->d_bb2, &h->d_bb16_1,
                             &h->d_bb16_2})
         b->release();
@@ -593,56 +616,67 @@ int mdx_rdf_accumulate(mdx_rdf_t h, const float *pos1, int64_t n1, const float *
         n2 = n1;
     if (n2 == 0)
         return MDX_OK;
-    if (boxes) {
-        for (int64_t f = 0; f < n_frames; ++f) {
-            const float *b = boxes + 6 * f;
-            if (!(b[3] == 90.f && b[4] == 90.f && b[5] == 90.f))
-                return fail(MDX_ERR_UNSUPPORTED,
-                            "frame %lld: only orthorhombic boxes are supported "
-                            "(angles %.4g %.4g %.4g)", (long long)f, b[3], b[4], b[5]);
-            MDX_REQUIRE(b[0] > 0.f && b[1] > 0.f && b[2] > 0.f,
-                        "frame %lld: box lengths must be positive", (long long)f);
-        }
+    MDX_TRY(check_host_boxes(boxes, n_frames));
+    return accumulate_pipelined(
+        h, n1, n2, same, boxes, n_frames, 12 * std::max(n1, n2),
+        [&](int b, int64_t f0, int64_t nf) -> int {
+            MDX_HIP(hipMemcpyAsync(h->d_stage1[b].ptr, pos1 + f0 * n1 * 3, size_t(12) * n1 * nf,
+                                   hipMemcpyHostToDevice, h->pipe.copy_stream));
+            if (!same)
+                MDX_HIP(hipMemcpyAsync(h->d_stage2[b].ptr, pos2 + f0 * n2 * 3,
+                                       size_t(12) * n2 * nf, hipMemcpyHostToDevice,
+                                       h->pipe.copy_stream));
+            return MDX_OK;
+        });
+}
+
+// Frames straight from a trajectory file (mdx_traj.hip): raw records -> pinned -> HBM ->
+// unpack/gather into the staging slabs, overlapped with the pair kernels of the previous slab.
+int mdx_rdf_accumulate_traj(mdx_rdf_t h, mdx_traj_t traj, const int64_t *frames, int64_t n_frames,
+                            const float *boxes, const int32_t *index1, int64_t n1,
+                            const int32_t *index2, int64_t n2)
+{
+    MDX_REQUIRE(h && traj, "NULL handle");
+    MDX_REQUIRE(n1 >= 0 && n2 >= 0 && n_frames >= 0, "negative size");
+    MDX_REQUIRE(n_frames == 0 || frames, "NULL frame list");
+    MDX_TRY(set_device(h->dev));
+    Trajectory *t = mdx_traj_internal(traj);
+    const bool same = (index2 == nullptr && n2 == 0);
+    if (index1 == nullptr)
+        n1 = t->n_atoms;
+    if (same)
+        n2 = n1;
+    else if (index2 == nullptr)
+        n2 = t->n_atoms;
+    if (n_frames == 0 || n1 == 0 || n2 == 0)
+        return MDX_OK;
+    MDX_TRY(check_host_boxes(boxes, n_frames));
+    // particle selections live on the device for the unpack kernel
+    const int32_t *host_idx[2] = {index1, same ? nullptr : index2};
+    const int64_t n_idx[2] = {n1, n2};
+    const int *d_idx[2] = {nullptr, nullptr};
+    for (int g = 0; g < 2; ++g) {
+        if (!host_idx[g])
+            continue;
+        for (int64_t i = 0; i < n_idx[g]; ++i)
+            if (host_idx[g][i] < 0 || host_idx[g][i] >= t->n_atoms)
+                return fail(MDX_ERR_INVALID_VALUE, "particle index %d out of range [0, %lld)",
+                            host_idx[g][i], (long long)t->n_atoms);
+        MDX_TRY(h->pipe.ensure());
+        // an earlier call's unpack kernels may still be reading the previous selection
+        MDX_HIP(hipStreamSynchronize(h->pipe.copy_stream));
+        MDX_TRY(h->d_index[g].ensure(size_t(4) * n_idx[g]));
+        MDX_HIP(hipMemcpy(h->d_index[g].ptr, host_idx[g], size_t(4) * n_idx[g],
+                          hipMemcpyHostToDevice));
+        d_idx[g] = h->d_index[g].as<int>();
     }
-    // Stage through HBM in slabs, double-buffered: the copy of slab k+1 (copy stream) overlaps
-    // the kernels of slab k (compute stream).  A buffer is refilled only after the kernels that
-    // read it have finished (event), and the call returns once the last copy has completed, so
-    // no host pointer is retained; the kernels of the last slabs may still be in flight.
-    const int64_t per_frame = 12 * std::max(n1, n2);
-    const int64_t slab = std::max<int64_t>(1, (int64_t(64) << 20) / per_frame);
-    MDX_TRY(h->ensure_copy_pipeline());
-    for (int64_t f0 = 0, k = 0; f0 < n_frames; f0 += slab, ++k) {
-        const int64_t nf = std::min(slab, n_frames - f0);
-        const int b = int(k & 1);
-        if (h->stage_busy[b]) {
-            MDX_HIP(hipEventSynchronize(h->ev_consumed[b]));
-            h->stage_busy[b] = false;
-        }
-        MDX_TRY(h->d_stage1[b].ensure(size_t(12) * n1 * nf));
-        MDX_HIP(hipMemcpyAsync(h->d_stage1[b].ptr, pos1 + f0 * n1 * 3, size_t(12) * n1 * nf,
-                               hipMemcpyHostToDevice, h->copy_stream));
-        const float *d2 = nullptr;
-        if (!same) {
-            MDX_TRY(h->d_stage2[b].ensure(size_t(12) * n2 * nf));
-            MDX_HIP(hipMemcpyAsync(h->d_stage2[b].ptr, pos2 + f0 * n2 * 3, size_t(12) * n2 * nf,
-                                   hipMemcpyHostToDevice, h->copy_stream));
-            d2 = h->d_stage2[b].as<float>();
-        }
-        const float *db = nullptr;
-        if (boxes) {
-            MDX_TRY(h->d_boxes[b].ensure(size_t(24) * nf));
-            MDX_HIP(hipMemcpyAsync(h->d_boxes[b].ptr, boxes + f0 * 6, size_t(24) * nf,
-                                   hipMemcpyHostToDevice, h->copy_stream));
-            db = h->d_boxes[b].as<float>();
-        }
-        MDX_HIP(hipEventRecord(h->ev_copied[b], h->copy_stream));
-        MDX_HIP(hipStreamWaitEvent(h->stream, h->ev_copied[b], 0));
-        MDX_TRY(accumulate_device(h, h->d_stage1[b].as<float>(), n1, d2, n2, db, nf));
-        MDX_HIP(hipEventRecord(h->ev_consumed[b], h->stream));
-        h->stage_busy[b] = true;
-    }
-    MDX_HIP(hipStreamSynchronize(h->copy_stream));
-    return MDX_OK;
+    return accumulate_pipelined(
+        h, n1, n2, same, boxes, n_frames, 12 * t->n_atoms,
+        [&](int b, int64_t f0, int64_t nf) -> int {
+            TrajSelection sel[2] = {{d_idx[0], n1, h->d_stage1[b].as<float>()},
+                                    {d_idx[1], n2, same ? nullptr : h->d_stage2[b].as<float>()}};
+            return t->stage_async(h->dev, h->pipe.copy_stream, frames + f0, nf, sel, same ? 1 : 2);
+        });
 }
 
 int mdx_rdf_synchronize(mdx_rdf_t h)
@@ -714,6 +748,19 @@ int mdx_rdf_debug_counters(mdx_rdf_t h, int64_t out[4])
     out[1] = (int64_t)raw[1];   // (64 i) x (16 j) units evaluated by the cell kernel
     out[2] = (int64_t)raw[2];   // ... of which on the per-pair image-search path
     out[3] = h->pairs_bruteforce;
+    return MDX_OK;
+}
+
+int mdx_rdf_debug_sorted(mdx_rdf_t h, int64_t frame, int64_t n_pad, float *pw, float *po)
+{
+    MDX_REQUIRE(h && pw && po, "NULL argument");
+    MDX_TRY(set_device(h->dev));
+    MDX_HIP(hipStreamSynchronize(h->stream));
+    MDX_REQUIRE(h->d_pw1.bytes >= size_t(16) * n_pad * (frame + 1), "frame outside the last slab");
+    MDX_HIP(hipMemcpy(pw, h->d_pw1.as<float4>() + frame * n_pad, size_t(16) * n_pad,
+                      hipMemcpyDeviceToHost));
+    MDX_HIP(hipMemcpy(po, h->d_po1.as<float4>() + frame * n_pad, size_t(16) * n_pad,
+                      hipMemcpyDeviceToHost));
     return MDX_OK;
 }
 

@@ -234,6 +234,7 @@ __device__ inline void cell_pair_exact(const PairCtx<true> &c, const CellArgs &a
 // wave-uniform float constants of the hot loop, forced into SGPRs
 struct CellHot {
     float cand_hi, cand_lo, inv_w, pos0, sure_half;
+    float L[3], invL[3];   // box lengths and fl32(1/L): only the cold block widens them to fp64
 };
 
 __device__ inline float cell_uniform(float v)
@@ -250,7 +251,7 @@ template <bool LOWER, int TAGS, int MODE, typename Hist>
 __device__ inline void cell_step(const CellHot &c, const CellArgs &a, const double *sT,
                                  const Hist &hist, float fx, float fy, float fz, int tag_i,
                                  int tag_j, const float4 *po1f, const float4 *po2f, unsigned i_idx,
-                                 unsigned j_idx, unsigned frame, unsigned w, unsigned &n_exact)
+                                 unsigned j_idx, unsigned w, unsigned &n_exact)
 {
     float r2 = __fmaf_rn(fz, fz, __fmaf_rn(fy, fy, fx * fx));
     // pos = (sqrt(r2) - r0) / width; raw v_sqrt_f32 (a denormal r2 ends on the exact path)
@@ -275,11 +276,10 @@ __device__ inline void cell_step(const CellHot &c, const CellArgs &a, const doub
                 // the fp64 constants are rebuilt here, in the cold block, instead of living in
                 // registers across the hot loop
                 PairCtx<true> cx;
-                const float *box = a.boxes + int64_t(frame) * 6;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    cx.Ld[k] = (double)box[k];
-                    cx.invd[k] = (double)(float)(1.0 / (double)box[k]);
+                    cx.Ld[k] = (double)c.L[k];
+                    cx.invd[k] = (double)c.invL[k];
                 }
                 cx.r0f = (float)a.r0;
                 cx.inv_wf = c.inv_w;
@@ -287,6 +287,8 @@ __device__ inline void cell_step(const CellHot &c, const CellArgs &a, const doub
             }
         }
     }
+    if (MODE == 1)   // global histogram: no spare slot behind the last bin
+        cand = cand && pos < (float)a.n_bins;
     if (cand && sure)
         hist.add((int)pos, w);
 }
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float4 *sJ = reinterpret_cast<float4 *>(smem_raw);                        // [4 waves][64]
     double *sT = reinterpret_cast<double *>(smem_raw + sizeof(float4) * 256); // [n_bins+1]
-    unsigned *sh = reinterpret_cast<unsigned *>(sT + (a.n_bins + 1));         // [n_hist][n_bins]
+    unsigned *sh = reinterpret_cast<unsigned *>(sT + (a.n_bins + 1));         // [n_hist][n_bins + 1]
     __shared__ unsigned s_exact, s_units, s_general, s_qn, s_qnext;
     __shared__ unsigned sQ[CELL_QCAP];
     __shared__ float s_geo[32];
@@ -309,17 +311,20 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
     // copies are streamed through a single XCD's L2 instead of all eight.
     const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x;
     const unsigned per_xcd = lin >> 3;
-    const int frame_l = int(per_xcd / gridDim.x) * 8 + int(lin & 7u);
+    // (the integer division runs on the VALU: pin its block-uniform results back into SGPRs,
+    // or every pointer derived from them costs two VGPRs)
+    const unsigned q_xcd = __builtin_amdgcn_readfirstlane(per_xcd / gridDim.x);
+    const int frame_l = int(q_xcd) * 8 + int(lin & 7u);
     if (frame_l >= a.n_frames)
         return;
     const int frame = frame_l + a.frame0;
-    const int I = int(per_xcd % gridDim.x);         // 128-particle i tile = two 64-particle halves
+    const int I = int(per_xcd - q_xcd * gridDim.x); // 128-particle i tile = two 64-particle halves
     const int t64_2 = a.n2p / 64;
 
     if (!GH) {
         for (int b = tid; b <= a.n_bins; b += 256)
             sT[b] = a.thresh[b];
-        for (int b = tid; b < a.n_hist * a.n_bins; b += 256)
+        for (int b = tid; b < a.n_hist * (a.n_bins + 1); b += 256)
             sh[b] = 0u;
     }
     if (tid == 0) {
@@ -372,14 +377,20 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
     hot.inv_w = cell_uniform(s_geo[28]);
     hot.pos0 = cell_uniform(s_geo[29]);
     hot.sure_half = cell_uniform(s_geo[30]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        hot.L[k] = cell_uniform(s_geo[k]);
+        hot.invL[k] = cell_uniform(s_geo[3 + k]);
+    }
     const double *thr = GH ? a.thresh : sT;
-    HistLds hl{sh + (GH ? 0 : (wave % a.n_hist) * a.n_bins)};
+    // per-wave histograms of n_bins + 1 slots: the extra slot absorbs a (proven impossible,
+    // DESIGN.md §4.2) index n_bins instead of letting it alias the next histogram's bin 0
+    HistLds hl{sh + (GH ? 0 : (wave % a.n_hist) * (a.n_bins + 1))};
     HistGlobal hg{out};
 
     const float4 *PW1 = a.pw1 + int64_t(frame) * a.n1p + int64_t(I) * 128;
     const float4 *PO1f = a.po1 + int64_t(frame) * a.n1p;     // this frame's original coordinates
     const unsigned i_idx0 = unsigned(I) * 128u + unsigned(lane);
-    const unsigned fslab = unsigned(frame);
     const float4 *PW2 = a.pw2 + int64_t(frame) * a.n2p;
     const float4 *PO2 = a.po2 + int64_t(frame) * a.n2p;
     const float4 *BB2 = a.bb2 + int64_t(frame) * t64_2 * 2;
@@ -500,11 +511,11 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
                     n_units += (bits & 1u) + (bits >> 1);
 #define MDX_CELL_ONE(TG, U0, U1, Q, JJ)                                                            \
     if (GH) {                                                                                      \
-        if (U0) cell_step<LOWER, TG, MODE>(hot, a, thr, hg, Q.x - p0.x, Q.y - p0.y, Q.z - p0.z, __float_as_int(p0.w), __float_as_int(Q.w), PO1f, PO2, i_idx0, jbase + (JJ), fslab, w, n_exact); \
-        if (U1) cell_step<LOWER, TG, MODE>(hot, a, thr, hg, Q.x - p1.x, Q.y - p1.y, Q.z - p1.z, __float_as_int(p1.w), __float_as_int(Q.w), PO1f, PO2, i_idx0 + 64u, jbase + (JJ), fslab, w, n_exact); \
+        if (U0) cell_step<LOWER, TG, MODE>(hot, a, thr, hg, Q.x - p0.x, Q.y - p0.y, Q.z - p0.z, __float_as_int(p0.w), __float_as_int(Q.w), PO1f, PO2, i_idx0, jbase + (JJ), w, n_exact); \
+        if (U1) cell_step<LOWER, TG, MODE>(hot, a, thr, hg, Q.x - p1.x, Q.y - p1.y, Q.z - p1.z, __float_as_int(p1.w), __float_as_int(Q.w), PO1f, PO2, i_idx0 + 64u, jbase + (JJ), w, n_exact); \
     } else {                                                                                       \
-        if (U0) cell_step<LOWER, TG, MODE>(hot, a, thr, hl, Q.x - p0.x, Q.y - p0.y, Q.z - p0.z, __float_as_int(p0.w), __float_as_int(Q.w), PO1f, PO2, i_idx0, jbase + (JJ), fslab, w, n_exact); \
-        if (U1) cell_step<LOWER, TG, MODE>(hot, a, thr, hl, Q.x - p1.x, Q.y - p1.y, Q.z - p1.z, __float_as_int(p1.w), __float_as_int(Q.w), PO1f, PO2, i_idx0 + 64u, jbase + (JJ), fslab, w, n_exact); \
+        if (U0) cell_step<LOWER, TG, MODE>(hot, a, thr, hl, Q.x - p0.x, Q.y - p0.y, Q.z - p0.z, __float_as_int(p0.w), __float_as_int(Q.w), PO1f, PO2, i_idx0, jbase + (JJ), w, n_exact); \
+        if (U1) cell_step<LOWER, TG, MODE>(hot, a, thr, hl, Q.x - p1.x, Q.y - p1.y, Q.z - p1.z, __float_as_int(p1.w), __float_as_int(Q.w), PO1f, PO2, i_idx0 + 64u, jbase + (JJ), w, n_exact); \
     }
 // four slab entries are fetched ahead of their use so the LDS latency overlaps the arithmetic
 #define MDX_CELL_RUN(TG, U0, U1)                                                                   \
@@ -541,8 +552,8 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
                         fx = __fmaf_rn(-rintf(fx * s_geo[3]), s_geo[0], fx);
                         fy = __fmaf_rn(-rintf(fy * s_geo[4]), s_geo[1], fy);
                         fz = __fmaf_rn(-rintf(fz * s_geo[5]), s_geo[2], fz);
-                        if (GH) cell_step<LOWER, EXCL ? 1 : 0, MODE>(hot, a, thr, hg, fx, fy, fz, __float_as_int(p.w), __float_as_int(q.w), PO1f, PO2, i_idx0 + 64u * u, jbase + jj, fslab, w, n_exact);
-                        else cell_step<LOWER, EXCL ? 1 : 0, MODE>(hot, a, thr, hl, fx, fy, fz, __float_as_int(p.w), __float_as_int(q.w), PO1f, PO2, i_idx0 + 64u * u, jbase + jj, fslab, w, n_exact);
+                        if (GH) cell_step<LOWER, EXCL ? 1 : 0, MODE>(hot, a, thr, hg, fx, fy, fz, __float_as_int(p.w), __float_as_int(q.w), PO1f, PO2, i_idx0 + 64u * u, jbase + jj, w, n_exact);
+                        else cell_step<LOWER, EXCL ? 1 : 0, MODE>(hot, a, thr, hl, fx, fy, fz, __float_as_int(p.w), __float_as_int(q.w), PO1f, PO2, i_idx0 + 64u * u, jbase + jj, w, n_exact);
                     }
                 }
             }
@@ -566,7 +577,7 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
         for (int b = tid; b < a.n_bins; b += 256) {
             unsigned long long s = 0;
             for (int h = 0; h < a.n_hist; ++h)
-                s += sh[h * a.n_bins + b];
+                s += sh[h * (a.n_bins + 1) + b];
             if (s)
                 atomicAdd(out + b, s);
         }

@@ -70,7 +70,14 @@ template <bool PBC> struct PairCtx {
         const double margin_d = 1.7320508075688772 * delta + r1 * 0x1p-21;
         r0f = (float)r0;
         inv_wf = (float)(1.0 / width);
-        double e = margin_d / width + n_bins * 0x1p-21 + 0x1p-20;
+        // Bin-coordinate budget.  Q = r1 / width is the largest magnitude the
+        // float32 bin arithmetic handles (n_bins only when r0 = 0).  Per unit of Q:
+        //   <= 0.625 * 2^-21  evaluating pos in float32 (sqrt 1 ulp, fma, 1/width, -r0/width),
+        //   <= 1.07  * 2^-21  how far the candidate window reaches past r1 + margin (and below
+        //                     r0 - margin) because of its own (1 +- 2^-20) safety factor,
+        // so Q * 2^-20 covers both at once: a candidate beyond either range end is never "sure".
+        const double Q = r1 / width;
+        double e = margin_d / width + Q * 0x1p-20 + 0x1p-20;
         eta = (float)fmin(e, 1.0);
         posmax = (float)n_bins - eta;
         double hi = (r1 + margin_d);

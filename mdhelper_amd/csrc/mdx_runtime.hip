@@ -112,6 +112,33 @@ void StreamTimer::destroy()
     pool.clear();
 }
 
+int StagePipeline::ensure()
+{
+    if (copy_stream)
+        return MDX_OK;
+    MDX_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b) {
+        MDX_HIP(hipEventCreateWithFlags(&ev_filled[b], hipEventDisableTiming));
+        MDX_HIP(hipEventCreateWithFlags(&ev_consumed[b], hipEventDisableTiming));
+    }
+    return MDX_OK;
+}
+
+void StagePipeline::destroy()
+{
+    if (!copy_stream)
+        return;
+    (void)hipStreamSynchronize(copy_stream);
+    (void)hipStreamDestroy(copy_stream);
+    copy_stream = nullptr;
+    for (int b = 0; b < 2; ++b) {
+        if (ev_filled[b]) (void)hipEventDestroy(ev_filled[b]);
+        if (ev_consumed[b]) (void)hipEventDestroy(ev_consumed[b]);
+        ev_filled[b] = ev_consumed[b] = nullptr;
+        busy[b] = false;
+    }
+}
+
 }  // namespace mdx
 
 using namespace mdx;

@@ -27,6 +27,7 @@
 using namespace mdx;
 
 #include "mdx_sq_device.hpp"
+#include "mdx_traj.hpp"
 
 using namespace mdx_sq_dev;
 
@@ -118,7 +119,8 @@ struct mdx_sq {
     int n_groups = 0, n_pairs = 0;
     int64_t n_total = 0;
     std::vector<int64_t> offsets;
-    DeviceBuffer d_q, d_offsets, d_pairs, d_acc, d_rho, d_stage, d_mtrip;
+    DeviceBuffer d_q, d_offsets, d_pairs, d_acc, d_rho, d_stage[2], d_index, d_mtrip;
+    StagePipeline pipe;   // host-buffer / trajectory-file entry points
     StreamTimer timer;
     bool lattice = false;        // wavevectors are integer multiples of one base per axis
     SqLattice lat{};
@@ -284,8 +286,9 @@ int mdx_sq_destroy(mdx_sq_t h)
     if (h->stream)
         (void)hipStreamSynchronize(h->stream);
     h->timer.destroy();
-    for (DeviceBuffer *b : {&h->d_q, &h->d_offsets, &h->d_pairs, &h->d_acc, &h->d_rho, &h->d_stage,
-                            &h->d_mtrip})
+    h->pipe.destroy();
+    for (DeviceBuffer *b : {&h->d_q, &h->d_offsets, &h->d_pairs, &h->d_acc, &h->d_rho, &h->d_stage[0],
+                            &h->d_stage[1], &h->d_index, &h->d_mtrip})
         b->release();
     if (h->stream)
         (void)hipStreamDestroy(h->stream);
@@ -316,16 +319,62 @@ int mdx_sq_accumulate(mdx_sq_t h, const float *pos, int64_t n, int64_t n_frames)
     MDX_REQUIRE(h && pos, "NULL argument");
     MDX_REQUIRE(n > 0 && n_frames >= 0, "bad size");
     MDX_TRY(set_device(h->dev));
-    const int64_t slab = std::max<int64_t>(1, (int64_t(256) << 20) / (12 * n));
-    for (int64_t f0 = 0; f0 < n_frames; f0 += slab) {
-        const int64_t nf = std::min(slab, n_frames - f0);
-        MDX_TRY(h->d_stage.ensure(size_t(12) * n * nf));
-        MDX_HIP(hipMemcpyAsync(h->d_stage.ptr, pos + f0 * n * 3, size_t(12) * n * nf,
-                               hipMemcpyHostToDevice, h->stream));
-        MDX_TRY(sq_accumulate_device(h, h->d_stage.as<float>(), n, nf));
-        MDX_HIP(hipStreamSynchronize(h->stream));
+    // copies of slab k+1 overlap the kernels of slab k (StagePipeline)
+    const int64_t slab = std::min<int64_t>(std::max<int64_t>(n_frames, 1),
+                                           std::max<int64_t>(1, (int64_t(64) << 20) / (12 * n)));
+    return h->pipe.run(
+        h->stream, n_frames, slab,
+        [&](int b, int64_t f0, int64_t nf) -> int {
+            MDX_TRY(h->d_stage[b].ensure(size_t(12) * n * slab));
+            MDX_HIP(hipMemcpyAsync(h->d_stage[b].ptr, pos + f0 * n * 3, size_t(12) * n * nf,
+                                   hipMemcpyHostToDevice, h->pipe.copy_stream));
+            return MDX_OK;
+        },
+        [&](int b, int64_t, int64_t nf) -> int {
+            return sq_accumulate_device(h, h->d_stage[b].as<float>(), n, nf);
+        });
+}
+
+// Frames straight from a trajectory file.  index: host int32[n_index] particle indices in the
+// order of the concatenated groups (structure.py:1484-1486), or NULL for the file's first
+// n_index particles.
+int mdx_sq_accumulate_traj(mdx_sq_t h, mdx_traj_t traj, const int64_t *frames, int64_t n_frames,
+                           const int32_t *index, int64_t n_index)
+{
+    MDX_REQUIRE(h && traj, "NULL handle");
+    MDX_REQUIRE(n_frames >= 0 && (n_frames == 0 || frames), "bad frame list");
+    MDX_TRY(set_device(h->dev));
+    Trajectory *t = mdx_traj_internal(traj);
+    const int64_t n = index ? n_index : (n_index > 0 ? n_index : t->n_atoms);
+    MDX_REQUIRE(n >= h->n_total, "the selection holds %lld particles, the groups need %lld",
+                (long long)n, (long long)h->n_total);
+    MDX_REQUIRE(index || n <= t->n_atoms, "selection larger than the trajectory");
+    if (n_frames == 0)
+        return MDX_OK;
+    MDX_TRY(h->pipe.ensure());
+    const int *d_index = nullptr;
+    if (index) {
+        for (int64_t i = 0; i < n; ++i)
+            if (index[i] < 0 || index[i] >= t->n_atoms)
+                return fail(MDX_ERR_INVALID_VALUE, "particle index %d out of range [0, %lld)",
+                            index[i], (long long)t->n_atoms);
+        MDX_HIP(hipStreamSynchronize(h->pipe.copy_stream));
+        MDX_TRY(h->d_index.ensure(size_t(4) * n));
+        MDX_HIP(hipMemcpy(h->d_index.ptr, index, size_t(4) * n, hipMemcpyHostToDevice));
+        d_index = h->d_index.as<int>();
     }
-    return MDX_OK;
+    const int64_t slab = std::min<int64_t>(
+        n_frames, std::max<int64_t>(1, (int64_t(64) << 20) / (12 * t->n_atoms)));
+    return h->pipe.run(
+        h->stream, n_frames, slab,
+        [&](int b, int64_t f0, int64_t nf) -> int {
+            MDX_TRY(h->d_stage[b].ensure(size_t(12) * n * slab));
+            TrajSelection sel{d_index, n, h->d_stage[b].as<float>()};
+            return t->stage_async(h->dev, h->pipe.copy_stream, frames + f0, nf, &sel, 1);
+        },
+        [&](int b, int64_t, int64_t nf) -> int {
+            return sq_accumulate_device(h, h->d_stage[b].as<float>(), n, nf);
+        });
 }
 
 int mdx_sq_result(mdx_sq_t h, double *ssf)

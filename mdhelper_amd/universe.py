@@ -26,14 +26,11 @@ class Timestep:
 
     @property
     def positions(self):
-        return self._trajectory._positions[self.frame]
+        return self._trajectory.frame_positions(self.frame)
 
     @property
     def dimensions(self):
-        d = self._trajectory._dimensions
-        if d is None:
-            return None
-        return d[self.frame if d.shape[0] > 1 else 0].copy()
+        return self._trajectory.frame_dimensions(self.frame)
 
     @property
     def volume(self):
@@ -52,7 +49,7 @@ class Timestep:
 
     @property
     def n_atoms(self):
-        return self._trajectory._positions.shape[1]
+        return self._trajectory.n_atoms
 
 
 class FrameSelection:
@@ -101,6 +98,19 @@ class ArrayTrajectory:
     @property
     def n_frames(self):
         return self._positions.shape[0]
+
+    @property
+    def n_atoms(self):
+        return self._positions.shape[1]
+
+    def frame_positions(self, frame):
+        return self._positions[frame]
+
+    def frame_dimensions(self, frame):
+        d = self._dimensions
+        if d is None:
+            return None
+        return d[frame if d.shape[0] > 1 else 0].copy()
 
     def __len__(self):
         return self.n_frames
@@ -245,7 +255,10 @@ class ArrayUniverse:
     def __init__(self, positions, dimensions=None, dt: float = 1.0, *, masses=None,
                  charges=None, resids=None, segids=None):
         self.trajectory = ArrayTrajectory(positions, dimensions, dt)
-        n = self.trajectory._positions.shape[1]
+        self._init_topology(masses, charges, resids, segids)
+
+    def _init_topology(self, masses, charges, resids, segids):
+        n = self.trajectory.n_atoms
         self._masses = np.ones(n) if masses is None else np.asarray(masses, dtype=float)
         self._charges = None if charges is None else np.asarray(charges, dtype=float)
         self._resids = np.arange(n) if resids is None else np.asarray(resids, dtype=int)

@@ -388,3 +388,55 @@ def test_sq_lattice_and_general_paths_agree(monkeypatch):
     eng.close()
     rho = of.fourier_sum_ref(q[::97], p[0].astype(np.float64))
     assert np.allclose(got[::97], (rho * rho.conj()).real, rtol=1e-6, atol=1e-6)
+
+
+def _dimers(n_pairs, L, r_lo, r_hi, seed):
+    """Isolated pairs on a coarse grid (cells far apart) with separations swept over [r_lo, r_hi]."""
+    rng = np.random.default_rng(seed)
+    side = int(np.ceil(n_pairs ** (1 / 3)))
+    grid = (np.stack(np.meshgrid(*[np.arange(side)] * 3, indexing="ij"), -1).reshape(-1, 3)[:n_pairs]
+            + 0.5) * (L / side)
+    u = rng.normal(size=(n_pairs, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    r = np.linspace(r_lo, r_hi, n_pairs)
+    a = grid + rng.uniform(-0.2, 0.2, (n_pairs, 3))
+    b = a + u * r[:, None]
+    return np.mod(np.vstack((a, b)), L).astype(np.float32)
+
+
+@pytest.mark.parametrize("algo", ["filter", "cell"])
+@pytest.mark.parametrize("case", [
+    # (range, n_bins): separations swept finely through both range ends, where the float32
+    # filter has to hand every pair near r0 / r1 to the exact path.  The second and third
+    # cases have r1 / width >> n_bins (narrow window far from the origin).
+    ((0.0, 3.0), 150), ((2.5, 3.0), 150), ((2.9, 3.0), 512), ((0.0, 3.0), 3)])
+def test_rdf_range_ends_swept_by_dimers(algo, case):
+    (r0, r1), nb = case
+    L = np.float32(140.0)
+    dims = np.array([L, L, L, 90, 90, 90], dtype=np.float32)
+    parts = [_dimers(6000, float(L), r1 - 2e-4, r1 + 2e-4, 31)]
+    if r0 > 0:
+        parts.append(_dimers(6000, float(L), r0 - 2e-4, r0 + 2e-4, 32) + np.float32(3.0))
+    pos = np.mod(np.vstack(parts), L).astype(np.float32)
+    want = c_radial_histogram(pos, pos, nb, (r0, r1), dims, exclusion=(1, 1))
+    for _ in range(3):     # the order inside a cell differs from run to run
+        got = _gpu_hist(pos, None, nb, (r0, r1), dims, (1, 1), algo)
+        assert np.array_equal(got, want), np.nonzero(got - want)[0]
+    assert want[-1] > 1000
+
+
+def test_rdf_cell_regression_pair_at_top_of_candidate_window():
+    """
+    A frame that used to gain two counts in bin 0 in ~85 % of the runs: one pair whose float32
+    distance sat in the last 1e-6 A of the candidate window was called "sure" with index
+    n_bins, which aliased the next per-wave histogram (slack budget).
+    """
+    rng = np.random.default_rng(12)
+    F, N, L = 24, 3000, 31.0
+    pos = rng.uniform(0, L, (1, N, 3)) + np.cumsum(rng.normal(0, 0.3, (F, N, 3)), axis=0)
+    pos = np.mod(pos, L).astype(np.float32)[17:18]
+    dims = np.array([[L + 0.17, L, L - 0.34, 90, 90, 90]], dtype=np.float32)
+    want = c_radial_histogram(pos[0], pos[0], 150, (0.0, 12.0), dims[0], exclusion=(1, 1))
+    for _ in range(10):
+        got = _gpu_hist(pos, None, 150, (0.0, 12.0), dims, (1, 1), "cell")
+        assert np.array_equal(got, want)
