@@ -262,6 +262,16 @@ int mdx_sq_accumulate_traj(mdx_sq_t h, mdx_traj_t traj, const int64_t *frames, i
 int mdx_isf_accumulate_traj(mdx_isf_t h, mdx_traj_t traj, const int64_t *frames,
                             int64_t n_frames, const int32_t *index, int64_t n_index);
 
+/* MSD / Onsager: the first n_blocks * n_frames_block listed frames of a trajectory file as
+ * one group's positions (the `self._positions[frame, slice] = g.positions` fill of
+ * transport.py:976-992 for groupings="atoms").  index: host int32[n_index] particle indices or
+ * NULL.  unwrap != 0 applies the reference's global unwrap (algorithm/topology.py:366-376,
+ * thresholds dims/2 as passed by transport.py:933-937) on the device, with dims = the three
+ * box lengths; zero_dims as for mdx_msd_push. */
+int mdx_msd_push_traj(mdx_msd_t h, int group, mdx_traj_t traj, const int64_t *frames,
+                      int64_t n_frames, const int32_t *index, int64_t n_index, int unwrap,
+                      const double *dims, int zero_dims);
+
 #ifdef __cplusplus
 }
 #endif

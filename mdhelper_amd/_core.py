@@ -385,6 +385,16 @@ class MsdEngine(_Engine):
     def push_device(self, group, d_pos, n_total, first, count, zero_dims=0):
         check(lib().mdx_msd_push_device(self.handle, group, d_pos, n_total, first, count, zero_dims))
 
+    def push_traj(self, group, traj_file, frames, index=None, *, unwrap_dims=None, zero_dims=0):
+        """A group's positions straight from a native trajectory file; ``unwrap_dims``: box
+        lengths for the device-side global unwrap (None: positions are used as stored)."""
+        f = np.ascontiguousarray(frames, dtype=np.int64)
+        i = None if index is None else np.ascontiguousarray(index, dtype=np.int32)
+        d = None if unwrap_dims is None else np.ascontiguousarray(unwrap_dims, dtype=np.float64)[:3]
+        check(lib().mdx_msd_push_traj(self.handle, group, traj_file.handle, _ptr(f), len(f), _ptr(i),
+                                      0 if i is None else len(i), 0 if d is None else 1, _ptr(d),
+                                      zero_dims))
+
     def result(self, want_msd=True):
         msd = np.zeros((self.n_groups, self.n_blocks, self.t_block)) if want_msd else None
         traj = np.zeros((self.n_groups, self.n_blocks, self.t_block, 3))

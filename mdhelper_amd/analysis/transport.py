@@ -276,9 +276,10 @@ class Onsager(SerialAnalysisBase):
         for lo, hi in self._own:
             self._own_slices.append(slice(index, index + hi - lo))
             index += hi - lo
-        self._positions = np.empty((self.n_frames, index, 3))
+        self._from_file = getattr(self, "_from_file", False)
+        self._positions = None if self._from_file else np.empty((self.n_frames, index, 3))
 
-        if self._unwrap:
+        if self._unwrap and not self._from_file:
             first = st.frames[0] if hasattr(st, "frames") else (self.start or 0)
             self.universe.trajectory[first]
             self._positions_old = np.array(self.universe.atoms.positions, dtype=float)
@@ -335,7 +336,7 @@ class Onsager(SerialAnalysisBase):
             self._positions[self._frame_index] -= scom
 
     def _conclude(self) -> None:
-        if self.n_frames != self._n_frames:
+        if self.n_frames != self._n_frames and self._positions is not None:
             self._positions = self._positions[:self._n_frames]
         delete_dimensions = np.isclose(self._dimensions, 0)
         zero_mask = int(sum(1 << k for k in range(3) if delete_dimensions[k]))
@@ -344,8 +345,17 @@ class Onsager(SerialAnalysisBase):
 
         if self._fft:
             eng = _core.MsdEngine(Tb, B, self._n_groups, dev=self._device)
+            if self._from_file:
+                # frames stream file -> pinned memory -> HBM; unwrapping and the float64
+                # widening happen on the device (mdx_msd_push_traj)
+                numbers = self._frame_numbers()[:self._n_frames]
+                for g, (grp, (lo, hi)) in enumerate(zip(self._groups, self._own)):
+                    if hi > lo:
+                        eng.push_traj(g, self._trajectory.native, numbers, grp.indices[lo:hi],
+                                      unwrap_dims=self._dimensions if self._unwrap else None,
+                                      zero_dims=zero_mask)
             for g, own in enumerate(self._own_slices):
-                if own.stop > own.start:
+                if own.stop > own.start and not self._from_file:
                     eng.push(g, self._positions, own.start, own.stop - own.start, zero_mask)
             if multi and getattr(self._comm, "device_collectives", False):
                 eng.allreduce(self._comm)
@@ -393,8 +403,10 @@ class Onsager(SerialAnalysisBase):
     def run(self, start=None, stop=None, step=None, frames=None, n_jobs: int = 1, verbose=None,
             **kwargs):
         traj = self._trajectory
-        fast = (hasattr(traj, "frame_block") and all(g == "atoms" for g in self._groupings)
-                and not self._unwrap and not self._center)
+        atoms_only = all(g == "atoms" for g in self._groupings) and not self._center
+        # trajectory files: nothing is staged on the host, unwrapping included
+        self._from_file = bool(atoms_only and self._fft and getattr(traj, "native", None) is not None)
+        fast = hasattr(traj, "frame_block") and atoms_only and (self._from_file or not self._unwrap)
         if not fast:
             return super().run(start=start, stop=stop, step=step, frames=frames, n_jobs=n_jobs,
                                verbose=verbose, **kwargs)
@@ -403,6 +415,9 @@ class Onsager(SerialAnalysisBase):
         numbers = self._frame_numbers()
         self.frames[:] = numbers
         self.times[:] = numbers * traj.dt
+        if self._from_file:
+            self._conclude()
+            return self
         block = traj.frame_block(numbers)
         for g, own, (lo, hi) in zip(self._groups, self._own_slices, self._own):
             self._positions[:, own] = block[:, g.indices[lo:hi]]

@@ -21,6 +21,7 @@
 // Everything is fp64: S_m - 2 A_m cancels catastrophically at small lags.
 #include "mdx_common.hpp"
 #include "mdx_internal.hpp"
+#include "mdx_traj.hpp"
 
 #include <rocfft/rocfft.h>
 
@@ -283,6 +284,7 @@ struct mdx_msd {
     FftCache fft;
     // accumulators: power [G][B][nc] + D [G][B*T_b] contiguous (one all-reduce), traj [G][B*T_b][3]
     DeviceBuffer d_acc, d_traj, d_series, d_spec, d_stage, d_inv_in, d_inv_out;
+    DeviceBuffer d_f32, d_index, d_prev, d_image;   // trajectory-file path: frames, unwrap state
     StreamTimer timer;
     int64_t bytes_moved = 0;
     double *power(int g) { return d_acc.as<double>() + int64_t(g) * n_blocks * nc; }
@@ -332,6 +334,88 @@ static int msd_push_device(mdx_msd *h, int group, const double *d_pos, int64_t n
     }
     h->timer.end(ev);
     MDX_HIP(hipGetLastError());
+    return MDX_OK;
+}
+
+// Frame preparation on the device: float32 frames -> the float64
+// [frame][particle][xyz] block the correlation kernels read, optionally unwrapped across the
+// periodic boundaries.  Restates `unwrap` (reference src/mdhelper/algorithm/topology.py:366-376)
+// per coordinate: d = x - x_old; |d| >= L/2 -> image -= sign(d); x_old = x; out = x + image * L,
+// with the same float64 operations (one multiply, one add, no contraction), so the unwrapped
+// trajectory is the one the reference builds.  One thread owns one coordinate and walks the
+// frames of the block in order; the state (x_old, image) persists between blocks.
+__global__ __launch_bounds__(256) void msd_unwrap_widen_kernel(
+    const float *__restrict__ in, int64_t n_coord, int64_t n_frames, int first_block, int unwrap,
+    double lx, double ly, double lz, float *__restrict__ prev, int *__restrict__ image,
+    double *__restrict__ out)
+{
+    const int64_t e = blockIdx.x * int64_t(256) + threadIdx.x;
+    if (e >= n_coord)
+        return;
+    const int k = int(e % 3);
+    const double L = k == 0 ? lx : (k == 1 ? ly : lz);
+    const double half = 0.5 * L;
+    float x_old = first_block ? in[e] : prev[e];
+    int img = first_block ? 0 : image[e];
+    for (int64_t f = 0; f < n_frames; ++f) {
+        const float x = in[f * n_coord + e];
+        double v = (double)x;
+        if (unwrap) {
+            const double d = __dsub_rn(v, (double)x_old);
+            if (fabs(d) >= half)
+                img -= (d > 0.0) - (d < 0.0);
+            x_old = x;
+            v = __dadd_rn(v, __dmul_rn((double)img, L));
+        }
+        out[f * n_coord + e] = v;
+    }
+    prev[e] = x_old;
+    image[e] = img;
+}
+
+// The first n_blocks * t_block listed frames of a trajectory file -> one group of the engine.
+static int msd_push_traj(mdx_msd *h, int group, Trajectory *t, const int64_t *frames,
+                         const int32_t *index, int64_t n_sel, int unwrap, const double *dims,
+                         int zero_dims)
+{
+    const int64_t T = int64_t(h->n_blocks) * h->t_block;
+    // particle chunks: the float64 block of a chunk within ~30 % of the free HBM
+    size_t free_b = 0, total_b = 0;
+    MDX_HIP(hipMemGetInfo(&free_b, &total_b));
+    free_b += h->d_stage.bytes;
+    int64_t chunk = std::max<int64_t>(1, int64_t(double(free_b) * 0.3) / (T * 24));
+    chunk = std::min(chunk, n_sel);
+    chunk = ceil_div(n_sel, ceil_div(n_sel, chunk));
+    std::vector<int32_t> iota;
+    if (!index) {
+        iota.resize(size_t(n_sel));
+        for (int64_t i = 0; i < n_sel; ++i)
+            iota[size_t(i)] = (int32_t)i;
+        index = iota.data();
+    }
+    MDX_HIP(hipStreamSynchronize(h->stream));
+    MDX_TRY(h->d_index.ensure(size_t(4) * n_sel));
+    MDX_HIP(hipMemcpy(h->d_index.ptr, index, size_t(4) * n_sel, hipMemcpyHostToDevice));
+    MDX_TRY(h->d_stage.ensure(size_t(T) * chunk * 24));
+    MDX_TRY(h->d_prev.ensure(size_t(chunk) * 12));
+    MDX_TRY(h->d_image.ensure(size_t(chunk) * 12));
+    const int64_t block = std::max<int64_t>(1, std::min<int64_t>(T, (int64_t(64) << 20) / (12 * chunk)));
+    MDX_TRY(h->d_f32.ensure(size_t(block) * chunk * 12));
+    for (int64_t a0 = 0; a0 < n_sel; a0 += chunk) {
+        const int64_t c = std::min(chunk, n_sel - a0);
+        for (int64_t f0 = 0; f0 < T; f0 += block) {
+            const int64_t nf = std::min(block, T - f0);
+            TrajSelection sel{h->d_index.as<int>() + a0, c, h->d_f32.as<float>()};
+            MDX_TRY(t->stage_async(h->dev, h->stream, frames + f0, nf, &sel, 1));
+            hipLaunchKernelGGL(msd_unwrap_widen_kernel, dim3((unsigned)ceil_div(3 * c, 256)),
+                               dim3(256), 0, h->stream, h->d_f32.as<float>(), 3 * c, nf,
+                               f0 == 0 ? 1 : 0, unwrap, dims ? dims[0] : 0.0, dims ? dims[1] : 0.0,
+                               dims ? dims[2] : 0.0, h->d_prev.as<float>(), h->d_image.as<int>(),
+                               h->d_stage.as<double>() + f0 * c * 3);
+            MDX_HIP(hipGetLastError());
+        }
+        MDX_TRY(msd_push_device(h, group, h->d_stage.as<double>(), c, 0, c, zero_dims));
+    }
     return MDX_OK;
 }
 
@@ -396,7 +480,8 @@ int mdx_msd_destroy(mdx_msd_t h)
     h->timer.destroy();
     h->fft.destroy();
     for (DeviceBuffer *b : {&h->d_acc, &h->d_traj, &h->d_series, &h->d_spec, &h->d_stage,
-                            &h->d_inv_in, &h->d_inv_out})
+                            &h->d_inv_in, &h->d_inv_out, &h->d_f32, &h->d_index, &h->d_prev,
+                            &h->d_image})
         b->release();
     if (h->stream)
         (void)hipStreamDestroy(h->stream);
@@ -457,6 +542,31 @@ int mdx_msd_push(mdx_msd_t h, int group, const double *pos, int64_t n_total, int
         MDX_HIP(hipStreamSynchronize(h->stream));
     }
     return MDX_OK;
+}
+
+int mdx_msd_push_traj(mdx_msd_t h, int group, mdx_traj_t traj, const int64_t *frames,
+                      int64_t n_frames, const int32_t *index, int64_t n_index, int unwrap,
+                      const double *dims, int zero_dims)
+{
+    MDX_REQUIRE(h && traj && frames, "NULL argument");
+    MDX_REQUIRE(group >= 0 && group < h->n_groups, "group %d out of range", group);
+    MDX_REQUIRE(zero_dims >= 0 && zero_dims < 8, "zero_dims is a 3-bit mask");
+    const int64_t T = int64_t(h->n_blocks) * h->t_block;
+    MDX_REQUIRE(n_frames >= T, "%lld frames listed, the engine needs %lld", (long long)n_frames,
+                (long long)T);
+    MDX_REQUIRE(!unwrap || (dims && dims[0] > 0 && dims[1] > 0 && dims[2] > 0),
+                "unwrapping needs positive box dimensions");
+    MDX_TRY(set_device(h->dev));
+    Trajectory *t = mdx_traj_internal(traj);
+    const int64_t n = index ? n_index : (n_index > 0 ? n_index : t->n_atoms);
+    MDX_REQUIRE(index || n <= t->n_atoms, "selection larger than the trajectory");
+    if (n == 0)
+        return MDX_OK;
+    for (int64_t i = 0; index && i < n; ++i)
+        if (index[i] < 0 || index[i] >= t->n_atoms)
+            return fail(MDX_ERR_INVALID_VALUE, "particle index %d out of range [0, %lld)", index[i],
+                        (long long)t->n_atoms);
+    return msd_push_traj(h, group, t, frames, index, n, unwrap, dims, zero_dims);
 }
 
 int mdx_msd_result(mdx_msd_t h, double *msd_self_sum, double *sum_traj)

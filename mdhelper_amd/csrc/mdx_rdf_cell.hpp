@@ -49,7 +49,8 @@ struct CellArgs {
 
 constexpr int CELL_MAX = 16384;   // cells per frame (64 KiB of LDS counters)
 constexpr int SORT_THREADS = 1024;
-constexpr int CELL_QCAP = 2048;   // surviving j tiles queued per round of the pair kernel
+constexpr int CELL_QCAP = 1024;   // surviving j tiles queued per round of the pair kernel
+constexpr int CELL_TODO = 128;    // per-wave list of pairs waiting for the exact arithmetic
 
 struct CellGrid {
     int nc[3];
@@ -227,14 +228,11 @@ __device__ inline void cell_pair_exact(const PairCtx<true> &c, const CellArgs &a
         hist.add(rdf_bin_exact(rsq, sT, a.n_bins, c.r0f, c.inv_wf), w);
 }
 
-// One float32 distance evaluation + binning.  The bin arithmetic is unconditional (after
-// culling nearly every wave step holds a candidate, so a branch around it would always be
-// taken); only the histogram add is predicated and only the rare uncertain pair branches.
-// TAGS: 0 no exclusion, 1 compare exclusion tags.
 // wave-uniform float constants of the hot loop, forced into SGPRs
 struct CellHot {
-    float cand_hi, cand_lo, inv_w, pos0, sure_half;
-    float L[3], invL[3];   // box lengths and fl32(1/L): only the cold block widens them to fp64
+    float cand_hi, cand_lo, inv_w, sure_w;   // sure_w = 1 - 2 eta
+    float pos0;   // -r0/width - eta; kept in a VECTOR register (an fma takes one scalar operand)
+    float L[3], invL[3];   // box lengths and fl32(1/L): widened to fp64 only by the exact passes
 };
 
 __device__ inline float cell_uniform(float v)
@@ -242,55 +240,161 @@ __device__ inline float cell_uniform(float v)
     return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
 
-// MODE: 0 per-wave LDS histograms, 1 global histogram (bin tables too large for LDS).
-// Register budget matters here: with the fp64 box constants live across the hot loop the
-// kernel needed 106 VGPRs (4 waves/SIMD); rebuilding them inside the cold block brings it
-// to 72 (7 waves/SIMD) and 17 % more throughput.  (Appending the undecided pairs to a global
-// list for a second kernel was measured too: the append atomics made it 10x slower.)
-template <bool LOWER, int TAGS, int MODE, typename Hist>
-__device__ inline void cell_step(const CellHot &c, const CellArgs &a, const double *sT,
-                                 const Hist &hist, float fx, float fy, float fz, int tag_i,
-                                 int tag_j, const float4 *po1f, const float4 *po2f, unsigned i_idx,
-                                 unsigned j_idx, unsigned w, unsigned &n_exact)
+// wave-uniform bookkeeping of the undecided pairs (scalar registers)
+struct CellWave {
+    uint2 *todo;         // this wave's list in LDS: (i index, j index | (weight - 1) << 31)
+    unsigned n_todo;     // entries waiting
+    unsigned overflow;   // an append did not fit since the mark was taken
+    unsigned n_exact;    // pairs sent to the exact arithmetic so far
+};
+
+// The float32 filter of one pair: bin coordinate, candidate and sure flags.
+template <bool LOWER, int TAGS>
+__device__ inline void cell_filter(const CellHot &c, float fx, float fy, float fz, int tag_i,
+                                   int tag_j, float &pos, bool &cand, bool &sure)
 {
     float r2 = __fmaf_rn(fz, fz, __fmaf_rn(fy, fy, fx * fx));
-    // pos = (sqrt(r2) - r0) / width; raw v_sqrt_f32 (a denormal r2 ends on the exact path)
-    float pos = __fmaf_rn(__builtin_amdgcn_sqrtf(r2), c.inv_w, c.pos0);
-    // v_fract_f32 = pos - floor(pos).  A sure candidate has pos > eta > 0 (the candidate window
-    // keeps pos > -eta and such a pos has fract > 1 - eta, i.e. is not sure), so truncation
-    // by v_cvt_i32_f32 is its floor.
-    float fr = __builtin_amdgcn_fractf(pos);
-    bool cand = LOWER ? (r2 < c.cand_hi && r2 >= c.cand_lo) : (r2 < c.cand_hi);
-    // farther than eta from both neighbouring edges (covers both range ends)
-    bool sure = fabsf(fr - 0.5f) < c.sure_half;
+    // pos = (sqrt(r2) - r0) / width - eta; raw v_sqrt_f32 (a denormal r2 ends on the exact path).
+    // "Farther than eta from both neighbouring bin edges" is fract(pos) < 1 - 2 eta in this
+    // shifted coordinate: with pos = k + t, the unshifted fraction is t + eta, which lies in
+    // (eta, 1 - eta) exactly when t < 1 - 2 eta (t + eta >= 1 means it wrapped to < eta).  One
+    // v_fract and one compare; for a sure pair floor(pos) is the bin, and since a candidate has
+    // pos > -2 eta (window) the truncating v_cvt_i32_f32 is that floor.
+    pos = __fmaf_rn(__builtin_amdgcn_sqrtf(r2), c.inv_w, c.pos0);
+    const float t = __builtin_amdgcn_fractf(pos);
+    cand = LOWER ? (r2 < c.cand_hi && r2 >= c.cand_lo) : (r2 < c.cand_hi);
+    sure = t < c.sure_w;
     if (TAGS)
         cand = cand && (tag_i != tag_j);
+}
+
+__device__ inline void cell_exact_ctx(const CellHot &c, const CellArgs &a, PairCtx<true> &cx)
+{
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {   // L and fl32(1/L), widened only here
+        cx.Ld[k] = (double)c.L[k];
+        cx.invd[k] = (double)c.invL[k];
+    }
+    cx.r0f = (float)a.r0;
+    cx.inv_wf = c.inv_w;
+}
+
+// One float32 distance evaluation + binning.  The bin arithmetic is unconditional (after
+// culling nearly every wave step holds a candidate, so a branch around it would always be
+// taken); only the histogram add is predicated.  An undecided pair is not evaluated here, a
+// lane or two at a time with fp64 temporaries in the middle of the hot loop: it is appended to
+// the wave's list in LDS (slot = list length + rank among the undecided lanes; the length lives
+// in a scalar register) and cell_flush evaluates the list 64 pairs at a time.  Measured at C2:
+// evaluating in place cost 15-20 % of the kernel (3 % of the wave steps took a ~70-instruction
+// detour with one or two lanes active) and 66 KB of code (the detour inlined ~50 times).
+// MODE: 0 per-wave LDS histograms, 1 global histogram (bin tables too large for LDS).
+// TAGS: 0 no exclusion, 1 compare exclusion tags.
+template <bool LOWER, int TAGS, int MODE, typename Hist>
+__device__ inline void cell_step(const CellHot &c, const CellArgs &a, const Hist &hist, float fx,
+                                 float fy, float fz, int tag_i, int tag_j, unsigned i_base,
+                                 unsigned j_idx, unsigned w, CellWave &wv)
+{
+    float pos;
+    bool cand, sure;
+    cell_filter<LOWER, TAGS>(c, fx, fy, fz, tag_i, tag_j, pos, cand, sure);
     // Scalar mask arithmetic (no extra VALU compare for the negation); the wave-uniform test
     // puts the cold block out of line so the hot path falls through.
     const unsigned long long m_cand = __builtin_amdgcn_ballot_w64(cand);
     const unsigned long long m_sure = __builtin_amdgcn_ballot_w64(sure);
-    if (__builtin_expect((m_cand & ~m_sure) != 0ull, 0)) {
-        if (cand && !sure) {
-            {
-                ++n_exact;
-                // the fp64 constants are rebuilt here, in the cold block, instead of living in
-                // registers across the hot loop
-                PairCtx<true> cx;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    cx.Ld[k] = (double)c.L[k];
-                    cx.invd[k] = (double)c.invL[k];
-                }
-                cx.r0f = (float)a.r0;
-                cx.inv_wf = c.inv_w;
-                cell_pair_exact(cx, a, sT, hist, po1f + i_idx, po2f + j_idx, w);
+    const unsigned long long m_todo = m_cand & ~m_sure;
+    if (__builtin_expect(m_todo != 0ull, 0)) {
+        const unsigned cnt = (unsigned)__popcll(m_todo);
+        if (wv.n_todo + cnt <= (unsigned)CELL_TODO) {
+            if (cand && !sure) {
+                const unsigned rank = __builtin_amdgcn_mbcnt_hi(
+                    (unsigned)(m_todo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_todo, 0u));
+                // i index = (wave-uniform base of the half tile) + lane, formed only here
+                wv.todo[wv.n_todo + rank] =
+                    make_uint2(i_base + (threadIdx.x & 63u), j_idx | ((w - 1u) << 31));
             }
+            wv.n_todo += cnt;
+        } else {
+            // the list is full (adversarial input: everything on a bin edge): the caller rolls
+            // the list back to its mark and redoes the unit with cell_slow_unit
+            wv.overflow = 1u;
         }
     }
     if (MODE == 1)   // global histogram: no spare slot behind the last bin
         cand = cand && pos < (float)a.n_bins;
     if (cand && sure)
         hist.add((int)pos, w);
+}
+
+// Exact arithmetic for the listed pairs, 64 at a time, one per lane (the list is wave-private).
+template <typename Hist>
+__device__ inline void cell_flush(const CellHot &c, const CellArgs &a, const double *sT,
+                                  const Hist &hist, CellWave &wv, const float4 *po1f,
+                                  const float4 *po2f)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    PairCtx<true> cx;
+    cell_exact_ctx(c, a, cx);
+    const unsigned lane = threadIdx.x & 63u;
+    for (unsigned e0 = 0; e0 < wv.n_todo; e0 += 64u) {
+        if (e0 + lane < wv.n_todo) {
+            const uint2 e = wv.todo[e0 + lane];
+            cell_pair_exact(cx, a, sT, hist, po1f + e.x, po2f + (e.y & 0x7fffffffu),
+                            (e.y >> 31) + 1u);
+        }
+    }
+    wv.n_exact += wv.n_todo;
+    wv.n_todo = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Redo of one unit whose undecided pairs did not fit the list: the same float32 filter (same
+// operations, hence the same classification) one wave step at a time, the list flushed whenever
+// the next step might not fit; sure pairs are skipped (the fast pass has binned them).
+// sJw: the wave's slab of (pre-shifted) j rows [j0, j0 + nj); u_mask: which i halves the fast
+// pass ran; general: per-pair image search.
+template <bool LOWER, bool EXCL, typename Hist>
+__device__ inline void cell_slow_unit(const CellHot &c, const CellArgs &a, const double *sT,
+                                      const Hist &hist, const float4 *sJw, int j0, int nj,
+                                      unsigned u_mask, bool tags, bool general, const float *geo,
+                                      const float4 &p0, const float4 &p1, const float4 *po1f,
+                                      const float4 *po2f, unsigned i_idx0, unsigned jbase,
+                                      unsigned w, CellWave &wv)
+{
+    for (int jj = j0; jj < j0 + nj; ++jj) {
+        const float4 q = sJw[jj];
+        for (int u = 0; u < 2; ++u) {
+            if (!((u_mask >> u) & 1u))
+                continue;
+            const float4 &p = u ? p1 : p0;
+            float fx = q.x - p.x, fy = q.y - p.y, fz = q.z - p.z;
+            if (general) {
+                fx = __fmaf_rn(-rintf(fx * geo[3]), geo[0], fx);
+                fy = __fmaf_rn(-rintf(fy * geo[4]), geo[1], fy);
+                fz = __fmaf_rn(-rintf(fz * geo[5]), geo[2], fz);
+            }
+            float pos;
+            bool cand, sure;
+            cell_filter<LOWER, 0>(c, fx, fy, fz, 0, 0, pos, cand, sure);
+            if (EXCL && tags)
+                cand = cand && (__float_as_int(p.w) != __float_as_int(q.w));
+            const bool todo = cand && !sure;
+            const unsigned long long m_todo = __builtin_amdgcn_ballot_w64(todo);
+            if (m_todo == 0ull)
+                continue;
+            if (wv.n_todo > (unsigned)CELL_TODO - 64u)
+                cell_flush(c, a, sT, hist, wv, po1f, po2f);
+            if (todo) {
+                const unsigned rank = __builtin_amdgcn_mbcnt_hi(
+                    (unsigned)(m_todo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_todo, 0u));
+                wv.todo[wv.n_todo + rank] =
+                    make_uint2(i_idx0 + 64u * u, (jbase + jj) | ((w - 1u) << 31));
+            }
+            wv.n_todo += (unsigned)__popcll(m_todo);
+        }
+    }
 }
 
 template <bool EXCL, bool LOWER, int MODE>
@@ -303,6 +407,7 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
     unsigned *sh = reinterpret_cast<unsigned *>(sT + (a.n_bins + 1));         // [n_hist][n_bins + 1]
     __shared__ unsigned s_exact, s_units, s_general, s_qn, s_qnext;
     __shared__ unsigned sQ[CELL_QCAP];
+    __shared__ uint2 s_todo[4][CELL_TODO];
     __shared__ float s_geo[32];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -338,7 +443,7 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
     // and parked in LDS; the hot loop keeps only five floats of them, in SGPRs.
     //   s_geo: [0..2] L, [3..5] 1/L (float32), [6] cut, [7] cut^2,
     //          [8..10] cI, [11..13] hI, [14..19] cH[2][3], [20..25] hH[2][3],
-    //          [26] cand_hi, [27] cand_lo, [28] inv_w, [29] pos0, [30] sure_half
+    //          [26] cand_hi, [27] cand_lo, [28] inv_w, [29] -r0/w - eta, [30] 1 - 2 eta
     unsigned long long *out =
         a.counts + int64_t((I + 7 * frame_l) % a.n_rep) * a.n_bins;
     if (tid == 0) {
@@ -367,16 +472,17 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
         s_geo[26] = ctx.cand_hi;
         s_geo[27] = ctx.cand_lo;
         s_geo[28] = ctx.inv_wf;
-        s_geo[29] = -ctx.r0f * ctx.inv_wf;
-        s_geo[30] = 0.5f - ctx.eta;
+        s_geo[29] = -ctx.r0f * ctx.inv_wf - ctx.eta;
+        s_geo[30] = 1.0f - 2.0f * ctx.eta;
     }
     __syncthreads();
     CellHot hot;
     hot.cand_hi = cell_uniform(s_geo[26]);
     hot.cand_lo = cell_uniform(s_geo[27]);
     hot.inv_w = cell_uniform(s_geo[28]);
-    hot.pos0 = cell_uniform(s_geo[29]);
-    hot.sure_half = cell_uniform(s_geo[30]);
+    hot.pos0 = s_geo[29];
+    asm volatile("" : "+v"(hot.pos0));   // stays in a VGPR
+    hot.sure_w = cell_uniform(s_geo[30]);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         hot.L[k] = cell_uniform(s_geo[k]);
@@ -390,7 +496,8 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
 
     const float4 *PW1 = a.pw1 + int64_t(frame) * a.n1p + int64_t(I) * 128;
     const float4 *PO1f = a.po1 + int64_t(frame) * a.n1p;     // this frame's original coordinates
-    const unsigned i_idx0 = unsigned(I) * 128u + unsigned(lane);
+    const unsigned i_base0 = unsigned(I) * 128u;   // wave-uniform; + lane = this lane's i index
+    const unsigned i_idx0 = i_base0 + unsigned(lane);
     const float4 *PW2 = a.pw2 + int64_t(frame) * a.n2p;
     const float4 *PO2 = a.po2 + int64_t(frame) * a.n2p;
     const float4 *BB2 = a.bb2 + int64_t(frame) * t64_2 * 2;
@@ -398,7 +505,8 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
     const float4 p0 = PW1[lane], p1 = PW1[64 + lane];
 
     float4 *sJw = sJ + wave * 64;
-    unsigned n_exact = 0, n_units = 0, n_general = 0;
+    CellWave wv{s_todo[wave], 0u, 0u, 0u};
+    unsigned n_units = 0, n_general = 0;
     const int Jbeg = a.self ? 2 * I : 0;
     // Rounds of up to CELL_QCAP candidate j tiles: all four waves test candidates and append
     // the survivors to one LDS queue, then pull tiles from it one at a time (LDS atomic), so
@@ -511,21 +619,26 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
                     n_units += (bits & 1u) + (bits >> 1);
 #define MDX_CELL_ONE(TG, U0, U1, Q, JJ)                                                            \
     if (GH) {                                                                                      \
-        if (U0) cell_step<LOWER, TG, MODE>(hot, a, thr, hg, Q.x - p0.x, Q.y - p0.y, Q.z - p0.z, __float_as_int(p0.w), __float_as_int(Q.w), PO1f, PO2, i_idx0, jbase + (JJ), w, n_exact); \
-        if (U1) cell_step<LOWER, TG, MODE>(hot, a, thr, hg, Q.x - p1.x, Q.y - p1.y, Q.z - p1.z, __float_as_int(p1.w), __float_as_int(Q.w), PO1f, PO2, i_idx0 + 64u, jbase + (JJ), w, n_exact); \
+        if (U0) cell_step<LOWER, TG, MODE>(hot, a, hg, Q.x - p0.x, Q.y - p0.y, Q.z - p0.z, __float_as_int(p0.w), __float_as_int(Q.w), i_base0, (JJ), w, wv); \
+        if (U1) cell_step<LOWER, TG, MODE>(hot, a, hg, Q.x - p1.x, Q.y - p1.y, Q.z - p1.z, __float_as_int(p1.w), __float_as_int(Q.w), i_base0 + 64u, (JJ), w, wv); \
     } else {                                                                                       \
-        if (U0) cell_step<LOWER, TG, MODE>(hot, a, thr, hl, Q.x - p0.x, Q.y - p0.y, Q.z - p0.z, __float_as_int(p0.w), __float_as_int(Q.w), PO1f, PO2, i_idx0, jbase + (JJ), w, n_exact); \
-        if (U1) cell_step<LOWER, TG, MODE>(hot, a, thr, hl, Q.x - p1.x, Q.y - p1.y, Q.z - p1.z, __float_as_int(p1.w), __float_as_int(Q.w), PO1f, PO2, i_idx0 + 64u, jbase + (JJ), w, n_exact); \
+        if (U0) cell_step<LOWER, TG, MODE>(hot, a, hl, Q.x - p0.x, Q.y - p0.y, Q.z - p0.z, __float_as_int(p0.w), __float_as_int(Q.w), i_base0, (JJ), w, wv); \
+        if (U1) cell_step<LOWER, TG, MODE>(hot, a, hl, Q.x - p1.x, Q.y - p1.y, Q.z - p1.z, __float_as_int(p1.w), __float_as_int(Q.w), i_base0 + 64u, (JJ), w, wv); \
     }
 // four slab entries are fetched ahead of their use so the LDS latency overlaps the arithmetic
 #define MDX_CELL_RUN(TG, U0, U1)                                                                   \
-    for (int jj = 16 * s; jj < 16 * s + 16; jj += 4) {                                             \
+    /* the global j index lives in a scalar register of its own: derived from the loop counter  \
+       it would be recomputed with a vector add at every step although only the cold block      \
+       reads it */                                                                              \
+    unsigned jg = __builtin_amdgcn_readfirstlane(jbase + 16u * unsigned(s));                       \
+    for (int jj = 16 * s; jj < 16 * s + 16; jj += 4, jg += 4u) {                                   \
         const float4 q0 = sJw[jj], q1 = sJw[jj + 1], q2 = sJw[jj + 2], q3 = sJw[jj + 3];           \
-        MDX_CELL_ONE(TG, U0, U1, q0, jj)                                                           \
-        MDX_CELL_ONE(TG, U0, U1, q1, jj + 1)                                                       \
-        MDX_CELL_ONE(TG, U0, U1, q2, jj + 2)                                                       \
-        MDX_CELL_ONE(TG, U0, U1, q3, jj + 3)                                                       \
+        MDX_CELL_ONE(TG, U0, U1, q0, jg)                                                           \
+        MDX_CELL_ONE(TG, U0, U1, q1, jg + 1u)                                                      \
+        MDX_CELL_ONE(TG, U0, U1, q2, jg + 2u)                                                      \
+        MDX_CELL_ONE(TG, U0, U1, q3, jg + 3u)                                                      \
     }
+                    const unsigned mark = wv.n_todo;
                     if (tags) {
                         if (bits == 3u) { MDX_CELL_RUN(1, true, true) }
                         else if (bits == 1u) { MDX_CELL_RUN(1, true, false) }
@@ -537,11 +650,18 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
                     }
 #undef MDX_CELL_RUN
 #undef MDX_CELL_ONE
+                    if (__builtin_expect(wv.overflow != 0u, 0)) {
+                        wv.overflow = 0u;
+                        wv.n_todo = mark;
+                        if (GH) cell_slow_unit<LOWER, EXCL>(hot, a, thr, hg, sJw, 16 * s, 16, bits, tags, false, s_geo, p0, p1, PO1f, PO2, i_idx0, jbase, w, wv);
+                        else cell_slow_unit<LOWER, EXCL>(hot, a, thr, hl, sJw, 16 * s, 16, bits, tags, false, s_geo, p0, p1, PO1f, PO2, i_idx0, jbase, w, wv);
+                    }
                 }
             } else {
                 // tile pair that straddles half a box: per-pair image search (float32), rare
                 n_units += 8;
                 n_general += 8;
+                const unsigned mark = wv.n_todo;
 #pragma unroll 2
                 for (int jj = 0; jj < 64; ++jj) {
                     float4 q = sJw[jj];
@@ -552,18 +672,30 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
                         fx = __fmaf_rn(-rintf(fx * s_geo[3]), s_geo[0], fx);
                         fy = __fmaf_rn(-rintf(fy * s_geo[4]), s_geo[1], fy);
                         fz = __fmaf_rn(-rintf(fz * s_geo[5]), s_geo[2], fz);
-                        if (GH) cell_step<LOWER, EXCL ? 1 : 0, MODE>(hot, a, thr, hg, fx, fy, fz, __float_as_int(p.w), __float_as_int(q.w), PO1f, PO2, i_idx0 + 64u * u, jbase + jj, w, n_exact);
-                        else cell_step<LOWER, EXCL ? 1 : 0, MODE>(hot, a, thr, hl, fx, fy, fz, __float_as_int(p.w), __float_as_int(q.w), PO1f, PO2, i_idx0 + 64u * u, jbase + jj, w, n_exact);
+                        if (GH) cell_step<LOWER, EXCL ? 1 : 0, MODE>(hot, a, hg, fx, fy, fz, __float_as_int(p.w), __float_as_int(q.w), i_base0 + 64u * u, jbase + jj, w, wv);
+                        else cell_step<LOWER, EXCL ? 1 : 0, MODE>(hot, a, hl, fx, fy, fz, __float_as_int(p.w), __float_as_int(q.w), i_base0 + 64u * u, jbase + jj, w, wv);
                     }
                 }
+                if (__builtin_expect(wv.overflow != 0u, 0)) {
+                    wv.overflow = 0u;
+                    wv.n_todo = mark;
+                    if (GH) cell_slow_unit<LOWER, EXCL>(hot, a, thr, hg, sJw, 0, 64, 3u, true, true, s_geo, p0, p1, PO1f, PO2, i_idx0, jbase, w, wv);
+                    else cell_slow_unit<LOWER, EXCL>(hot, a, thr, hl, sJw, 0, 64, 3u, true, true, s_geo, p0, p1, PO1f, PO2, i_idx0, jbase, w, wv);
+                }
+            }
+            if (wv.n_todo >= 64u) {   // enough undecided pairs for a full-width exact pass
+                if (GH) cell_flush(hot, a, thr, hg, wv, PO1f, PO2);
+                else cell_flush(hot, a, thr, hl, wv, PO1f, PO2);
             }
         }
         __syncthreads();   // the queue is reset by the next round
     }
-    for (int off = 32; off > 0; off >>= 1)
-        n_exact += __shfl_xor((int)n_exact, off);
+    if (wv.n_todo) {
+        if (GH) cell_flush(hot, a, thr, hg, wv, PO1f, PO2);
+        else cell_flush(hot, a, thr, hl, wv, PO1f, PO2);
+    }
     if (lane == 0) {
-        if (n_exact) atomicAdd(&s_exact, n_exact);
+        if (wv.n_exact) atomicAdd(&s_exact, wv.n_exact);
         if (n_units) atomicAdd(&s_units, n_units);
         if (n_general) atomicAdd(&s_general, n_general);
     }

@@ -112,3 +112,46 @@ def test_structure_factor_and_isf_from_file_universe(tmp_path):
     assert np.allclose(a.results.iisf, ref["iisf"], rtol=1e-6, atol=1e-9)
     assert np.allclose(a.results.cisf, b.results.cisf, rtol=1e-12, atol=1e-12)
     assert np.array_equal(a.results.times, b.results.times)
+
+
+@pytest.mark.parametrize("kind", ["netcdf", "dcd"])
+def test_onsager_from_file_with_device_unwrap(tmp_path, kind):
+    """Wrapped trajectory on disk -> device unwrap + MSD equals the host-unwrapped analysis."""
+    import warnings
+    from mdhelper_amd.analysis import Onsager
+    rng = np.random.default_rng(33)
+    T, N, L = 400, 96, np.array([11.0, 12.5, 10.25])
+    walk = rng.uniform(0, L, (1, N, 3)) + np.cumsum(rng.normal(0, 0.45, (T, N, 3)), axis=0)
+    wrapped = np.mod(walk, L).astype(np.float32)          # crosses the box many times
+    path = tmp_path / ("w.nc" if kind == "netcdf" else "w.dcd")
+    if kind == "netcdf":
+        write_amber_netcdf(path, wrapped, L, times=np.arange(T) * 0.5)
+    else:
+        write_dcd(path, wrapped, [[*L, 90, 90, 90]])
+    dims = np.array([*L, 90, 90, 90], dtype=np.float32)
+    charges = np.where(np.arange(N) % 2 == 0, 1.0, -1.0)
+    uf = mdhelper_amd.FileUniverse(path, dt=0.5, charges=charges)
+    um = mdhelper_amd.ArrayUniverse(wrapped, dims, dt=0.5, charges=charges)
+    cat, an = np.arange(0, N, 2), np.arange(1, N, 2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = Onsager([uf.select(cat), uf.select(an)], temperature=300, n_blocks=3, unwrap=True,
+                    verbose=False).run()
+        b = Onsager([um.select(cat), um.select(an)], temperature=300, n_blocks=3, unwrap=True,
+                    verbose=False).run()
+    assert a._from_file and not b._from_file
+    assert a.results.msd_self.shape == (2, 3, 133)
+    scale = np.abs(b.results.msd_self).max()
+    assert np.allclose(a.results.msd_self, b.results.msd_self, rtol=1e-9, atol=1e-9 * scale)
+    assert np.allclose(a.results.msd_cross, b.results.msd_cross, rtol=1e-9,
+                       atol=1e-9 * np.abs(b.results.msd_cross).max())
+    # the walk really is diffusive after unwrapping: MSD(m) ~ 3 sigma^2 m / (2 D) with D = 3
+    m = np.arange(1, 40)
+    assert np.allclose(a.results.msd_self[:, :, 1:40].mean(axis=(0, 1)), 0.45 ** 2 * m / 2, rtol=0.15)
+    # without unwrapping the file path equals the in-memory fast path
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = Onsager(uf.atoms, temperature=300, verbose=False).run(stop=300)
+        b = Onsager(um.atoms, temperature=300, verbose=False).run(stop=300)
+    assert np.allclose(a.results.msd_self, b.results.msd_self, rtol=1e-9,
+                       atol=1e-9 * np.abs(b.results.msd_self).max())
