@@ -15,7 +15,7 @@ per-rank histograms meet in ONE RCCL all-reduce at the end of the timed region.
 
 Prints one JSON line on rank 0:
   value        = pair distances binned per second, whole job (sum of all counts / time)
-  roofline     = dominant kernel (rdf_tile_kernel) algorithmic HBM bytes / its HIP-event time
+  roofline     = dominant kernel (rdf_cell_pair_kernel) algorithmic HBM bytes / its HIP-event time
   cpu_baseline = the C restatement of the reference path (oracle/c/rdf_oracle.c,
                  OpenMP on the host cores) on a bounded sample of the same frames;
                  its counts are also checked bit-for-bit against the GPU's.
@@ -35,6 +35,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 FP64_VALU_PEAK_TFLOPS = 78.6   # vector fp64 spec
 FP32_VALU_PEAK_TFLOPS = 157.3
+CUS = 256                      # 4 SIMDs each
+CLOCK_HZ = 2.4e9
 
 
 def parse():
@@ -224,9 +226,11 @@ def bench_rdf(args, world, wide=False):
                 "evaluated_fraction_of_pair_space": st["pairs_computed"] / max(st["pairs_evaluated"], 1),
                 "exact_path_fraction_of_evaluations": st["pairs_exact"] / max(st["pairs_computed"], 1),
                 "image_search_path_fraction": st["cell_units_general"] / max(st["cell_units"], 1),
-                # 7 float32 VALU instructions per evaluation in the culled inner loop
-                "fp32_valu_frac_est": (st["pairs_computed"] / kernel_s * 7 * 2 / 1e12 / FP32_VALU_PEAK_TFLOPS)
-                if kernel_s > 0 else 0.0,
+                # The hot step (64 evaluations) issues 10 plain VALU + v_sqrt_f32 + 2 v_cmp; at the
+                # measured issue costs (profiles/r01_d_valu_issue_microbench.txt: 3.0 / 8.3 / 4.2
+                # cycles per wave-instruction per SIMD) that is 46.7 cycles per step per SIMD.
+                "valu_issue_bound_frac_est": (st["pairs_computed"] / kernel_s / 64.0 / (4 * CUS)
+                                              * 46.7 / CLOCK_HZ) if kernel_s > 0 else 0.0,
             },
         },
     }

@@ -33,6 +33,7 @@ from ..algorithm.molecule import center_of_mass
 from ..algorithm.unit import strip_unit
 from ..algorithm.utility import get_closest_factors
 from ..comm import shard_range
+from ..universe import box_volumes
 from .base import DynamicAnalysisBase, FrameBatcher, NumbaAnalysisBase
 
 _GROUPINGS_RDF = {"atoms", "residues", "segments"}
@@ -50,8 +51,7 @@ def radial_histogram(pos1, pos2, n_bins: int, range, dims, *, exclusion=None) ->
     n_bins : int
     range : (float, float)
     dims : array-like, shape (6,)
-        Box lengths and angles; only orthorhombic boxes are supported
-        (``NotImplementedError`` otherwise).
+        Box lengths and angles (orthorhombic or triclinic).
     exclusion : (int, int), keyword-only, optional
         Pairs with ``i // exclusion[0] == j // exclusion[1]`` are dropped;
         ``(1, 1)`` drops self pairs.
@@ -317,7 +317,7 @@ class RadialDistributionFunction(DynamicAnalysisBase):
         for b0 in np.arange(0, len(mine), block):
             sel = mine[b0:b0 + block]
             boxes = traj.box_block(sel)
-            self._area_or_volume += float(np.prod(boxes[:, :3].astype(np.float64), axis=1).sum())
+            self._area_or_volume += float(box_volumes(boxes).sum())
             if native is not None:
                 self._engine.accumulate_traj(native, sel, boxes, None if all1 else i1,
                                              None if self._same else i2, same=self._same)

@@ -203,6 +203,139 @@ __global__ __launch_bounds__(256) void rdf_tile_kernel(RdfArgs a)
     }
 }
 
+// ------------------------------------------------------------------ triclinic cells
+//
+// Contract (restating MDAnalysis' brute-force triclinic path):
+// both sets are moved into the central cell (c, then b, then a axis; double arithmetic on the
+// float32 coordinates, result stored as float32), dx = (double)(float)(x_j - x_i), and the
+// squared distance is the strictly smallest of the 27 images dx + ix a + iy b + iz c scanned in
+// double with ix outermost.  tri: float[frames][9], row-major lower-triangular cell matrix.
+__global__ __launch_bounds__(256) void rdf_tri_pack_kernel(const float *__restrict__ pos,
+                                                           const float *__restrict__ tri,
+                                                           float4 *__restrict__ out, int n,
+                                                           int n_pad, int64_t excl)
+{
+    const int frame = blockIdx.y;
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    if (a >= n_pad)
+        return;
+    float4 v;
+    if (a < n) {
+        const float *p = pos + (int64_t(frame) * n + a) * 3;
+        const float *B = tri + int64_t(frame) * 9;
+        double r[3] = {(double)p[0], (double)p[1], (double)p[2]};
+#pragma unroll
+        for (int k = 2; k >= 0; --k) {
+            const double s = floor(r[k] / (double)B[4 * k]);
+#pragma unroll
+            for (int c = 0; c <= k; ++c)
+                r[c] -= s * (double)B[3 * k + c];
+        }
+        v.x = (float)r[0];
+        v.y = (float)r[1];
+        v.z = (float)r[2];
+        v.w = __int_as_float(excl > 0 ? int(int64_t(a) / excl) : a);
+    } else {
+        v.x = v.y = v.z = __int_as_float(0x7fc00000);
+        v.w = __int_as_float(-1);
+    }
+    out[int64_t(frame) * n_pad + a] = v;
+}
+
+struct TriArgs {
+    const float4 *p1, *p2;
+    const float *tri;
+    const double *thresh;
+    unsigned long long *counts;
+    double t_lo, t_hi;
+    float r0f, inv_wf;
+    int n1p, n2p, nt1, nt2;
+    int n_bins, n_hist, n_rep;
+    int chunk, self, frame0;
+};
+
+template <bool EXCL, bool GH>
+__global__ __launch_bounds__(256) void rdf_tri_tile_kernel(TriArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    float4 *sj = reinterpret_cast<float4 *>(smem_raw);                         // [256]
+    double *sT = reinterpret_cast<double *>(smem_raw + sizeof(float4) * 256);  // [n_bins+1]
+    unsigned *sh = reinterpret_cast<unsigned *>(sT + (a.n_bins + 1));          // [n_hist][n_bins]
+
+    const int tid = threadIdx.x;
+    const int frame = blockIdx.z + a.frame0;
+    const int I = blockIdx.y;
+    int J0 = blockIdx.x * a.chunk;
+    int J1 = min(J0 + a.chunk, a.nt2);
+    if (a.self)
+        J0 = max(J0, I);
+    if (J0 >= J1)
+        return;
+    if (!GH) {
+        for (int b = tid; b <= a.n_bins; b += 256)
+            sT[b] = a.thresh[b];
+        for (int b = tid; b < a.n_hist * a.n_bins; b += 256)
+            sh[b] = 0u;
+    }
+    const float *Bf = a.tri + int64_t(frame) * 9;
+    const double b00 = Bf[0], b10 = Bf[3], b11 = Bf[4], b20 = Bf[6], b21 = Bf[7], b22 = Bf[8];
+    unsigned long long *out =
+        a.counts + int64_t((blockIdx.x + 3 * blockIdx.y + 7 * blockIdx.z) % a.n_rep) * a.n_bins;
+    const double *thr = GH ? a.thresh : sT;
+    HistLds hl{sh + (GH ? 0 : ((tid >> 6) % a.n_hist) * a.n_bins)};
+    HistGlobal hg{out};
+    const float4 pi = a.p1[int64_t(frame) * a.n1p + int64_t(I) * 256 + tid];
+
+    for (int J = J0; J < J1; ++J) {
+        __syncthreads();
+        sj[tid] = a.p2[int64_t(frame) * a.n2p + int64_t(J) * 256 + tid];
+        __syncthreads();
+        const unsigned w = (a.self && J != I) ? 2u : 1u;
+        for (int jj = 0; jj < 256; ++jj) {
+            const float4 pj = sj[jj];
+            const double dx = (double)(pj.x - pi.x), dy = (double)(pj.y - pi.y),
+                         dz = (double)(pj.z - pi.z);
+            double best = 1.0e300;
+#pragma unroll
+            for (int ix = -1; ix < 2; ++ix) {
+                const double rx = dx + b00 * (double)ix;
+#pragma unroll
+                for (int iy = -1; iy < 2; ++iy) {
+                    const double ry0 = rx + b10 * (double)iy;
+                    const double ry1 = dy + b11 * (double)iy;
+#pragma unroll
+                    for (int iz = -1; iz < 2; ++iz) {
+                        const double rz0 = ry0 + b20 * (double)iz;
+                        const double rz1 = ry1 + b21 * (double)iz;
+                        const double rz2 = dz + b22 * (double)iz;
+                        const double dsq = (rz0 * rz0 + rz1 * rz1) + rz2 * rz2;
+                        best = dsq < best ? dsq : best;
+                    }
+                }
+            }
+            // NaN (padding) fails both comparisons
+            bool in = (best >= a.t_lo) && (best < a.t_hi);
+            if (EXCL)
+                in = in && (__float_as_int(pi.w) != __float_as_int(pj.w));
+            if (in) {
+                const int k = rdf_bin_exact(best, thr, a.n_bins, a.r0f, a.inv_wf);
+                if (GH) hg.add(k, w);
+                else hl.add(k, w);
+            }
+        }
+    }
+    __syncthreads();
+    if (!GH) {
+        for (int b = tid; b < a.n_bins; b += 256) {
+            unsigned long long s = 0;
+            for (int h = 0; h < a.n_hist; ++h)
+                s += sh[h * a.n_bins + b];
+            if (s)
+                atomicAdd(out + b, s);
+        }
+    }
+}
+
 __global__ void rdf_reduce_kernel(const unsigned long long *__restrict__ rep, int n_rep, int n_bins,
                                   unsigned long long *__restrict__ total)
 {
@@ -227,7 +360,7 @@ struct mdx_rdf {
     int64_t excl1 = 0, excl2 = 0;
     int algo = MDX_RDF_ALGO_AUTO;
     int n_rep = 32;
-    DeviceBuffer d_thresh, d_counts, d_total, d_pack1, d_pack2, d_misc;
+    DeviceBuffer d_thresh, d_counts, d_total, d_pack1, d_pack2, d_misc, d_tri;
     // host-buffer entry point: double-buffered staging, copy stream, hand-over events
     DeviceBuffer d_stage1[2], d_stage2[2], d_boxes[2], d_index[2];
     StagePipeline pipe;
@@ -381,8 +514,8 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
     return MDX_OK;
 }
 
-static int accumulate_device(mdx_rdf *h, const float *d_pos1, int64_t n1, const float *d_pos2,
-                             int64_t n2, const float *d_boxes, int64_t n_frames)
+static int accumulate_ortho(mdx_rdf *h, const float *d_pos1, int64_t n1, const float *d_pos2,
+                            int64_t n2, const float *d_boxes, int64_t n_frames)
 {
     if (n_frames == 0 || n1 == 0 || n2 == 0)
         return MDX_OK;
@@ -459,14 +592,164 @@ static int accumulate_device(mdx_rdf *h, const float *d_pos1, int64_t n1, const 
     return MDX_OK;
 }
 
+// cell matrix of (lx, ly, lz, alpha, beta, gamma): float64 arithmetic through libm, float32
+// entries, exact zeros for right angles
+static void tri_vectors(const float *box6, float *B)
+{
+    const double lx = box6[0], ly = box6[1], lz = box6[2];
+    const double deg = 3.14159265358979323846 / 180.0;
+    const double ca = box6[3] == 90.0f ? 0.0 : std::cos((double)box6[3] * deg);
+    const double cb = box6[4] == 90.0f ? 0.0 : std::cos((double)box6[4] * deg);
+    const double cg = box6[5] == 90.0f ? 0.0 : std::cos((double)box6[5] * deg);
+    const double sg = box6[5] == 90.0f ? 1.0 : std::sin((double)box6[5] * deg);
+    for (int i = 0; i < 9; ++i)
+        B[i] = 0.0f;
+    B[0] = (float)lx;
+    B[3] = (float)(ly * cg);
+    B[4] = (float)(ly * sg);
+    const double cx = lz * cb;
+    const double cy = lz * (ca - cb * cg) / sg;
+    B[6] = (float)cx;
+    B[7] = (float)cy;
+    B[8] = (float)std::sqrt(lz * lz - cx * cx - cy * cy);
+}
+
+static inline bool box_is_ortho(const float *b) { return b[3] == 90.f && b[4] == 90.f && b[5] == 90.f; }
+
+// Triclinic frames: brute-force tiles, 27-image search in double on every pair.
+static int accumulate_triclinic(mdx_rdf *h, const float *d_pos1, int64_t n1, const float *d_pos2,
+                                int64_t n2, const float *h_boxes, int64_t n_frames)
+{
+    if (n_frames == 0 || n1 == 0 || n2 == 0)
+        return MDX_OK;
+    if (h->reduced_global)
+        return fail(MDX_ERR_STATE, "handle holds all-reduced counts; call mdx_rdf_reset() first");
+    const bool same = (d_pos2 == nullptr || (d_pos2 == d_pos1 && n2 == n1));
+    if (d_pos2 == nullptr) {
+        d_pos2 = d_pos1;
+        n2 = n1;
+    }
+    const bool excl = h->excl1 > 0;
+    const bool self = same && (!excl || h->excl1 == h->excl2);
+    MDX_REQUIRE(n1 < (int64_t(1) << 30) && n2 < (int64_t(1) << 30), "too many particles");
+    std::vector<float> tri(size_t(9) * n_frames);
+    for (int64_t f = 0; f < n_frames; ++f) {
+        const float *b = h_boxes + 6 * f;
+        if (!(b[0] > 0.f && b[1] > 0.f && b[2] > 0.f && b[3] > 0.f && b[3] < 180.f && b[4] > 0.f &&
+              b[4] < 180.f && b[5] > 0.f && b[5] < 180.f))
+            return fail(MDX_ERR_INVALID_VALUE, "frame %lld: invalid cell (%g %g %g %g %g %g)",
+                        (long long)f, b[0], b[1], b[2], b[3], b[4], b[5]);
+        tri_vectors(b, tri.data() + 9 * f);
+        if (!(tri[9 * f + 8] > 0.f) || !(tri[9 * f + 4] > 0.f))
+            return fail(MDX_ERR_INVALID_VALUE, "frame %lld: the cell angles do not span a volume",
+                        (long long)f);
+    }
+    const int64_t n1p = ceil_div(n1, 256) * 256, n2p = ceil_div(n2, 256) * 256;
+    int64_t slab = std::max<int64_t>(1, (int64_t(1) << 30) / (int64_t(16) * (n1p + (self ? 0 : n2p))));
+    slab = std::min<int64_t>(std::min<int64_t>(slab, 32768), n_frames);
+    MDX_TRY(h->d_pack1.ensure(size_t(16) * n1p * slab));
+    if (!self)
+        MDX_TRY(h->d_pack2.ensure(size_t(16) * n2p * slab));
+    // the previous call's kernels may still read the cell matrices
+    MDX_HIP(hipStreamSynchronize(h->stream));
+    MDX_TRY(h->d_tri.ensure(size_t(36) * n_frames));
+    MDX_HIP(hipMemcpyAsync(h->d_tri.ptr, tri.data(), size_t(36) * n_frames, hipMemcpyHostToDevice,
+                           h->stream));
+    MDX_HIP(hipStreamSynchronize(h->stream));   // `tri` leaves scope
+
+    size_t base = sizeof(float4) * 256 + sizeof(double) * (h->n_bins + 1);
+    int n_hist = 4;
+    while (n_hist > 1 && base + size_t(n_hist) * h->n_bins * 4 > size_t(64) * 1024)
+        n_hist >>= 1;
+    size_t lds = base + size_t(n_hist) * h->n_bins * 4;
+    const bool gh = lds > size_t(64) * 1024;
+    if (gh)
+        lds = sizeof(float4) * 256;
+    void (*kern)(TriArgs) = excl ? (gh ? rdf_tri_tile_kernel<true, true> : rdf_tri_tile_kernel<true, false>)
+                                 : (gh ? rdf_tri_tile_kernel<false, true> : rdf_tri_tile_kernel<false, false>);
+    if (lds > 48 * 1024)
+        MDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const double width = (h->edges.back() - h->edges.front()) / h->n_bins;
+    for (int64_t f0 = 0; f0 < n_frames; f0 += slab) {
+        const int64_t nf = std::min(slab, n_frames - f0);
+        const float *d_tri = h->d_tri.as<float>() + f0 * 9;
+        hipLaunchKernelGGL(rdf_tri_pack_kernel, dim3((unsigned)(n1p / 256), (unsigned)nf), dim3(256),
+                           0, h->stream, d_pos1 + f0 * n1 * 3, d_tri, h->d_pack1.as<float4>(),
+                           (int)n1, (int)n1p, excl ? h->excl1 : 0);
+        if (!self)
+            hipLaunchKernelGGL(rdf_tri_pack_kernel, dim3((unsigned)(n2p / 256), (unsigned)nf),
+                               dim3(256), 0, h->stream, d_pos2 + f0 * n2 * 3, d_tri,
+                               h->d_pack2.as<float4>(), (int)n2, (int)n2p, excl ? h->excl2 : 0);
+        TriArgs a{};
+        a.p1 = h->d_pack1.as<float4>();
+        a.p2 = self ? a.p1 : h->d_pack2.as<float4>();
+        a.tri = d_tri;
+        a.thresh = h->d_thresh.as<double>();
+        a.counts = h->d_counts.as<unsigned long long>();
+        a.t_lo = h->t_lo;
+        a.t_hi = h->t_hi;
+        a.r0f = (float)h->edges.front();
+        a.inv_wf = (float)(1.0 / width);
+        a.n1p = (int)n1p;
+        a.n2p = (int)n2p;
+        a.nt1 = (int)(n1p / 256);
+        a.nt2 = (int)(n2p / 256);
+        a.n_bins = h->n_bins;
+        a.n_hist = n_hist;
+        a.n_rep = h->n_rep;
+        a.chunk = self ? 4 : 8;
+        a.self = self ? 1 : 0;
+        a.frame0 = 0;
+        hipEvent_t ev = h->timer.begin();
+        dim3 grid((unsigned)ceil_div(a.nt2, a.chunk), (unsigned)a.nt1, (unsigned)nf);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, h->stream, a);
+        h->timer.end(ev);
+        MDX_HIP(hipGetLastError());
+        const int64_t tile_pairs = self ? int64_t(a.nt1) * (a.nt1 + 1) / 2 : int64_t(a.nt1) * a.nt2;
+        h->pairs_bruteforce += nf * tile_pairs * 256 * 256;
+    }
+    h->pairs_evaluated += n_frames * n1 * n2;
+    return MDX_OK;
+}
+
+// Frames are dispatched by cell type: orthorhombic runs take the filter / cell-sorted kernels,
+// triclinic runs the 27-image kernel.  h_boxes: the same boxes on the host, or nullptr (then
+// they are copied back from d_boxes — 24 bytes per frame and one stream synchronisation).
+static int accumulate_device(mdx_rdf *h, const float *d_pos1, int64_t n1, const float *d_pos2,
+                             int64_t n2, const float *d_boxes, const float *h_boxes,
+                             int64_t n_frames)
+{
+    if (!d_boxes || n_frames == 0)
+        return accumulate_ortho(h, d_pos1, n1, d_pos2, n2, d_boxes, n_frames);
+    std::vector<float> copy;
+    if (!h_boxes) {
+        copy.resize(size_t(6) * n_frames);
+        MDX_HIP(hipMemcpyAsync(copy.data(), d_boxes, size_t(24) * n_frames, hipMemcpyDeviceToHost,
+                               h->stream));
+        MDX_HIP(hipStreamSynchronize(h->stream));
+        h_boxes = copy.data();
+    }
+    for (int64_t f0 = 0; f0 < n_frames;) {
+        const bool ortho = box_is_ortho(h_boxes + 6 * f0);
+        int64_t f1 = f0 + 1;
+        while (f1 < n_frames && box_is_ortho(h_boxes + 6 * f1) == ortho)
+            ++f1;
+        const float *p1 = d_pos1 + f0 * n1 * 3;
+        const float *p2 = d_pos2 ? d_pos2 + f0 * n2 * 3 : nullptr;
+        if (ortho)
+            MDX_TRY(accumulate_ortho(h, p1, n1, p2, n2, d_boxes + f0 * 6, f1 - f0));
+        else
+            MDX_TRY(accumulate_triclinic(h, p1, n1, p2, n2, h_boxes + 6 * f0, f1 - f0));
+        f0 = f1;
+    }
+    return MDX_OK;
+}
+
 static int check_host_boxes(const float *boxes, int64_t n_frames)
 {
     for (int64_t f = 0; boxes && f < n_frames; ++f) {
         const float *b = boxes + 6 * f;
-        if (!(b[3] == 90.f && b[4] == 90.f && b[5] == 90.f))
-            return fail(MDX_ERR_UNSUPPORTED,
-                        "frame %lld: only orthorhombic boxes are supported "
-                        "(angles %.4g %.4g %.4g)", (long long)f, b[3], b[4], b[5]);
         MDX_REQUIRE(b[0] > 0.f && b[1] > 0.f && b[2] > 0.f,
                     "frame %lld: box lengths must be positive", (long long)f);
     }
@@ -496,10 +779,11 @@ static int accumulate_pipelined(mdx_rdf *h, int64_t n1, int64_t n2, bool same, c
             }
             return MDX_OK;
         },
-        [&](int b, int64_t, int64_t nf) -> int {
+        [&](int b, int64_t f0, int64_t nf) -> int {
             return accumulate_device(h, h->d_stage1[b].as<float>(), n1,
                                      same ? nullptr : h->d_stage2[b].as<float>(), n2,
-                                     boxes ? h->d_boxes[b].as<float>() : nullptr, nf);
+                                     boxes ? h->d_boxes[b].as<float>() : nullptr,
+                                     boxes ? boxes + f0 * 6 : nullptr, nf);
         });
 }
 
@@ -568,7 +852,7 @@ int mdx_rdf_destroy(mdx_rdf_t h)
     h->pipe.destroy();
     for (DeviceBuffer *b : {&h->d_thresh, &h->d_counts, &h->d_total, &h->d_pack1, &h->d_pack2,
                             &h->d_stage1[0], &h->d_stage2[0], &h->d_boxes[0], &h->d_stage1[1],
-                            &h->d_stage2[1], &h->d_boxes[1], &h->d_index[0], &h->d_index[1], &h->d_misc, &h->d_pw1,
+                            &h->d_stage2[1], &h->d_boxes[1], &h->d_index[0], &h->d_index[1], &h->d_tri, &h->d_misc, &h->d_pw1,
                             &h->d_po1, &h->d_bb1, &h->d_pw2, &h->d_po2, &h->d_bb2, &h->d_bb16_1,
                             &h->d_bb16_2})
         b->release();
@@ -600,7 +884,7 @@ int mdx_rdf_accumulate_device(mdx_rdf_t h, const float *d_pos1, int64_t n1, cons
     MDX_REQUIRE(h && d_pos1, "NULL argument");
     MDX_REQUIRE(n1 >= 0 && n2 >= 0 && n_frames >= 0, "negative size");
     MDX_TRY(set_device(h->dev));
-    return accumulate_device(h, d_pos1, n1, d_pos2, n2, d_boxes, n_frames);
+    return accumulate_device(h, d_pos1, n1, d_pos2, n2, d_boxes, nullptr, n_frames);
 }
 
 int mdx_rdf_accumulate(mdx_rdf_t h, const float *pos1, int64_t n1, const float *pos2, int64_t n2,

@@ -19,6 +19,17 @@ from __future__ import annotations
 import numpy as np
 
 
+def box_volumes(boxes) -> np.ndarray:
+    """float64 volumes of cells given as rows (lx, ly, lz, alpha, beta, gamma)."""
+    b = np.atleast_2d(np.asarray(boxes, dtype=np.float64))
+    vol = b[:, 0] * b[:, 1] * b[:, 2]
+    tri = ~np.all(b[:, 3:] == 90.0, axis=1)
+    if tri.any():
+        ca, cb, cg = (np.cos(np.radians(b[tri, k])) for k in (3, 4, 5))
+        vol[tri] *= np.sqrt(np.maximum(0.0, 1 - ca * ca - cb * cb - cg * cg + 2 * ca * cb * cg))
+    return vol
+
+
 class Timestep:
     def __init__(self, trajectory, frame: int):
         self._trajectory = trajectory

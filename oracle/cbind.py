@@ -54,8 +54,6 @@ def c_radial_histogram(pos1, pos2, n_bins, range, dims, *, exclusion=None, n_thr
         p1.ctypes.data, p1.shape[0], p2.ctypes.data, p2.shape[0],
         None if box is None else box.ctypes.data, edges.ctypes.data, int(n_bins),
         float(range[0]), float(range[1]), e0, e1, counts.ctypes.data, int(n_threads))
-    if rc == -2:
-        raise NotImplementedError("Only orthorhombic boxes are supported.")
     if rc != 0:
         raise RuntimeError(f"rdf_oracle_histogram failed ({rc})")
     return counts

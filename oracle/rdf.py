@@ -34,15 +34,78 @@ def _c_round(s: np.ndarray) -> np.ndarray:
 
 
 def check_box(dims):
-    """float32 box[6] as MDAnalysis stores it; orthorhombic only."""
+    """float32 box[6] as MDAnalysis stores it."""
     if dims is None:
         return None
     box = np.asarray(dims, dtype=np.float32).reshape(-1)
     if box.shape[0] != 6:
         raise ValueError("dims must have six entries (lx, ly, lz, alpha, beta, gamma).")
-    if not np.all(box[3:] == 90.0):
-        raise NotImplementedError("Only orthorhombic boxes are supported.")
     return box
+
+
+def is_triclinic(box) -> bool:
+    return box is not None and not np.all(box[3:] == 90.0)
+
+
+def triclinic_vectors(box) -> np.ndarray:
+    """
+    float32[3, 3] cell matrix (rows a, b, c; lower triangular) of (lx, ly, lz, alpha, beta, gamma),
+    restating ``MDAnalysis.lib.mdamath.triclinic_vectors`` (third party, absent; float64
+    arithmetic through libm, entries stored as float32, exact zeros for right angles).
+    """
+    import math
+    lx, ly, lz = (float(x) for x in box[:3])
+    ca = 0.0 if box[3] == 90.0 else math.cos(math.radians(1.0) * float(box[3]))
+    cb = 0.0 if box[4] == 90.0 else math.cos(math.radians(1.0) * float(box[4]))
+    cg = 0.0 if box[5] == 90.0 else math.cos(math.radians(1.0) * float(box[5]))
+    sg = 1.0 if box[5] == 90.0 else math.sin(math.radians(1.0) * float(box[5]))
+    B = np.zeros((3, 3), dtype=np.float32)
+    B[0, 0] = lx
+    B[1, 0] = ly * cg
+    B[1, 1] = ly * sg
+    cx = lz * cb
+    cy = lz * (ca - cb * cg) / sg
+    B[2, 0] = cx
+    B[2, 1] = cy
+    B[2, 2] = math.sqrt(lz * lz - cx * cx - cy * cy)
+    return B
+
+
+def triclinic_wrap(pos, B) -> np.ndarray:
+    """Coordinates moved into the central cell, c then b then a axis, in double; float32 out."""
+    r = np.asarray(pos, dtype=np.float32).reshape(-1, 3).astype(np.float64)
+    Bd = B.astype(np.float64)
+    for k in (2, 1, 0):
+        s = np.floor(r[:, k] / Bd[k, k])
+        for c in range(k + 1):
+            r[:, c] -= s * Bd[k, c]
+    return r.astype(np.float32)
+
+
+def pair_distances_triclinic(pos1, pos2, B) -> np.ndarray:
+    """
+    Minimum over the 27 neighbouring images of the float32 difference of WRAPPED coordinates
+    (``MDAnalysis/lib/src/calc_distances.h``: ``minimum_image_triclinic``; published algorithm
+    restated — parity unpinned): ix outermost, first strictly smaller squared length wins,
+    ``rsq = (x*x + y*y) + z*z`` in double.
+    """
+    ref = np.ascontiguousarray(pos1, dtype=np.float32).reshape(-1, 3)
+    conf = np.ascontiguousarray(pos2, dtype=np.float32).reshape(-1, 3)
+    dx = (conf[None, :, :] - ref[:, None, :]).astype(np.float64)
+    Bd = B.astype(np.float64)
+    best = np.full(dx.shape[:2], 1.0e300)
+    for ix in (-1, 0, 1):
+        rx = dx[..., 0] + Bd[0, 0] * ix
+        for iy in (-1, 0, 1):
+            ry0 = rx + Bd[1, 0] * iy
+            ry1 = dx[..., 1] + Bd[1, 1] * iy
+            for iz in (-1, 0, 1):
+                rz0 = ry0 + Bd[2, 0] * iz
+                rz1 = ry1 + Bd[2, 1] * iz
+                rz2 = dx[..., 2] + Bd[2, 2] * iz
+                dsq = (rz0 * rz0 + rz1 * rz1) + rz2 * rz2
+                best = np.where(dsq < best, dsq, best)
+    return np.sqrt(best)
 
 
 def pair_distances(pos1: np.ndarray, pos2: np.ndarray, box) -> np.ndarray:
@@ -84,6 +147,10 @@ def radial_histogram_ref(pos1, pos2, n_bins, range, dims, *, exclusion=None,
     box = check_box(dims)
     ref = np.ascontiguousarray(pos1, dtype=np.float32).reshape(-1, 3)
     conf = np.ascontiguousarray(pos2, dtype=np.float32).reshape(-1, 3)
+    tri = is_triclinic(box)
+    if tri:
+        B = triclinic_vectors(box)
+        ref, conf = triclinic_wrap(ref, B), triclinic_wrap(conf, B)
     n1, n2 = ref.shape[0], conf.shape[0]
     counts = np.zeros(n_bins, dtype=np.int64)
     if n1 == 0 or n2 == 0:
@@ -94,7 +161,8 @@ def radial_histogram_ref(pos1, pos2, n_bins, range, dims, *, exclusion=None,
     j_idx = np.arange(n2)
     for lo in np.arange(0, n1, rows):
         hi = min(n1, lo + rows)
-        d = pair_distances(ref[lo:hi], conf, box)
+        d = (pair_distances_triclinic(ref[lo:hi], conf, B) if tri
+             else pair_distances(ref[lo:hi], conf, box))
         keep = (d <= max_cut) & (d > min_cut)
         if exclusion is not None:
             i_idx = np.arange(lo, hi)

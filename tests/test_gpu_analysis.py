@@ -98,8 +98,9 @@ def test_radial_histogram_function():
     got = structure.radial_histogram(origin, neighbors, n_bins=half_L, range=(0, half_L + 1), dims=dims)
     want = orf.radial_histogram_ref(origin, neighbors, half_L, (0, half_L + 1), dims)
     assert np.array_equal(got, want)
-    with pytest.raises(NotImplementedError):
-        structure.radial_histogram(origin, neighbors, 4, (0, 5), [20, 20, 20, 90, 60, 90])
+    tri = [20, 20, 20, 90, 60, 90]
+    assert np.array_equal(structure.radial_histogram(origin, neighbors, 4, (0, 5), tri),
+                          orf.radial_histogram_ref(origin, neighbors, 4, (0, 5), tri))
 
 
 @pytest.mark.parametrize("mode", [None, "pair", "partial"])

@@ -174,11 +174,13 @@ def test_rdf_reference_test_geometry():
     assert np.array_equal(got, want) and got.sum() == 1000
 
 
-def test_rdf_triclinic_rejected_and_empty():
+def test_rdf_bad_cell_rejected_and_empty():
     pos = np.zeros((4, 3), dtype=np.float32)
     eng = _core.RdfEngine(_edges(4, (0, 1)))
-    with pytest.raises(NotImplementedError):
-        eng.accumulate(pos, None, np.array([10, 10, 10, 90, 80, 90], dtype=np.float32))
+    with pytest.raises(ValueError):      # angles that span no volume
+        eng.accumulate(pos, None, np.array([10, 10, 10, 30, 30, 170], dtype=np.float32))
+    with pytest.raises(ValueError):
+        eng.accumulate(pos, None, np.array([10, -1, 10, 90, 90, 90], dtype=np.float32))
     eng.accumulate(np.zeros((0, 3), dtype=np.float32).reshape(1, 0, 3), None, None)
     assert eng.counts().sum() == 0
     eng.close()
@@ -440,3 +442,48 @@ def test_rdf_cell_regression_pair_at_top_of_candidate_window():
     for _ in range(10):
         got = _gpu_hist(pos, None, 150, (0.0, 12.0), dims, (1, 1), "cell")
         assert np.array_equal(got, want)
+
+
+TRICLINIC = [(31.0, 28.5, 35.25, 75.0, 80.0, 110.0), (25.0, 25.0, 25.0, 60.0, 60.0, 90.0),
+             (40.0, 22.0, 30.0, 90.0, 90.0, 120.0), (18.0, 30.0, 27.0, 101.5, 90.0, 67.25)]
+
+
+@pytest.mark.parametrize("cell", TRICLINIC)
+@pytest.mark.parametrize("exclusion", [None, (1, 1), (3, 3)])
+def test_rdf_triclinic_cells(cell, exclusion):
+    """Non-orthogonal cells: 27-image search on wrapped coordinates, bit-exact vs the C oracle."""
+    rng = np.random.default_rng(44)
+    dims = np.array(cell, dtype=np.float32)
+    B = orf.triclinic_vectors(dims).astype(np.float64)
+    pos = (rng.random((1100, 3)) @ B + rng.normal(0, 25.0, (1100, 3))).astype(np.float32)   # far outside the cell too
+    for rng_range, nb in [((0.0, 9.0), 120), ((1.5, 8.0), 33)]:
+        want = c_radial_histogram(pos, pos, nb, rng_range, dims, exclusion=exclusion)
+        got = _gpu_hist(pos, None, nb, rng_range, dims, exclusion, "auto")
+        assert np.array_equal(got, want), (cell, rng_range)
+        assert want.sum() > 10000
+    other = (rng.random((700, 3)) @ B).astype(np.float32)
+    want = c_radial_histogram(pos, other, 64, (0.0, 7.0), dims)
+    assert np.array_equal(_gpu_hist(pos, other, 64, (0.0, 7.0), dims, None, "cell"), want)
+
+
+def test_rdf_mixed_orthorhombic_and_triclinic_frames_in_one_batch():
+    rng = np.random.default_rng(45)
+    F, N = 9, 1300
+    boxes = np.array([[30, 30, 30, 90, 90, 90]] * 3 + [[30, 31, 29, 80, 95, 105]] * 2
+                     + [[30, 30, 30, 90, 90, 90]] + [[28, 30, 33, 90, 70, 90]] * 3, dtype=np.float32)
+    pos = (rng.random((F, N, 3)) * 30.0).astype(np.float32)
+    want = np.zeros(150, dtype=np.int64)
+    for f in range(F):
+        want += c_radial_histogram(pos[f], pos[f], 150, (0.0, 10.0), boxes[f], exclusion=(1, 1))
+    for algo in ("auto", "filter"):
+        eng = _core.RdfEngine(_edges(150, (0.0, 10.0)), (1, 1), algo=algo)
+        eng.accumulate(pos, None, boxes)
+        assert np.array_equal(eng.counts(), want), algo
+        # device-resident entry point: the boxes are inspected after a copy back
+        eng.reset()
+        d_pos = _core.DeviceArray.from_host(pos)
+        d_box = _core.DeviceArray.from_host(boxes)
+        eng.accumulate_device(d_pos.ptr, N, None, N, d_box.ptr, F)
+        assert np.array_equal(eng.counts(), want), algo
+        d_pos.free(); d_box.free()
+        eng.close()

@@ -83,10 +83,33 @@ def test_self_pairs_and_exclusion_semantics():
     assert h[9] == 2 and h.sum() == 4
 
 
-def test_triclinic_rejected():
-    pos = np.zeros((2, 3), dtype=np.float32)
-    with pytest.raises(NotImplementedError):
-        orf.radial_histogram_ref(pos, pos, 4, (0, 1), [10, 10, 10, 90, 80, 90])
+def test_triclinic_contract_numpy_vs_c_and_true_minimum_image():
+    from oracle.cbind import c_radial_histogram
+    rng = np.random.default_rng(21)
+    for dims in ([20, 22, 25, 75, 80, 110], [18, 18, 18, 60, 60, 90], [30, 20, 25, 90, 90, 120]):
+        dims = np.array(dims, dtype=np.float32)
+        B = orf.triclinic_vectors(dims).astype(np.float64)
+        pos = (rng.random((400, 3)) @ B + rng.normal(0, 30, (400, 3))).astype(np.float32)
+        a = orf.radial_histogram_ref(pos, pos, 40, (0.0, 8.0), dims, exclusion=(1, 1))
+        b = c_radial_histogram(pos, pos, 40, (0.0, 8.0), dims, exclusion=(1, 1))
+        assert np.array_equal(a, b)
+        # physics: the true minimum image from a wide lattice search agrees up to edge rounding
+        frac = np.linalg.solve(B.T, pos.astype(np.float64).T).T
+        d = frac[None] - frac[:, None]
+        d -= np.rint(d)
+        best = np.full(d.shape[:2], np.inf)
+        for i in range(-2, 3):
+            for j in range(-2, 3):
+                for k in range(-2, 3):
+                    v = (d + np.array([i, j, k])) @ B
+                    best = np.minimum(best, (v * v).sum(-1))
+        dd = np.sqrt(best)
+        np.fill_diagonal(dd, np.inf)
+        h = np.histogram(dd[dd <= 8.0], 40, (0.0, 8.0))[0]
+        assert np.abs(h - a).max() <= 4 and abs(int(h.sum()) - int(a.sum())) <= 4
+    # right angles give exact zeros in the cell matrix
+    B = orf.triclinic_vectors(np.array([10, 11, 12, 90, 90, 120], dtype=np.float32))
+    assert B[2, 0] == 0 and B[2, 1] == 0 and B[1, 0] == np.float32(11 * np.cos(np.radians(120.0)))
 
 
 def test_ideal_gas_rdf_is_one():
