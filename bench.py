@@ -374,10 +374,14 @@ def bench_msd(args, world):
         "n_gpus": world.world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"C4 self-MSD {N} atoms x {T} frames, 2 groups, rocFFT n_fft={eng.n_fft}"},
+        "config": {"workload": f"C4 self-MSD {N} atoms x {T} frames, 2 groups, n_fft={eng.n_fft}"
+                               + (" (own two-pass transform)" if eng.n_fft == 262144
+                                  and not os.environ.get("MDX_MSD_ROCFFT") else " (rocFFT)")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "msd pipeline (gather + rocFFT R2C + power) of the last step",
+                     "kernel": "msd pipeline of one step: sums + forward transforms + power "
+                               "(msd_fft_cols/rows_power kernels for n_fft = 2^18, else gather + "
+                               "rocFFT R2C + power)",
                      "pipeline_bytes_model": st["bytes_moved"]},
         "physics_check_msd_over_3sigma2m": float(msd[10] / (3 * 0.01 * 10)),
     }

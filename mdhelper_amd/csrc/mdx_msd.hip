@@ -22,6 +22,7 @@
 #include "mdx_common.hpp"
 #include "mdx_internal.hpp"
 #include "mdx_traj.hpp"
+#include "mdx_msd_fft.hpp"
 
 #include <rocfft/rocfft.h>
 
@@ -285,6 +286,8 @@ struct mdx_msd {
     // accumulators: power [G][B][nc] + D [G][B*T_b] contiguous (one all-reduce), traj [G][B*T_b][3]
     DeviceBuffer d_acc, d_traj, d_series, d_spec, d_stage, d_inv_in, d_inv_out;
     DeviceBuffer d_f32, d_index, d_prev, d_image;   // trajectory-file path: frames, unwrap state
+    bool own_fft = false;                           // n_fft = 2^18: mdx_msd_fft.hpp instead of rocFFT
+    DeviceBuffer d_tw, d_pfull;                     // twiddle tables [2][512], full-spectrum sums [B][N]
     StreamTimer timer;
     int64_t bytes_moved = 0;
     double *power(int g) { return d_acc.as<double>() + int64_t(g) * n_blocks * nc; }
@@ -307,23 +310,46 @@ static int msd_push_device(mdx_msd *h, int group, const double *d_pos, int64_t n
     size_t free_b = 0, total_b = 0;
     MDX_HIP(hipMemGetInfo(&free_b, &total_b));
     free_b += h->d_series.bytes + h->d_spec.bytes;
-    const int64_t per_atom = 3 * B * (h->n_fft * 8 + h->nc * 16);
+    const int64_t per_atom = h->own_fft ? 3 * B * h->n_fft * 8   // Y: one complex per two reals
+                                        : 3 * B * (h->n_fft * 8 + h->nc * 16);
     int64_t chunk = std::max<int64_t>(1, int64_t(double(free_b) * 0.4) / per_atom);
     chunk = std::min<int64_t>(chunk, count);
     // a handful of equal chunks keeps the rocFFT plan cache small
     const int64_t n_chunks = ceil_div(count, chunk);
     chunk = ceil_div(count, n_chunks);
-    MDX_TRY(h->d_series.ensure(size_t(chunk) * 3 * B * h->n_fft * 8));
-    MDX_TRY(h->d_spec.ensure(size_t(chunk) * 3 * B * h->nc * 16));
+    if (h->own_fft) {
+        const int64_t p_pad_max = ceil_div(ceil_div(chunk * 3, 2), msdfft::PG) * msdfft::PG;
+        MDX_TRY(h->d_spec.ensure(size_t(B) * msdfft::N * p_pad_max * 16));
+    } else {
+        MDX_TRY(h->d_series.ensure(size_t(chunk) * 3 * B * h->n_fft * 8));
+        MDX_TRY(h->d_spec.ensure(size_t(chunk) * 3 * B * h->nc * 16));
+    }
     hipEvent_t ev = h->timer.begin();
     for (int64_t a0 = 0; a0 < count; a0 += chunk) {
         const int64_t c = std::min(chunk, count - a0);
         const int64_t n_elem = c * 3;
+        hipLaunchKernelGGL(msd_sums_kernel, dim3((unsigned)(B * h->t_block)), dim3(192), 0, h->stream,
+                           d_pos, n_total, first + a0, c, zero_dims, h->traj(group), h->dsq(group));
+        if (h->own_fft) {
+            const int p_pad = (int)(ceil_div(ceil_div(n_elem, 2), msdfft::PG) * msdfft::PG);
+            const double2 *tw512 = h->d_tw.as<double2>(), *twN = tw512 + msdfft::R;
+            hipLaunchKernelGGL(msdfft::msd_fft_cols_kernel,
+                               dim3((unsigned)(p_pad / msdfft::PG), msdfft::COLS_SPLIT, (unsigned)B),
+                               dim3(msdfft::THREADS), 0, h->stream, d_pos, n_total, first + a0, n_elem,
+                               h->t_block, zero_dims, p_pad, tw512, twN, h->d_spec.as<double2>());
+            hipLaunchKernelGGL(msdfft::msd_fft_rows_power_kernel, dim3(msdfft::R, (unsigned)B),
+                               dim3(msdfft::THREADS), 0, h->stream, h->d_spec.as<double2>(), p_pad,
+                               tw512, h->d_pfull.as<double>());
+            hipLaunchKernelGGL(msdfft::msd_power_fold_kernel,
+                               dim3((unsigned)ceil_div(h->nc, 256), (unsigned)B), dim3(256), 0,
+                               h->stream, h->d_pfull.as<double>(), h->nc, h->power(group));
+            // positions read twice (sums, pass A), Y written and read once
+            h->bytes_moved += c * 3 * B * (2 * h->t_block * 8 + 2 * h->n_fft * 8);
+            continue;
+        }
         dim3 g1((unsigned)ceil_div(h->n_fft, GT), (unsigned)ceil_div(n_elem, GT), (unsigned)B);
         hipLaunchKernelGGL(msd_gather_kernel, g1, dim3(256), 0, h->stream, d_pos, n_total,
                            first + a0, c, h->t_block, h->n_fft, zero_dims, h->d_series.as<double>());
-        hipLaunchKernelGGL(msd_sums_kernel, dim3((unsigned)(B * h->t_block)), dim3(192), 0, h->stream,
-                           d_pos, n_total, first + a0, c, zero_dims, h->traj(group), h->dsq(group));
         MDX_TRY(h->fft.exec(0, n_elem * B, h->d_series.ptr, h->d_spec.ptr, h->stream));
         hipLaunchKernelGGL(msd_power_kernel, dim3((unsigned)ceil_div(h->nc, 256), (unsigned)B),
                            dim3(256), 0, h->stream, h->d_spec.as<double2>(), n_elem, h->nc,
@@ -447,7 +473,10 @@ int mdx_msd_create(mdx_msd_t *out, int dev, int64_t n_frames_block, int n_blocks
         const char *mode = getenv("MDX_MSD_NFFT");
         const bool force_ref = mode && !strcmp(mode, "ref");
         const bool force_pow2 = mode && !strcmp(mode, "pow2");
-        if (force_pow2 || (!force_ref && 2 * p <= 3 * h->n_fft))
+        // ... and always when it is 2^18, the length of the engine's own two-pass transform
+        // (mdx_msd_fft.hpp), which never materialises the padding
+        const bool own = p == msdfft::N && !getenv("MDX_MSD_ROCFFT");
+        if (force_pow2 || (!force_ref && (own || 2 * p <= 3 * h->n_fft)))
             h->n_fft = p;
     }
     h->nc = h->n_fft / 2 + 1;
@@ -461,6 +490,25 @@ int mdx_msd_create(mdx_msd_t *out, int dev, int64_t n_frames_block, int n_blocks
         h->timer.stream = h->stream;
         if ((rc = h->d_acc.ensure(size_t(8) * h->acc_len())) != MDX_OK) break;
         if ((rc = h->d_traj.ensure(size_t(8) * h->traj_len())) != MDX_OK) break;
+        // forward transforms of length 2^18 run through the engine's own two-pass kernels
+        // (MDX_MSD_ROCFFT=1 keeps rocFFT for them too)
+        h->own_fft = h->n_fft == msdfft::N && !getenv("MDX_MSD_ROCFFT");
+        if (h->own_fft) {
+            std::vector<double> tw(size_t(4) * msdfft::R);
+            const double two_pi = 6.283185307179586476925286766559;
+            for (int m = 0; m < msdfft::R; ++m) {
+                tw[2 * m] = std::cos(two_pi * m / msdfft::R);
+                tw[2 * m + 1] = -std::sin(two_pi * m / msdfft::R);
+                tw[2 * (msdfft::R + m)] = std::cos(two_pi * m / msdfft::N);
+                tw[2 * (msdfft::R + m) + 1] = -std::sin(two_pi * m / msdfft::N);
+            }
+            if ((rc = h->d_tw.ensure(tw.size() * 8)) != MDX_OK) break;
+            if (hipMemcpy(h->d_tw.ptr, tw.data(), tw.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
+                rc = fail(MDX_ERR_HIP, "twiddle table upload failed");
+                break;
+            }
+            if ((rc = h->d_pfull.ensure(size_t(8) * n_blocks * msdfft::N)) != MDX_OK) break;
+        }
     } while (0);
     if (rc != MDX_OK) {
         mdx_msd_destroy(h);
@@ -481,7 +529,7 @@ int mdx_msd_destroy(mdx_msd_t h)
     h->fft.destroy();
     for (DeviceBuffer *b : {&h->d_acc, &h->d_traj, &h->d_series, &h->d_spec, &h->d_stage,
                             &h->d_inv_in, &h->d_inv_out, &h->d_f32, &h->d_index, &h->d_prev,
-                            &h->d_image})
+                            &h->d_image, &h->d_tw, &h->d_pfull})
         b->release();
     if (h->stream)
         (void)hipStreamDestroy(h->stream);
