@@ -110,6 +110,13 @@ int mdx_rdf_reset(mdx_rdf_t h);
  * bit-identical because the contract arithmetic is exactly antisymmetric. */
 int mdx_rdf_accumulate(mdx_rdf_t h, const float *pos1, int64_t n1, const float *pos2,
                        int64_t n2, const float *boxes, int64_t n_frames);
+/* Centres of mass on the device for groupings="residues"/"segments" (structure.py:753-759 via
+ * algorithm/molecule.py:300-306): the rows of set `which` (1 or 2) handed to any accumulate
+ * call are then PARTICLES, molecule g owning rows [offsets[g], offsets[g+1]); the histogram is
+ * taken over the float32 centres sum_a m_a x_a / M_g.  offsets: int64[n_groups+1], masses:
+ * float64[offsets[n_groups]], both on the host; n_groups <= 0 removes the grouping. */
+int mdx_rdf_set_grouping(mdx_rdf_t h, int which, int64_t n_groups, const int64_t *offsets,
+                         const double *masses);
 /* Same, all pointers in HBM (from mdx_malloc); asynchronous on the handle's stream. */
 int mdx_rdf_accumulate_device(mdx_rdf_t h, const float *d_pos1, int64_t n1,
                               const float *d_pos2, int64_t n2, const float *d_boxes,

@@ -191,6 +191,18 @@ class RdfEngine(_Engine):
     def accumulate_device(self, d_pos1, n1, d_pos2, n2, d_boxes, n_frames):
         check(lib().mdx_rdf_accumulate_device(self.handle, d_pos1, n1, d_pos2, n2, d_boxes, n_frames))
 
+    def set_grouping(self, which, offsets, masses):
+        """Rows of set ``which`` (1 or 2) become particles of molecules ``[offsets[g], offsets[g+1])``
+        whose centres of mass are binned; ``offsets=None`` removes the grouping."""
+        if offsets is None:
+            check(lib().mdx_rdf_set_grouping(self.handle, which, 0, None, None))
+            return
+        o = np.ascontiguousarray(offsets, dtype=np.int64)
+        m = np.ascontiguousarray(masses, dtype=np.float64)
+        if len(m) != o[-1]:
+            raise ValueError("masses must hold one entry per particle of the grouping.")
+        check(lib().mdx_rdf_set_grouping(self.handle, which, len(o) - 1, _ptr(o), _ptr(m)))
+
     def accumulate_traj(self, traj_file, frames, boxes, index1=None, index2=None, same=True):
         """Frames of a native trajectory file (``io.TrajectoryFile``); ``index``: particle
         selections (None = all particles), ``same``: one group against itself."""

@@ -291,12 +291,24 @@ class RadialDistributionFunction(DynamicAnalysisBase):
                                * self.n_frames / self._area_or_volume)
         self.results.rdf = self.results.counts / norm
 
-    # batched fast path for in-memory trajectories: frames go to the engine in
-    # contiguous blocks instead of one Python iteration per frame
+    # batched fast path for in-memory and file trajectories: frames go to the engine in
+    # contiguous blocks instead of one Python iteration per frame; residue / segment centres
+    # of mass are formed on the device (mdx_rdf_set_grouping)
+    @staticmethod
+    def _selection(ag, grouping):
+        """(particle indices, CSR offsets or None, masses or None) of one side of the histogram."""
+        idx = np.asarray(ag.indices)
+        if grouping == "atoms":
+            return idx, None, None
+        from ..algorithm.molecule import _level_ids
+        _, inverse = np.unique(_level_ids(ag, grouping), return_inverse=True)
+        order = np.argsort(inverse, kind="stable")        # molecule by molecule, atom order kept
+        offsets = np.concatenate(([0], np.cumsum(np.bincount(inverse))))
+        return idx[order], offsets, np.asarray(ag.masses, dtype=np.float64)[order]
+
     def run(self, start=None, stop=None, step=None, frames=None, verbose=None, **kwargs):
         traj = self._trajectory
-        fast = (_is_array_trajectory(traj) and self._groupings == ["atoms", "atoms"]
-                and self._drop_axis is None)
+        fast = _is_array_trajectory(traj) and self._drop_axis is None
         if not fast:
             return super().run(start=start, stop=stop, step=step, frames=frames, verbose=verbose,
                                **kwargs)
@@ -308,7 +320,12 @@ class RadialDistributionFunction(DynamicAnalysisBase):
         lo, hi = self._frames_mine
         mine = numbers[lo:hi]
         block = self._batch.capacity
-        i1, i2 = self.ag1.indices, self.ag2.indices
+        i1, off1, m1 = self._selection(self.ag1, self._groupings[0])
+        i2, off2, m2 = (i1, off1, m1) if self._same else self._selection(self.ag2, self._groupings[1])
+        if off1 is not None:
+            self._engine.set_grouping(1, off1, m1)
+        if off2 is not None and not self._same:
+            self._engine.set_grouping(2, off2, m2)
         all1 = len(i1) == traj.n_atoms and np.array_equal(i1, np.arange(len(i1)))
         native = getattr(traj, "native", None)
         if native is not None:

@@ -336,6 +336,30 @@ __global__ __launch_bounds__(256) void rdf_tri_tile_kernel(TriArgs a)
     }
 }
 
+// Centres of mass on the device: out[frame][g][k] = (float)(sum_a m_a x_a / M_g)
+// over the particles a in [offsets[g], offsets[g+1]) of the incoming order, accumulated in
+// double in that order with separate multiply and add — the operations of the reference's host
+// path (algorithm/molecule.py:300-306 through numpy: weights m * x, sequential sums, one
+// division), so the float32 centres are the ones the reference bins.
+__global__ __launch_bounds__(256) void rdf_com_kernel(const float *__restrict__ pos, int64_t n_atoms,
+                                                      const int64_t *__restrict__ offsets,
+                                                      const double *__restrict__ masses,
+                                                      const double *__restrict__ total_mass,
+                                                      int64_t n_groups, float *__restrict__ out)
+{
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;   // (group, k)
+    const int64_t frame = blockIdx.y;
+    if (i >= n_groups * 3)
+        return;
+    const int64_t g = i / 3;
+    const int k = int(i - 3 * g);
+    const float *p = pos + frame * n_atoms * 3 + k;
+    double acc = 0.0;
+    for (int64_t a = offsets[g]; a < offsets[g + 1]; ++a)
+        acc = __dadd_rn(acc, __dmul_rn(masses[a], (double)p[3 * a]));
+    out[(frame * n_groups + g) * 3 + k] = (float)(acc / total_mass[g]);
+}
+
 __global__ void rdf_reduce_kernel(const unsigned long long *__restrict__ rep, int n_rep, int n_bins,
                                   unsigned long long *__restrict__ total)
 {
@@ -361,6 +385,11 @@ struct mdx_rdf {
     int algo = MDX_RDF_ALGO_AUTO;
     int n_rep = 32;
     DeviceBuffer d_thresh, d_counts, d_total, d_pack1, d_pack2, d_misc, d_tri;
+    // optional centre-of-mass stage per set: incoming rows are particles grouped into molecules
+    struct Grouping {
+        int64_t n_atoms = 0, n_groups = 0;
+        DeviceBuffer d_offsets, d_masses, d_total, d_com;
+    } grouping[2];
     // host-buffer entry point: double-buffered staging, copy stream, hand-over events
     DeviceBuffer d_stage1[2], d_stage2[2], d_boxes[2], d_index[2];
     StagePipeline pipe;
@@ -716,9 +745,49 @@ static int accumulate_triclinic(mdx_rdf *h, const float *d_pos1, int64_t n1, con
 // Frames are dispatched by cell type: orthorhombic runs take the filter / cell-sorted kernels,
 // triclinic runs the 27-image kernel.  h_boxes: the same boxes on the host, or nullptr (then
 // they are copied back from d_boxes — 24 bytes per frame and one stream synchronisation).
+static int accumulate_device_points(mdx_rdf *h, const float *d_pos1, int64_t n1,
+                                    const float *d_pos2, int64_t n2, const float *d_boxes,
+                                    const float *h_boxes, int64_t n_frames);
+
+// Entry of every accumulate variant: sets with a grouping are reduced to centres of mass first.
 static int accumulate_device(mdx_rdf *h, const float *d_pos1, int64_t n1, const float *d_pos2,
                              int64_t n2, const float *d_boxes, const float *h_boxes,
                              int64_t n_frames)
+{
+    if (!h->grouping[0].n_groups && !h->grouping[1].n_groups)
+        return accumulate_device_points(h, d_pos1, n1, d_pos2, n2, d_boxes, h_boxes, n_frames);
+    if (n_frames == 0)
+        return MDX_OK;
+    const bool same = (d_pos2 == nullptr || (d_pos2 == d_pos1 && n2 == n1));
+    const float *src[2] = {d_pos1, same ? d_pos1 : d_pos2};
+    int64_t n[2] = {n1, same ? n1 : n2};
+    const float *pts[2] = {src[0], src[1]};
+    for (int g = 0; g < (same ? 1 : 2); ++g) {
+        mdx_rdf::Grouping &G = h->grouping[g];
+        if (!G.n_groups)
+            continue;
+        MDX_REQUIRE(n[g] == G.n_atoms, "set %d holds %lld particles, its grouping was defined for %lld",
+                    g + 1, (long long)n[g], (long long)G.n_atoms);
+        MDX_TRY(G.d_com.ensure(size_t(12) * G.n_groups * n_frames));
+        hipLaunchKernelGGL(rdf_com_kernel, dim3((unsigned)ceil_div(G.n_groups * 3, 256), (unsigned)n_frames),
+                           dim3(256), 0, h->stream, src[g], G.n_atoms, G.d_offsets.as<int64_t>(),
+                           G.d_masses.as<double>(), G.d_total.as<double>(), G.n_groups,
+                           G.d_com.as<float>());
+        pts[g] = G.d_com.as<float>();
+        n[g] = G.n_groups;
+    }
+    MDX_HIP(hipGetLastError());
+    if (same) {
+        MDX_REQUIRE(!h->grouping[1].n_groups || h->grouping[0].n_groups,
+                    "a self histogram takes the grouping of set 1");
+        return accumulate_device_points(h, pts[0], n[0], nullptr, n[0], d_boxes, h_boxes, n_frames);
+    }
+    return accumulate_device_points(h, pts[0], n[0], pts[1], n[1], d_boxes, h_boxes, n_frames);
+}
+
+static int accumulate_device_points(mdx_rdf *h, const float *d_pos1, int64_t n1,
+                                    const float *d_pos2, int64_t n2, const float *d_boxes,
+                                    const float *h_boxes, int64_t n_frames)
 {
     if (!d_boxes || n_frames == 0)
         return accumulate_ortho(h, d_pos1, n1, d_pos2, n2, d_boxes, n_frames);
@@ -852,7 +921,10 @@ int mdx_rdf_destroy(mdx_rdf_t h)
     h->pipe.destroy();
     for (DeviceBuffer *b : {&h->d_thresh, &h->d_counts, &h->d_total, &h->d_pack1, &h->d_pack2,
                             &h->d_stage1[0], &h->d_stage2[0], &h->d_boxes[0], &h->d_stage1[1],
-                            &h->d_stage2[1], &h->d_boxes[1], &h->d_index[0], &h->d_index[1], &h->d_tri, &h->d_misc, &h->d_pw1,
+                            &h->d_stage2[1], &h->d_boxes[1], &h->d_index[0], &h->d_index[1], &h->d_tri, &h->grouping[0].d_offsets,
+                            &h->grouping[0].d_masses, &h->grouping[0].d_total, &h->grouping[0].d_com,
+                            &h->grouping[1].d_offsets, &h->grouping[1].d_masses,
+                            &h->grouping[1].d_total, &h->grouping[1].d_com, &h->d_misc, &h->d_pw1,
                             &h->d_po1, &h->d_bb1, &h->d_pw2, &h->d_po2, &h->d_bb2, &h->d_bb16_1,
                             &h->d_bb16_2})
         b->release();
@@ -875,6 +947,41 @@ int mdx_rdf_reset(mdx_rdf_t h)
     h->pairs_evaluated = 0;
     h->pairs_bruteforce = 0;
     h->reduced_global = false;
+    return MDX_OK;
+}
+
+int mdx_rdf_set_grouping(mdx_rdf_t h, int which, int64_t n_groups, const int64_t *offsets,
+                         const double *masses)
+{
+    MDX_REQUIRE(h, "NULL handle");
+    MDX_REQUIRE(which == 1 || which == 2, "which must be 1 or 2");
+    MDX_TRY(set_device(h->dev));
+    MDX_HIP(hipStreamSynchronize(h->stream));
+    mdx_rdf::Grouping &G = h->grouping[which - 1];
+    if (n_groups <= 0) {   // back to plain particles
+        G.n_groups = G.n_atoms = 0;
+        return MDX_OK;
+    }
+    MDX_REQUIRE(offsets && masses, "NULL argument");
+    MDX_REQUIRE(offsets[0] == 0, "offsets must start at 0");
+    const int64_t n_atoms = offsets[n_groups];
+    std::vector<double> total((size_t)n_groups);
+    for (int64_t g = 0; g < n_groups; ++g) {
+        MDX_REQUIRE(offsets[g + 1] > offsets[g], "group %lld is empty", (long long)g);
+        double m = 0.0;
+        for (int64_t a = offsets[g]; a < offsets[g + 1]; ++a)
+            m += masses[a];   // sequential, as numpy.bincount sums the weights
+        MDX_REQUIRE(m > 0.0, "group %lld has no mass", (long long)g);
+        total[(size_t)g] = m;
+    }
+    MDX_TRY(G.d_offsets.ensure(size_t(8) * (n_groups + 1)));
+    MDX_TRY(G.d_masses.ensure(size_t(8) * n_atoms));
+    MDX_TRY(G.d_total.ensure(size_t(8) * n_groups));
+    MDX_HIP(hipMemcpy(G.d_offsets.ptr, offsets, size_t(8) * (n_groups + 1), hipMemcpyHostToDevice));
+    MDX_HIP(hipMemcpy(G.d_masses.ptr, masses, size_t(8) * n_atoms, hipMemcpyHostToDevice));
+    MDX_HIP(hipMemcpy(G.d_total.ptr, total.data(), size_t(8) * n_groups, hipMemcpyHostToDevice));
+    G.n_groups = n_groups;
+    G.n_atoms = n_atoms;
     return MDX_OK;
 }
 

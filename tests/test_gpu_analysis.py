@@ -317,3 +317,39 @@ def test_intermediate_scattering_function(mode):
     ref = of.isf_run_ref(pos[::2], sizes, q, 5, mode=mode, sort=False, unique=False)
     assert np.allclose(raw.results.cisf, ref["cisf"], rtol=1e-6, atol=1e-9 * np.abs(ref["cisf"]).max())
     assert "iisf" not in raw.results and np.allclose(raw.results.times, np.arange(5))
+
+
+def test_rdf_device_centres_of_mass_equal_the_per_frame_path(tmp_path):
+    """groupings = residues / segments: centres of mass formed on the device (fast batched path,
+    in-memory and from a file) against the generic per-frame path (host NumPy centres)."""
+    import sys
+    sys.path.insert(0, str(__import__("pathlib").Path(__file__).parent))
+    from trajfiles import write_amber_netcdf
+    from mdhelper_amd.analysis.base import DynamicAnalysisBase
+    rng = np.random.default_rng(61)
+    F, N, L = 6, 1200, 26.0
+    frames = (rng.random((F, N, 3)) * L).astype(np.float32)
+    dims = np.array([L, L + 1, L - 1, 90, 90, 90], dtype=np.float32)
+    masses = rng.uniform(1.0, 40.0, N)
+    resids = rng.permutation(np.repeat(np.arange(300), 4))        # residues interleaved in atom order
+    segids = np.arange(N) // 100
+    write_amber_netcdf(tmp_path / "m.nc", frames, dims[:3])
+    universes = [mdhelper_amd.ArrayUniverse(frames, dims, masses=masses, resids=resids, segids=segids),
+                 mdhelper_amd.FileUniverse(tmp_path / "m.nc", masses=masses, resids=resids, segids=segids)]
+    cases = [dict(groupings="residues", exclusion=(1, 1)),
+             dict(groupings=("atoms", "residues")),
+             dict(groupings=("residues", "segments")),
+             dict(groupings="segments", exclusion=(1, 1))]
+    for kw in cases:
+        ref = None
+        for u in universes:
+            a, b = u.atoms[:800], u.atoms[300:]
+            args = (a, b) if isinstance(kw["groupings"], tuple) else (u.atoms,)
+            fast = RadialDistributionFunction(*args, n_bins=40, range=(0.0, 11.0), **kw).run()
+            if ref is None:
+                slow = RadialDistributionFunction(*args, n_bins=40, range=(0.0, 11.0), **kw)
+                DynamicAnalysisBase.run(slow)          # the per-frame driver
+                ref = slow.results
+                assert ref.counts.sum() > 0
+            assert np.array_equal(fast.results.counts, ref.counts), kw
+            assert np.allclose(fast.results.rdf, ref.rdf, rtol=1e-12), kw

@@ -23,11 +23,29 @@ class OracleRdfEngine:
         self.edges, self.exclusion = np.asarray(edges), exclusion
         self.n_bins = len(edges) - 1
         self._counts = np.zeros(self.n_bins, dtype=np.int64)
+        self._grouping = {}
+
+    def set_grouping(self, which, offsets, masses):
+        self._grouping[which] = None if offsets is None else (np.asarray(offsets), np.asarray(masses))
+
+    def _points(self, which, pos):
+        # centres of mass as the host path forms them (algorithm/molecule.py)
+        g = self._grouping.get(which)
+        if g is None:
+            return pos
+        offsets, m = g
+        inverse = np.repeat(np.arange(len(offsets) - 1), np.diff(offsets))
+        msum = np.bincount(inverse, weights=m)
+        p = np.asarray(pos, dtype=np.float64)
+        return np.stack([np.bincount(inverse, weights=m * p[:, k]) for k in range(3)], axis=1) / msum[:, None]
 
     def accumulate(self, pos1, pos2=None, boxes=None):
         from oracle.cbind import c_radial_histogram
         pos1 = np.asarray(pos1)
-        for f in range(pos1.shape[0]):
+        a = [self._points(1, pos1[f]) for f in range(pos1.shape[0])]
+        b = a if pos2 is None else [self._points(2, np.asarray(pos2)[f]) for f in range(pos1.shape[0])]
+        pos1, pos2 = a, (None if pos2 is None else b)
+        for f in range(len(pos1)):
             p2 = pos1[f] if pos2 is None else np.asarray(pos2)[f]
             c_radial_histogram(pos1[f], p2, self.n_bins, (self.edges[0], self.edges[-1]),
                                None if boxes is None else np.asarray(boxes)[f],
@@ -107,11 +125,14 @@ def _analyses(comm):
     u = mdhelper_amd.ArrayUniverse(frames, [L, L, L, 90, 90, 90])
     rdf = RadialDistributionFunction(u.atoms, n_bins=40, range=(0.0, 6.0), exclusion=(1, 1), comm=comm).run()
     slow = RadialDistributionFunction(u.atoms[:100], u.atoms[100:], n_bins=40, range=(0.0, 6.0),
-                                      groupings="residues", comm=comm).run()
+                                      groupings="residues", drop_axis="y", comm=comm).run()
+    com = RadialDistributionFunction(u.atoms[:100], u.atoms[100:], n_bins=40, range=(0.0, 6.0),
+                                     groupings="residues", comm=comm).run()
     sf = StructureFactor((u.atoms[:120], u.atoms[120:]), mode="partial", n_points=3, comm=comm).run()
     uw = mdhelper_amd.ArrayUniverse(walk, [14.0, 14.0, 14.0, 90, 90, 90])
     ons = Onsager((uw.atoms[:15], uw.atoms[15:]), temperature=1.0, reduced=True, n_blocks=2, comm=comm).run()
     return {"counts": rdf.results.counts, "rdf": rdf.results.rdf, "counts_slow": slow.results.counts,
+            "counts_com": com.results.counts,
             "ssf": sf.results.ssf, "msd_self": ons.results.msd_self, "msd_cross": ons.results.msd_cross}
 
 
@@ -144,8 +165,9 @@ def test_world_size_2_matches_single_rank(tmp_path):
         got = np.load(tmp_path / f"rank{rank}.npz")
         assert np.array_equal(got["counts"], single["counts"])            # integer sums: bit-exact
         assert np.array_equal(got["counts_slow"], single["counts_slow"])
+        assert np.array_equal(got["counts_com"], single["counts_com"])
         assert np.allclose(got["rdf"], single["rdf"], rtol=1e-12)
         assert np.allclose(got["ssf"], single["ssf"], rtol=1e-9, atol=1e-12)
         assert np.allclose(got["msd_self"], single["msd_self"], rtol=1e-9, atol=1e-12)
         assert np.allclose(got["msd_cross"], single["msd_cross"], rtol=1e-9, atol=1e-10)
-    assert single["counts"].sum() > 0
+    assert single["counts"].sum() > 0 and single["counts_com"].sum() > 0
