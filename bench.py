@@ -369,6 +369,13 @@ def bench_msd(args, world):
     kernel_s = st["kernel_ms"] * 1e-3
     achieved = alg_bytes / max(kernel_s, 1e-9) / 1e9
     msd = box["msd"][0, 0] / (N // 2)
+    traffic = None
+    try:   # PMC pass of the same workload (scripts/profile_pmc.sh), per step
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            if N == 10000 and T == 100000 and eng.n_fft == 262144 and not os.environ.get("MDX_MSD_ROCFFT"):
+                traffic = json.load(fh)["msd_c4_step"]["hbm_bytes_per_step"]
+    except (OSError, KeyError, ValueError):
+        pass
     out = {
         "metric": "MSD atom-frames/sec", "value": atom_frames / dt, "unit": "atom-frames/s",
         "n_gpus": world.world, "steps": args.steps, "warmup": args.warmup,
@@ -378,7 +385,7 @@ def bench_msd(args, world):
                                + (" (own two-pass transform)" if eng.n_fft == 262144
                                   and not os.environ.get("MDX_MSD_ROCFFT") else " (rocFFT)")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "msd pipeline of one step: sums + forward transforms + power "
                                "(msd_fft_cols/rows_power kernels for n_fft = 2^18, else gather + "
                                "rocFFT R2C + power)",

@@ -138,6 +138,74 @@ __global__ __launch_bounds__(SQ_THREADS) void isf_incoherent_kernel(
     }
 }
 
+// Lattice wavevectors (mdx_sq_device.hpp): the same sums through separable phase tables of
+// the DISPLACEMENTS — one sincos per (particle, axis), two complex multiplies per (q, particle).
+__global__ __launch_bounds__(SQ_THREADS, 6) void isf_incoherent_lattice_kernel(
+    const float *__restrict__ pos_ring, int ring_slots, int64_t n_atoms,
+    const short4 *__restrict__ mtrip, int n_q, SqLattice lat,
+    const int64_t *__restrict__ ranges /*[n_slots][2]*/, int n_slots, int n_split, int n_lags,
+    long long f_first, int n_new, double *__restrict__ part)
+{
+    extern __shared__ double2 lat_tab[];
+    const int tid = threadIdx.x;
+    const int qb = blockIdx.x;
+    const int slot = blockIdx.y / n_split, sp = blockIdx.y % n_split;
+    const int lag = blockIdx.z;
+    const int A = lat.tile;
+    double2 *tab[3] = {lat_tab, lat_tab + size_t(A) * lat.R[0],
+                       lat_tab + size_t(A) * (lat.R[0] + lat.R[1])};
+    int i0[SQ_QPT], i1[SQ_QPT], i2[SQ_QPT];
+    double ac[SQ_QPT];
+#pragma unroll
+    for (int u = 0; u < SQ_QPT; ++u) {
+        int qi = qb * SQ_QPB + u * SQ_THREADS + tid;
+        short4 m = mtrip[min(qi, n_q - 1)];
+        i0[u] = m.x - lat.mmin[0];
+        i1[u] = m.y - lat.mmin[1];
+        i2[u] = m.z - lat.mmin[2];
+        ac[u] = 0.0;
+    }
+    const int64_t g_lo = ranges[2 * slot], g_hi = ranges[2 * slot + 1];
+    const int64_t per = (g_hi - g_lo + n_split - 1) / n_split;
+    const int64_t lo = g_lo + sp * per, hi = min(g_hi, lo + per);
+
+    for (int i = 0; i < n_new; ++i) {
+        const long long f = f_first + i;
+        if (f < lag)
+            continue;
+        const float *C = pos_ring + int64_t(f % ring_slots) * n_atoms * 3;
+        const float *P = pos_ring + int64_t((f - lag) % ring_slots) * n_atoms * 3;
+        for (int64_t base = lo; base < hi; base += A) {
+            const int cnt = (int)min<int64_t>(A, hi - base);
+            __syncthreads();
+            for (int t = tid; t < cnt * 3; t += SQ_THREADS) {
+                const int a = t / 3, k = t - 3 * a;
+                // float32 coordinates widened first: the difference is exact in fp64
+                const double d = (double)C[(base + a) * 3 + k] - (double)P[(base + a) * 3 + k];
+                sq_lattice_fill_row(tab[k] + size_t(a) * lat.R[k], lat.base[k] * d, lat.mmin[k],
+                                    lat.R[k]);
+            }
+            __syncthreads();
+            for (int a = 0; a < cnt; ++a) {
+                const double2 *r0 = tab[0] + size_t(a) * lat.R[0], *r1 = tab[1] + size_t(a) * lat.R[1],
+                              *r2 = tab[2] + size_t(a) * lat.R[2];
+#pragma unroll
+                for (int u = 0; u < SQ_QPT; ++u) {
+                    const double2 ex = r0[i0[u]], ey = r1[i1[u]], ez = r2[i2[u]];
+                    const double tr = fma(ex.x, ey.x, -ex.y * ey.y), ti = fma(ex.x, ey.y, ex.y * ey.x);
+                    ac[u] += fma(tr, ez.x, -ti * ez.y);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < SQ_QPT; ++u) {
+        int qi = qb * SQ_QPB + u * SQ_THREADS + tid;
+        if (qi < n_q)
+            part[((int64_t(sp) * n_lags + lag) * n_slots + slot) * n_q + qi] = ac[u];
+    }
+}
+
 // iisf[lag][slot][q] += sum over splits (fixed order)
 __global__ void isf_reduce_kernel(const double *__restrict__ part, int n_split, int64_t n,
                                   double *__restrict__ iisf)
@@ -163,7 +231,10 @@ struct mdx_isf {
     std::vector<int64_t> offsets;
     std::vector<int64_t> ranges;      // particle range of every incoherent slot
     DeviceBuffer d_q, d_offsets, d_pairs, d_ranges, d_rho_ring, d_pos_ring, d_cisf, d_iisf, d_part,
-        d_pos_stage, d_index;
+        d_pos_stage, d_index, d_mtrip;
+    bool lattice = false;   // grid wavevectors: separable phase tables (mdx_sq_device.hpp)
+    SqLattice lat{};
+    size_t lat_lds = 0;
     StreamTimer timer;
 };
 
@@ -194,10 +265,17 @@ static int isf_accumulate(mdx_isf *h, int64_t n, int64_t n_frames, Source source
         }
         MDX_TRY(source(d_new, done, nf));
         hipEvent_t ev = h->timer.begin();
-        hipLaunchKernelGGL(sq_rho_kernel, dim3(qblocks, h->n_groups, (unsigned)nf), dim3(SQ_THREADS),
-                           0, h->stream, d_new, n, h->d_q.as<double>(), (int)h->n_q,
-                           h->d_offsets.as<int64_t>(), h->n_groups, 1,
-                           h->d_rho_ring.as<double2>() + int64_t(slot0) * h->n_groups * h->n_q);
+        if (h->lattice)
+            hipLaunchKernelGGL(sq_rho_lattice_kernel, dim3(qblocks, h->n_groups, (unsigned)nf),
+                               dim3(SQ_THREADS), h->lat_lds, h->stream, d_new, n,
+                               h->d_mtrip.as<short4>(), (int)h->n_q, h->lat,
+                               h->d_offsets.as<int64_t>(), h->n_groups, 1,
+                               h->d_rho_ring.as<double2>() + int64_t(slot0) * h->n_groups * h->n_q);
+        else
+            hipLaunchKernelGGL(sq_rho_kernel, dim3(qblocks, h->n_groups, (unsigned)nf),
+                               dim3(SQ_THREADS), 0, h->stream, d_new, n, h->d_q.as<double>(),
+                               (int)h->n_q, h->d_offsets.as<int64_t>(), h->n_groups, 1,
+                               h->d_rho_ring.as<double2>() + int64_t(slot0) * h->n_groups * h->n_q);
         hipLaunchKernelGGL(isf_coherent_kernel,
                            dim3((unsigned)ceil_div(h->n_q, 256), h->n_pairs, h->n_lags), dim3(256), 0,
                            h->stream, h->d_rho_ring.as<double2>(), h->ring_slots, h->n_groups,
@@ -213,11 +291,20 @@ static int isf_accumulate(mdx_isf *h, int64_t n, int64_t n_frames, Source source
                 n_split *= 2;
             const int64_t n_out = int64_t(h->n_lags) * h->n_slots * h->n_q;
             MDX_TRY(h->d_part.ensure(size_t(8) * n_out * n_split));
-            hipLaunchKernelGGL(isf_incoherent_kernel,
-                               dim3(qblocks, h->n_slots * n_split, h->n_lags), dim3(SQ_THREADS), 0,
-                               h->stream, h->d_pos_ring.as<float>(), h->ring_slots, n,
-                               h->d_q.as<double>(), (int)h->n_q, h->d_ranges.as<int64_t>(),
-                               h->n_slots, n_split, h->n_lags, f0, (int)nf, h->d_part.as<double>());
+            if (h->lattice)
+                hipLaunchKernelGGL(isf_incoherent_lattice_kernel,
+                                   dim3(qblocks, h->n_slots * n_split, h->n_lags), dim3(SQ_THREADS),
+                                   h->lat_lds, h->stream, h->d_pos_ring.as<float>(), h->ring_slots, n,
+                                   h->d_mtrip.as<short4>(), (int)h->n_q, h->lat,
+                                   h->d_ranges.as<int64_t>(), h->n_slots, n_split, h->n_lags, f0,
+                                   (int)nf, h->d_part.as<double>());
+            else
+                hipLaunchKernelGGL(isf_incoherent_kernel,
+                                   dim3(qblocks, h->n_slots * n_split, h->n_lags), dim3(SQ_THREADS), 0,
+                                   h->stream, h->d_pos_ring.as<float>(), h->ring_slots, n,
+                                   h->d_q.as<double>(), (int)h->n_q, h->d_ranges.as<int64_t>(),
+                                   h->n_slots, n_split, h->n_lags, f0, (int)nf,
+                                   h->d_part.as<double>());
             hipLaunchKernelGGL(isf_reduce_kernel, dim3((unsigned)ceil_div(n_out, 256)), dim3(256), 0,
                                h->stream, h->d_part.as<double>(), n_split, n_out,
                                h->d_iisf.as<double>());
@@ -340,6 +427,17 @@ int mdx_isf_create(mdx_isf_t *out, int dev, const double *wavevectors, int64_t n
             rc = fail(MDX_ERR_HIP, "upload failed");
             break;
         }
+        std::vector<short> trip;
+        h->lattice = sq_detect_lattice(wavevectors, n_q, h->lat, trip);
+        if (h->lattice) {
+            h->lat_lds = size_t(16) * h->lat.tile * (h->lat.R[0] + h->lat.R[1] + h->lat.R[2]);
+            if ((rc = h->d_mtrip.ensure(size_t(8) * n_q)) != MDX_OK) break;
+            if (hipMemcpy(h->d_mtrip.ptr, trip.data(), size_t(8) * n_q, hipMemcpyHostToDevice) !=
+                hipSuccess) {
+                rc = fail(MDX_ERR_HIP, "lattice table setup failed");
+                break;
+            }
+        }
     } while (0);
     if (rc != MDX_OK) {
         mdx_isf_destroy(h);
@@ -359,7 +457,7 @@ int mdx_isf_destroy(mdx_isf_t h)
     h->timer.destroy();
     for (DeviceBuffer *b : {&h->d_q, &h->d_offsets, &h->d_pairs, &h->d_ranges, &h->d_rho_ring,
                             &h->d_pos_ring, &h->d_cisf, &h->d_iisf, &h->d_part, &h->d_pos_stage,
-                            &h->d_index})
+                            &h->d_index, &h->d_mtrip})
         b->release();
     if (h->stream)
         (void)hipStreamDestroy(h->stream);

@@ -127,46 +127,6 @@ struct mdx_sq {
     size_t lat_lds = 0;
 };
 
-// Detects the lattice structure of the wavevector set (see mdx_sq_device.hpp).
-static bool sq_detect_lattice(const double *q, int64_t n_q, SqLattice &lat, std::vector<short> &trip)
-{
-    if (getenv("MDX_SQ_NO_LATTICE"))
-        return false;
-    trip.assign(size_t(4) * n_q, 0);
-    int total = 0;
-    for (int k = 0; k < 3; ++k) {
-        double g = 0.0, big = 0.0;
-        for (int64_t i = 0; i < n_q; ++i)
-            big = std::max(big, std::fabs(q[3 * i + k]));
-        for (int64_t i = 0; i < n_q; ++i) {
-            double v = std::fabs(q[3 * i + k]);
-            if (v > 1e-12 * std::max(big, 1e-300) && (g == 0.0 || v < g))
-                g = v;
-        }
-        int mmin = 0, mmax = 0;
-        if (g > 0.0) {
-            for (int64_t i = 0; i < n_q; ++i) {
-                double m = q[3 * i + k] / g, r = std::nearbyint(m);
-                if (std::fabs(m - r) > 1e-9 * std::max(1.0, std::fabs(r)) || std::fabs(r) > 512)
-                    return false;
-                trip[4 * i + k] = (short)r;
-                mmin = std::min(mmin, (int)r);
-                mmax = std::max(mmax, (int)r);
-            }
-        }
-        lat.base[k] = g;
-        lat.mmin[k] = mmin;
-        lat.R[k] = mmax - mmin + 1;
-        total += lat.R[k];
-    }
-    // particles per LDS stage: as many as fit ~26 KiB of tables (6 blocks per CU), between 8 and 64
-    int tile = int((26 * 1024) / (size_t(16) * total));
-    if (tile < 8)
-        return false;
-    lat.tile = std::min(tile, 64);
-    return true;
-}
-
 static int sq_accumulate_device(mdx_sq *h, const float *d_pos, int64_t n, int64_t n_frames)
 {
     if (n_frames == 0)

@@ -4,7 +4,11 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
+#include <cstdlib>
+#include <vector>
 
 namespace mdx_sq_dev {
 namespace {   // internal linkage: the header is compiled into two translation units
@@ -122,6 +126,72 @@ struct SqLattice {
     int tile;      // particles per LDS stage
 };
 
+// Detects the lattice structure of a wavevector set (host).  trip: short[n_q][4] integer
+// multiples (m_x, m_y, m_z, 0).  MDX_SQ_NO_LATTICE=1 disables the fast path.
+inline bool sq_detect_lattice(const double *q, int64_t n_q, SqLattice &lat, std::vector<short> &trip)
+{
+    if (getenv("MDX_SQ_NO_LATTICE"))
+        return false;
+    trip.assign(size_t(4) * n_q, 0);
+    int total = 0;
+    for (int k = 0; k < 3; ++k) {
+        double g = 0.0, big = 0.0;
+        for (int64_t i = 0; i < n_q; ++i)
+            big = std::max(big, std::fabs(q[3 * i + k]));
+        for (int64_t i = 0; i < n_q; ++i) {
+            double v = std::fabs(q[3 * i + k]);
+            if (v > 1e-12 * std::max(big, 1e-300) && (g == 0.0 || v < g))
+                g = v;
+        }
+        int mmin = 0, mmax = 0;
+        if (g > 0.0) {
+            for (int64_t i = 0; i < n_q; ++i) {
+                double m = q[3 * i + k] / g, r = std::nearbyint(m);
+                if (std::fabs(m - r) > 1e-9 * std::max(1.0, std::fabs(r)) || std::fabs(r) > 512)
+                    return false;
+                trip[4 * i + k] = (short)r;
+                mmin = std::min(mmin, (int)r);
+                mmax = std::max(mmax, (int)r);
+            }
+        }
+        lat.base[k] = g;
+        lat.mmin[k] = mmin;
+        lat.R[k] = mmax - mmin + 1;
+        total += lat.R[k];
+    }
+    // particles per LDS stage: as many as fit ~26 KiB of tables (6 blocks per CU), between 8 and 64
+    int tile = int((26 * 1024) / (size_t(16) * total));
+    if (tile < 8)
+        return false;
+    lat.tile = std::min(tile, 64);
+    return true;
+}
+
+// row[m - mmin] = exp(i m theta) for m in [mmin, mmin + R): E(1) by sincos, the rest by recurrence
+__device__ inline void sq_lattice_fill_row(double2 *row, double theta, int mmin, int R)
+{
+    double s1, c1;
+    sincos_f64(theta, s1, c1);
+    const int mmax = mmin + R - 1;
+    double er = 1.0, ei = 0.0;                 // E(0)
+    for (int m = 0; m <= mmax; ++m) {
+        if (m >= mmin)
+            row[m - mmin] = make_double2(er, ei);
+        const double nr = fma(er, c1, -ei * s1), ni = fma(er, s1, ei * c1);
+        er = nr;
+        ei = ni;
+    }
+    er = c1;
+    ei = -s1;                                  // E(-1)
+    for (int m = -1; m >= mmin; --m) {
+        if (m <= mmax)
+            row[m - mmin] = make_double2(er, ei);
+        const double nr = fma(er, c1, ei * s1), ni = fma(ei, c1, -er * s1);
+        er = nr;
+        ei = ni;
+    }
+}
+
 // 6 waves/SIMD: 78 VGPRs without spills (unbounded the table-build code takes 120 = 4 waves)
 __global__ __launch_bounds__(SQ_THREADS, 6) void sq_rho_lattice_kernel(
     const float *__restrict__ pos, int64_t n_atoms, const short4 *__restrict__ mtrip, int n_q,
@@ -161,27 +231,7 @@ __global__ __launch_bounds__(SQ_THREADS, 6) void sq_rho_lattice_kernel(
         for (int t = tid; t < cnt * 3; t += SQ_THREADS) {
             const int a = t / 3, k = t - 3 * a;
             const double theta = lat.base[k] * (double)P[(base + a) * 3 + k];
-            double s1, c1;
-            sincos_f64(theta, s1, c1);
-            double2 *row = tab[k] + size_t(a) * lat.R[k];
-            const int mmin = lat.mmin[k], mmax = mmin + lat.R[k] - 1;
-            double er = 1.0, ei = 0.0;                 // E(0)
-            for (int m = 0; m <= mmax; ++m) {
-                if (m >= mmin)
-                    row[m - mmin] = make_double2(er, ei);
-                const double nr = fma(er, c1, -ei * s1), ni = fma(er, s1, ei * c1);
-                er = nr;
-                ei = ni;
-            }
-            er = c1;
-            ei = -s1;                                  // E(-1)
-            for (int m = -1; m >= mmin; --m) {
-                if (m <= mmax)
-                    row[m - mmin] = make_double2(er, ei);
-                const double nr = fma(er, c1, ei * s1), ni = fma(ei, c1, -er * s1);
-                er = nr;
-                ei = ni;
-            }
+            sq_lattice_fill_row(tab[k] + size_t(a) * lat.R[k], theta, lat.mmin[k], lat.R[k]);
         }
         __syncthreads();
         for (int a = 0; a < cnt; ++a) {

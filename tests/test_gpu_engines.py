@@ -519,3 +519,32 @@ def test_msd_own_two_pass_transform_equals_rocfft(case, monkeypatch):
     for m in (1, 17, 4096, t_block - 3):
         d = p[m:] - p[:-m]
         assert np.isclose(msd[m], (d * d).sum(-1).mean(), rtol=1e-8)
+
+
+@pytest.mark.parametrize("mode", [None, "partial"])
+def test_isf_lattice_tables_equal_general_sincos_path(mode, monkeypatch):
+    """Grid wavevectors: separable phase tables (coherent and incoherent parts) against the
+    general fp64 sincos kernels, and both against the restated driver on a subset."""
+    rng = np.random.default_rng(71)
+    F, sizes, L = 14, (2600, 1900), 33.0
+    N = sum(sizes)
+    pos = np.mod(rng.uniform(0, L, (1, N, 3)) + np.cumsum(rng.normal(0, 0.25, (F, N, 3)), axis=0), L).astype(np.float32)
+    q = of.grid_wavevectors([L, L, L], 4)[1:]            # drop q = 0: a q_max-style subset
+    pairs = of.ssf_pairs(2, mode)
+    out = {}
+    for kind in ("lattice", "general"):
+        if kind == "general":
+            monkeypatch.setenv("MDX_SQ_NO_LATTICE", "1")
+        else:
+            monkeypatch.delenv("MDX_SQ_NO_LATTICE", raising=False)
+        eng = _core.IsfEngine(q, sizes if mode else [N], pairs, 6, True)
+        eng.accumulate(pos[:5])
+        eng.accumulate(pos[5:])
+        out[kind] = eng.result()
+        eng.close()
+    for a, b in zip(out["lattice"], out["general"]):
+        assert np.allclose(a, b, rtol=1e-9, atol=1e-9 * np.abs(b).max())
+    ref = of.isf_run_ref(pos, sizes, q, 6, mode=mode, incoherent=True, sort=False, unique=False)
+    norm = N * np.arange(F, F - 6, -1)[:, None, None]
+    assert np.allclose(out["lattice"][0] / norm, ref["cisf"], rtol=1e-6, atol=1e-9 * np.abs(ref["cisf"]).max())
+    assert np.allclose(out["lattice"][1] / norm, ref["iisf"], rtol=1e-6, atol=1e-9)
