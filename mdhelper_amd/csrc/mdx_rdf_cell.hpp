@@ -633,6 +633,8 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
     unsigned jg = __builtin_amdgcn_readfirstlane(jbase + 16u * unsigned(s));                       \
     for (int jj = 16 * s; jj < 16 * s + 16; jj += 4, jg += 4u) {                                   \
         const float4 q0 = sJw[jj], q1 = sJw[jj + 1], q2 = sJw[jj + 2], q3 = sJw[jj + 3];           \
+        /* keep the 16-byte reads whole: ds_read_b96 costs 8 LDS cycles, ds_read_b128 4 */        \
+        asm volatile("" ::"v"(q0.w), "v"(q1.w), "v"(q2.w), "v"(q3.w));                             \
         MDX_CELL_ONE(TG, U0, U1, q0, jg)                                                           \
         MDX_CELL_ONE(TG, U0, U1, q1, jg + 1u)                                                      \
         MDX_CELL_ONE(TG, U0, U1, q2, jg + 2u)                                                      \

@@ -115,3 +115,34 @@ def test_c4_long_trajectory_msd():
     m = np.arange(1, 2000)
     assert np.allclose(msd[1:2000] / (3 * 0.01 * m), 1.0, atol=0.05)
     assert np.allclose(traj[0, 0], pos.sum(axis=1), rtol=1e-12, atol=1e-9)
+
+
+def test_c5_size_cell_path_equals_filter_path():
+    """131 072 atoms (BASELINE C5): 2 048 j tiles per frame, i.e. two rounds of the survivor
+    queue; the culled kernel must agree bit for bit with the brute-force float32-filter tiles,
+    and the contract-arithmetic kernel on a sub-block."""
+    n = 131072
+    Lc = np.float32(109.4)
+    dims = np.array([Lc, Lc, Lc, 90, 90, 90], dtype=np.float32)
+    d = _core.synth_random_walk(2, n, [Lc, Lc, Lc], 0.3, seed=5)
+    frames = d.to_host()
+    d.free()
+    edges = np.linspace(0.0, 15.0, 202)
+    out = {}
+    for algo in ("cell", "filter"):
+        eng = _core.RdfEngine(edges, (1, 1), algo=algo)
+        eng.accumulate(frames, None, dims)
+        out[algo] = eng.counts()
+        eng.close()
+    assert np.array_equal(out["cell"], out["filter"]) and out["cell"].sum() > 0
+    # density 0.1 / A^3: about 4/3 pi 15^3 * 0.1 = 1414 neighbours per atom
+    assert abs(out["cell"].sum() / (2 * n) - 1413.7) < 15
+    sub = frames[:1, :20000]
+    eng = _core.RdfEngine(edges, (1, 1), algo="exact")
+    eng.accumulate(sub, None, dims)
+    ref = eng.counts()
+    eng.close()
+    eng = _core.RdfEngine(edges, (1, 1), algo="cell")
+    eng.accumulate(sub, None, dims)
+    assert np.array_equal(eng.counts(), ref)
+    eng.close()

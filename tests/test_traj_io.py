@@ -125,3 +125,37 @@ def test_file_universe_surface(tmp_path):
     sel = u.trajectory[1:6:2]
     assert [t.frame for t in sel] == [1, 3, 5]
     np.testing.assert_array_equal(u.trajectory.frame_block([5, 0]), pos[[5, 0]])
+
+
+def test_mutated_headers_fail_cleanly(tmp_path):
+    """Random corruption of the first kilobyte: every file is either read or refused with a
+    Python exception — never a crash, hang or out-of-bounds read."""
+    pos = _walk(3, 9, 5.0, 8)
+    write_amber_netcdf(tmp_path / "good.nc", pos, (5.0, 5.0, 5.0))
+    write_dcd(tmp_path / "good.dcd", pos, [[5.0, 5.0, 5.0, 90, 90, 90]])
+    rng = np.random.default_rng(9)
+    outcomes = {"ok": 0, "refused": 0}
+    for name in ("good.nc", "good.dcd"):
+        data = bytearray((tmp_path / name).read_bytes())
+        for trial in range(150):
+            bad = bytearray(data)
+            for _ in range(int(rng.integers(1, 6))):
+                at = int(rng.integers(0, min(len(bad), 1024)))
+                bad[at] = int(rng.integers(0, 256))
+            if trial % 5 == 0:
+                bad = bad[:int(rng.integers(8, len(bad)))]
+            path = tmp_path / f"m{trial}{name[-4:]}"
+            path.write_bytes(bytes(bad))
+            try:
+                t = TrajectoryFile(path)
+                if 0 < t.n_frames <= 1000 and 0 < t.n_atoms <= 100000:
+                    t.read_positions([0, t.n_frames - 1])
+                    if t.has_box:
+                        t.read_boxes([t.n_frames - 1])
+                    if t.has_time:
+                        t.read_times([0])
+                t.close()
+                outcomes["ok"] += 1
+            except (ValueError, OSError, NotImplementedError, RuntimeError, MemoryError):
+                outcomes["refused"] += 1
+    assert outcomes["ok"] + outcomes["refused"] == 300 and outcomes["refused"] > 20
