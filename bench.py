@@ -392,6 +392,27 @@ def bench_msd(args, world):
                      "pipeline_bytes_model": st["bytes_moved"]},
         "physics_check_msd_over_3sigma2m": float(msd[10] / (3 * 0.01 * 10)),
     }
+    if world.rank == 0 and world.world == 1 and not args.no_cpu_baseline:
+        # the reference's msd_fft (scipy FFTs, one core) on a bounded sample of particles, and
+        # the engine on the same particles checked against it
+        from oracle import correlation as oc
+        n_s = 64
+        small = _core.synth_random_walk(T, n_s, [1.0, 1.0, 1.0], 0.1, seed=99, dev=dev, dtype=np.float64)
+        h_small = small.to_host()
+        t0 = time.perf_counter()
+        ref = oc.msd_fft_ref(h_small[None], axis=1, average=False)[0].sum(axis=-1)
+        t_cpu = time.perf_counter() - t0
+        chk = _core.MsdEngine(T, 1, 1, dev=dev)
+        chk.push_device(0, small.ptr, n_s, 0, n_s)
+        got = chk.result()[0][0, 0]
+        chk.close()
+        small.free()
+        err = float(np.abs(got - ref).max() / np.abs(ref).max())
+        out["cpu_baseline"] = {"value": n_s * float(T) / t_cpu, "unit": "atom-frames/s", "cores": 1,
+                               "kind": "port",
+                               "sample": f"{n_s} particles x {T} frames, scipy-FFT msd_fft restatement "
+                                         f"(oracle/correlation.py), {t_cpu:.1f} s",
+                               "gpu_max_rel_deviation_on_sample": err}
     eng.close()
     traj.free()
     return out

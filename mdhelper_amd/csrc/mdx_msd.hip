@@ -473,10 +473,15 @@ int mdx_msd_create(mdx_msd_t *out, int dev, int64_t n_frames_block, int n_blocks
         const char *mode = getenv("MDX_MSD_NFFT");
         const bool force_ref = mode && !strcmp(mode, "ref");
         const bool force_pow2 = mode && !strcmp(mode, "pow2");
-        // ... and always when it is 2^18, the length of the engine's own two-pass transform
-        // (mdx_msd_fft.hpp), which never materialises the padding
-        const bool own = p == msdfft::N && !getenv("MDX_MSD_ROCFFT");
-        if (force_pow2 || (!force_ref && (own || 2 * p <= 3 * h->n_fft)))
+        // ... and 2^18 — the length of the engine's own two-pass transform (mdx_msd_fft.hpp), which
+        // never materialises the padding and moves ~4.3 MB per series whatever N_t is — whenever
+        // it is long enough and the rocFFT pipeline (~17.7 MB per series at 2^18, in proportion
+        // for shorter transforms) would move more: from N_t = 40 000 up to 131 072
+        const bool own = !getenv("MDX_MSD_ROCFFT") && 2 * n_frames_block <= msdfft::N &&
+                         n_frames_block >= 40000;
+        if (own && !force_ref)
+            h->n_fft = msdfft::N;
+        else if (force_pow2 || (!force_ref && 2 * p <= 3 * h->n_fft))
             h->n_fft = p;
     }
     h->nc = h->n_fft / 2 + 1;

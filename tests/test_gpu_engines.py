@@ -489,7 +489,7 @@ def test_rdf_mixed_orthorhombic_and_triclinic_frames_in_one_batch():
         eng.close()
 
 
-@pytest.mark.parametrize("case", [(70001, 1, 37, 0), (66000, 2, 20, 2), (131072, 1, 9, 5)])
+@pytest.mark.parametrize("case", [(70001, 1, 37, 0), (66000, 2, 20, 2), (131072, 1, 9, 5), (40000, 3, 11, 0)])
 def test_msd_own_two_pass_transform_equals_rocfft(case, monkeypatch):
     """n_fft = 2^18: the engine's own packed two-pass transform against the rocFFT pipeline."""
     t_block, n_blocks, n_atoms, zero_dims = case
@@ -497,14 +497,13 @@ def test_msd_own_two_pass_transform_equals_rocfft(case, monkeypatch):
     T = t_block * n_blocks
     pos = np.cumsum(rng.normal(0, 0.3, (T, n_atoms, 3)), axis=0) + rng.uniform(0, 50, (1, n_atoms, 3))
     out = {}
-    monkeypatch.setenv("MDX_MSD_NFFT", "pow2")
     for mode in ("own", "rocfft"):
         if mode == "rocfft":
             monkeypatch.setenv("MDX_MSD_ROCFFT", "1")
         else:
             monkeypatch.delenv("MDX_MSD_ROCFFT", raising=False)
         eng = _core.MsdEngine(t_block, n_blocks, 2)
-        assert eng.n_fft == 262144
+        assert mode != "own" or eng.n_fft == 262144     # rocFFT runs its own choice of length
         eng.push(0, pos, 0, n_atoms, zero_dims)
         eng.push(1, pos, 3, n_atoms - 5, zero_dims)
         out[mode] = eng.result()
