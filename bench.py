@@ -278,14 +278,15 @@ def cpu_baseline_rdf(args, traj, box, edges, rng, n_bins, N, eng):
 
 def bench_sq(args, world):
     from mdhelper_amd import _core
-    from oracle import fourier as of
     dev = world.local_rank
     N = args.atoms or 32768
     F = args.frames or 1000
     L = 68.94
-    q = of.grid_wavevectors([L, L, L], 8)          # 512 wavevectors (structure.py:1379-1381)
+    # 512 grid wavevectors, numpy.meshgrid's default 'xy' order (structure.py:1379-1381)
+    grid = 2 * np.pi * np.arange(8) / L
+    q = np.stack(np.meshgrid(grid, grid, grid), -1).reshape(-1, 3)
     sizes = [N // 2, N - N // 2]
-    pairs = of.ssf_pairs(2, "partial")
+    pairs = ((0, 0), (0, 1), (1, 1))               # mode="partial" (structure.py:1459-1464)
     traj = _core.synth_random_walk(F, N, [L, L, L], 0.3, seed=2 + world.rank, dev=dev)
     eng = _core.SqEngine(q, sizes, pairs, dev=dev, timing=True)
 
@@ -324,13 +325,16 @@ def bench_sq(args, world):
         "checksum": float(ssf.sum()),
     }
     if world.rank == 0 and world.world == 1 and not args.no_cpu_baseline:
+        from oracle import fourier as of
         sample = traj.to_host(0, 2).astype(np.float64)
         t0 = time.perf_counter()
-        for f in range(2):
-            of.fourier_sum_ref(q, sample[f])
+        refs = [of.fourier_sum_ref(q, sample[f]) for f in range(2)]
         t_cpu = time.perf_counter() - t0
+        got = _core.fourier_sum_device(q, sample[0], dev=dev)
+        err = float(np.abs(got - refs[0]).max() / np.abs(refs[0]).max())
         out["cpu_baseline"] = {"value": 2 * float(N) * len(q) / t_cpu, "unit": "evals/s", "cores": 1,
-                               "kind": "port", "sample": f"2 frames, numpy exp(1j q.r) ({t_cpu:.1f} s)"}
+                               "kind": "port", "sample": f"2 frames, numpy exp(1j q.r) ({t_cpu:.1f} s)",
+                               "gpu_max_rel_deviation_on_sample": err}
     eng.close()
     traj.free()
     return out
@@ -382,12 +386,12 @@ def bench_msd(args, world):
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"C4 self-MSD {N} atoms x {T} frames, 2 groups, n_fft={eng.n_fft}"
-                               + (" (own two-pass transform)" if eng.n_fft == 262144
+                               + (" (own two-pass transform)" if eng.n_fft in (1 << 18, 1 << 19, 1 << 20)
                                   and not os.environ.get("MDX_MSD_ROCFFT") else " (rocFFT)")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "msd pipeline of one step: sums + forward transforms + power "
-                               "(msd_fft_cols/rows_power kernels for n_fft = 2^18, else gather + "
+                               "(msd_fft_cols/rows_power kernels for n_fft = 2^18..2^20, else gather + "
                                "rocFFT R2C + power)",
                      "pipeline_bytes_model": st["bytes_moved"]},
         "physics_check_msd_over_3sigma2m": float(msd[10] / (3 * 0.01 * 10)),

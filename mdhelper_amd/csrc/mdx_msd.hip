@@ -286,7 +286,8 @@ struct mdx_msd {
     // accumulators: power [G][B][nc] + D [G][B*T_b] contiguous (one all-reduce), traj [G][B*T_b][3]
     DeviceBuffer d_acc, d_traj, d_series, d_spec, d_stage, d_inv_in, d_inv_out;
     DeviceBuffer d_f32, d_index, d_prev, d_image;   // trajectory-file path: frames, unwrap state
-    bool own_fft = false;                           // n_fft = 2^18: mdx_msd_fft.hpp instead of rocFFT
+    bool own_fft = false;                           // n_fft = 2^18..2^20: mdx_msd_fft.hpp, not rocFFT
+    msdfft::Shape shape;
     DeviceBuffer d_tw, d_pfull;                     // twiddle tables [2][512], full-spectrum sums [B][N]
     StreamTimer timer;
     int64_t bytes_moved = 0;
@@ -319,7 +320,7 @@ static int msd_push_device(mdx_msd *h, int group, const double *d_pos, int64_t n
     chunk = ceil_div(count, n_chunks);
     if (h->own_fft) {
         const int64_t p_pad_max = ceil_div(ceil_div(chunk * 3, 2), msdfft::PG) * msdfft::PG;
-        MDX_TRY(h->d_spec.ensure(size_t(B) * msdfft::N * p_pad_max * 16));
+        MDX_TRY(h->d_spec.ensure(size_t(B) * h->n_fft * p_pad_max * 16));
     } else {
         MDX_TRY(h->d_series.ensure(size_t(chunk) * 3 * B * h->n_fft * 8));
         MDX_TRY(h->d_spec.ensure(size_t(chunk) * 3 * B * h->nc * 16));
@@ -332,17 +333,12 @@ static int msd_push_device(mdx_msd *h, int group, const double *d_pos, int64_t n
                            d_pos, n_total, first + a0, c, zero_dims, h->traj(group), h->dsq(group));
         if (h->own_fft) {
             const int p_pad = (int)(ceil_div(ceil_div(n_elem, 2), msdfft::PG) * msdfft::PG);
-            const double2 *tw512 = h->d_tw.as<double2>(), *twN = tw512 + msdfft::R;
-            hipLaunchKernelGGL(msdfft::msd_fft_cols_kernel,
-                               dim3((unsigned)(p_pad / msdfft::PG), msdfft::COLS_SPLIT, (unsigned)B),
-                               dim3(msdfft::THREADS), 0, h->stream, d_pos, n_total, first + a0, n_elem,
-                               h->t_block, zero_dims, p_pad, tw512, twN, h->d_spec.as<double2>());
-            hipLaunchKernelGGL(msdfft::msd_fft_rows_power_kernel, dim3(msdfft::R, (unsigned)B),
-                               dim3(msdfft::THREADS), 0, h->stream, h->d_spec.as<double2>(), p_pad,
-                               tw512, h->d_pfull.as<double>());
-            hipLaunchKernelGGL(msdfft::msd_power_fold_kernel,
-                               dim3((unsigned)ceil_div(h->nc, 256), (unsigned)B), dim3(256), 0,
-                               h->stream, h->d_pfull.as<double>(), h->nc, h->power(group));
+            // tables: half table of W_R1, half table of W_R2, W_N^m for m < R2
+            const double2 *tw_r1 = h->d_tw.as<double2>(), *tw_r2 = tw_r1 + h->shape.r1 / 2,
+                          *twN = tw_r2 + h->shape.r2 / 2;
+            msdfft::launch(h->shape, h->stream, d_pos, n_total, first + a0, n_elem, h->t_block, B,
+                           zero_dims, p_pad, tw_r1, tw_r2, twN, h->d_spec.as<double2>(),
+                           h->d_pfull.as<double>(), h->nc, h->power(group));
             // positions read twice (sums, pass A), Y written and read once
             h->bytes_moved += c * 3 * B * (2 * h->t_block * 8 + 2 * h->n_fft * 8);
             continue;
@@ -473,14 +469,15 @@ int mdx_msd_create(mdx_msd_t *out, int dev, int64_t n_frames_block, int n_blocks
         const char *mode = getenv("MDX_MSD_NFFT");
         const bool force_ref = mode && !strcmp(mode, "ref");
         const bool force_pow2 = mode && !strcmp(mode, "pow2");
-        // ... and 2^18 — the length of the engine's own two-pass transform (mdx_msd_fft.hpp), which
-        // never materialises the padding and moves ~4.3 MB per series whatever N_t is — whenever
-        // it is long enough and the rocFFT pipeline (~17.7 MB per series at 2^18, in proportion
-        // for shorter transforms) would move more: from N_t = 40 000 up to 131 072
-        const bool own = !getenv("MDX_MSD_ROCFFT") && 2 * n_frames_block <= msdfft::N &&
-                         n_frames_block >= 40000;
-        if (own && !force_ref)
-            h->n_fft = msdfft::N;
+        // ... and the lengths of the engine's own two-pass transform (mdx_msd_fft.hpp: 2^18, 2^19,
+        // 2^20), which never materialises the padding and moves ~4.3 MB per series at 2^18
+        // whatever N_t is — whenever the rocFFT pipeline (~17.7 MB per series at 2^18, in
+        // proportion for other lengths) would move more: from N_t = 40 000 up to 524 288
+        int64_t own_len = 0;
+        if (!getenv("MDX_MSD_ROCFFT") && n_frames_block >= 40000)
+            own_len = std::max<int64_t>(p, int64_t(1) << 18);
+        if (own_len && msdfft::shape_for(own_len).r1 && !force_ref)
+            h->n_fft = own_len;
         else if (force_pow2 || (!force_ref && 2 * p <= 3 * h->n_fft))
             h->n_fft = p;
     }
@@ -497,22 +494,27 @@ int mdx_msd_create(mdx_msd_t *out, int dev, int64_t n_frames_block, int n_blocks
         if ((rc = h->d_traj.ensure(size_t(8) * h->traj_len())) != MDX_OK) break;
         // forward transforms of length 2^18 run through the engine's own two-pass kernels
         // (MDX_MSD_ROCFFT=1 keeps rocFFT for them too)
-        h->own_fft = h->n_fft == msdfft::N && !getenv("MDX_MSD_ROCFFT");
+        h->shape = msdfft::shape_for(h->n_fft);
+        h->own_fft = h->shape.r1 != 0 && !getenv("MDX_MSD_ROCFFT");
         if (h->own_fft) {
-            std::vector<double> tw(size_t(4) * msdfft::R);
+            const int r1 = h->shape.r1, r2 = h->shape.r2;
+            std::vector<double> tw;
             const double two_pi = 6.283185307179586476925286766559;
-            for (int m = 0; m < msdfft::R; ++m) {
-                tw[2 * m] = std::cos(two_pi * m / msdfft::R);
-                tw[2 * m + 1] = -std::sin(two_pi * m / msdfft::R);
-                tw[2 * (msdfft::R + m)] = std::cos(two_pi * m / msdfft::N);
-                tw[2 * (msdfft::R + m) + 1] = -std::sin(two_pi * m / msdfft::N);
-            }
+            auto push = [&](int count, double period) {
+                for (int m = 0; m < count; ++m) {
+                    tw.push_back(std::cos(two_pi * m / period));
+                    tw.push_back(-std::sin(two_pi * m / period));
+                }
+            };
+            push(r1 / 2, r1);
+            push(r2 / 2, r2);
+            push(r2, (double)h->n_fft);
             if ((rc = h->d_tw.ensure(tw.size() * 8)) != MDX_OK) break;
             if (hipMemcpy(h->d_tw.ptr, tw.data(), tw.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
                 rc = fail(MDX_ERR_HIP, "twiddle table upload failed");
                 break;
             }
-            if ((rc = h->d_pfull.ensure(size_t(8) * n_blocks * msdfft::N)) != MDX_OK) break;
+            if ((rc = h->d_pfull.ensure(size_t(8) * n_blocks * h->n_fft)) != MDX_OK) break;
         }
     } while (0);
     if (rc != MDX_OK) {

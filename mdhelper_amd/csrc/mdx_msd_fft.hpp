@@ -1,24 +1,25 @@
-// mdx_msd_fft.hpp — the MSD engine's own forward transform for n_fft = 2^18.
+// mdx_msd_fft.hpp — the MSD engine's own forward transforms for n_fft = 2^18, 2^19, 2^20.
 //
 // The power spectrum sum_series |F_k|^2 of ~30 000 zero-padded real series of 10^5 points is
-// HBM traffic, not arithmetic.  Through rocFFT the pipeline moves ~17.7 MB per series
+// HBM traffic, not arithmetic.  Through rocFFT the pipeline moves ~17.7 MB per series at 2^18
 // (gather with explicit zero padding, three transform passes each reading and writing the
 // padded complex array, a separate |F|^2 pass).  Here it is 4.8 MB per series:
 //
 //   * two real series travel as ONE complex series z = x_a + i x_b; since x_a, x_b are real,
 //     (|Z_k|^2 + |Z_{N-k}|^2) / 2 = |X_a,k|^2 + |X_b,k|^2, which is all the engine accumulates;
-//   * four-step transform N = 512 x 512, index n = 512 n1 + n2, k = k1 + 512 k2:
+//   * four-step transform N = R1 x R2, index n = R2 n1 + n2, k = k1 + R1 k2:
 //       pass A (msd_fft_cols_kernel): reads the positions where they lie ([frame][particle][xyz],
 //         16 consecutive coordinates = 128 B per frame row, only the t < T_b rows — the zero
-//         padding is never materialised), 512-point transforms over n1 in LDS, twiddle
+//         padding is never materialised), R1-point transforms over n1 in LDS, twiddle
 //         W_N^(n2 k1), writes Y[k1][pair group][n2][pair] (8 pairs = 128 B contiguous);
-//       pass B (msd_fft_rows_power_kernel): streams Y once (64 KB contiguous per step),
-//         512-point transforms over n2 in LDS,
-//         accumulates |Z|^2 over all pairs in registers — the spectrum itself is never written;
+//       pass B (msd_fft_rows_power_kernel): streams Y once (R2 x 128 B contiguous per step),
+//         R2-point transforms over n2 in LDS, accumulates |Z|^2 over all pairs in registers —
+//         the spectrum itself is never written;
 //   * msd_power_fold_kernel folds the N-point sums into the half spectrum the inverse step uses.
 //
-// One wave owns one 512-point transform (radix-8 Stockham, three in-place stages in an 8 KB LDS
-// buffer; a wave's LDS operations execute in order, so no barrier is needed inside a transform).
+// One wave owns one transform (radix-8 Stockham stages, a radix-16 last stage for 1024 points,
+// in place in a wave-private LDS buffer; a wave's LDS operations execute in order, so there is
+// no barrier inside a transform).  Shapes: 2^18 = 512 x 512, 2^19 = 1024 x 512, 2^20 = 1024 x 1024.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -27,10 +28,7 @@
 
 namespace msdfft {
 
-constexpr int R = 512;             // rows = columns
-constexpr int N = R * R;           // 262144
 constexpr int PG = 8;              // pairs per block, one wave each
-constexpr int ZSTRIDE = R + 1;     // complex elements per pair buffer (+1: bank spread)
 constexpr int THREADS = 64 * PG;
 
 __device__ inline double2 cmul(double2 a, double2 b)
@@ -42,7 +40,7 @@ __device__ inline double2 csub(double2 a, double2 b) { return make_double2(a.x -
 __device__ inline double2 mul_mi(double2 a) { return make_double2(a.y, -a.x); }   // * (-i)
 
 // forward 8-point transform, natural order in and out
-__device__ inline void dft8(double2 (&a)[8])
+__device__ __forceinline__ void dft8(double2 *a)
 {
     const double s = 0.70710678118654752440;
     const double2 b0 = cadd(a[0], a[4]), b4 = csub(a[0], a[4]);
@@ -67,11 +65,44 @@ __device__ inline void dft8(double2 (&a)[8])
     a[7] = csub(c6, c7);
 }
 
-// exp(-2 pi i m / 512) from the half table h[m] (m < 256): the upper half is its negative
-__device__ inline double2 tw512_at(const double2 *h, int m)
+// forward 16-point transform, natural order in and out: two 8-point transforms of the even and
+// odd samples, combined with W_16^k
+__device__ __forceinline__ void dft16(double2 *a)
 {
-    const double2 t = h[m & 255];
-    return (m & 256) ? make_double2(-t.x, -t.y) : t;
+    double2 e[8], o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        e[i] = a[2 * i];
+        o[i] = a[2 * i + 1];
+    }
+    dft8(e);
+    dft8(o);
+    const double c1 = 0.92387953251128675613, s1 = 0.38268343236508977173;   // cos, sin(pi/8)
+    const double r = 0.70710678118654752440;
+    const double2 w[8] = {make_double2(1.0, 0.0),  make_double2(c1, -s1), make_double2(r, -r),
+                          make_double2(s1, -c1),   make_double2(0.0, -1.0), make_double2(-s1, -c1),
+                          make_double2(-r, -r),    make_double2(-c1, -s1)};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const double2 t = cmul(o[k], w[k]);
+        a[k] = cadd(e[k], t);
+        a[k + 8] = csub(e[k], t);
+    }
+}
+
+template <int RADIX> __device__ __forceinline__ void dft(double2 *a)
+{
+    if (RADIX == 8)
+        dft8(a);
+    else
+        dft16(a);
+}
+
+// exp(-2 pi i m / M) from the half table h[m] (m < M/2): the upper half is its negative
+template <int M> __device__ inline double2 tw_at(const double2 *h, int m)
+{
+    const double2 t = h[m & (M / 2 - 1)];
+    return (m & (M / 2)) ? make_double2(-t.x, -t.y) : t;
 }
 
 __device__ inline void wave_lds_fence()
@@ -81,79 +112,82 @@ __device__ inline void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// In-place forward 512-point transform of z[0..511] (LDS) by one wave; entries with index
-// >= n_live are taken as zero without being read.  tw: exp(-2 pi i m / 512), m < 256, in LDS
-// (global twiddle loads would share the vmcnt queue with the streaming loads of the callers
-// and make every transform wait for HBM).
-__device__ inline void fft512_wave(double2 *z, const double2 *__restrict__ tw, int lane, int n_live)
+// One in-place Stockham stage of an M-point transform by one wave: M / RADIX butterflies,
+// M / RADIX / 64 per lane, all loaded before any is stored.  NS: product of the earlier radices.
+// FIRST: entries with index >= n_live are taken as zero without being read.
+template <int M, int RADIX, int NS, bool FIRST>
+__device__ __forceinline__ void stockham_stage(double2 *z, const double2 *tw, int lane, int n_live)
 {
-    double2 v[8];
-    // stage Ns = 1
+    constexpr int T = M / RADIX;     // butterflies
+    constexpr int PER = T / 64;      // per lane
+    static_assert(PER >= 1, "at least one butterfly per lane");
+    double2 v[PER][RADIX];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int idx = lane + 64 * r;
-        v[r] = idx < n_live ? z[idx] : make_double2(0.0, 0.0);
-    }
-    dft8(v);
-    wave_lds_fence();
+    for (int p = 0; p < PER; ++p) {
+        const int j = lane + 64 * p;
+        const int k = j & (NS - 1);
 #pragma unroll
-    for (int r = 0; r < 8; ++r)
-        z[lane * 8 + r] = v[r];
-    wave_lds_fence();
-    // stage Ns = 8
-    {
-        const int k = lane & 7;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            v[r] = z[lane + 64 * r];
-            if (r)
-                v[r] = cmul(v[r], tw512_at(tw, (r * k * 8) & 511));
+        for (int r = 0; r < RADIX; ++r) {
+            const int idx = j + r * T;
+            v[p][r] = (!FIRST || idx < n_live) ? z[idx] : make_double2(0.0, 0.0);
+            if (NS > 1 && r)   // W_(RADIX NS)^(r k)
+                v[p][r] = cmul(v[p][r], tw_at<M>(tw, (r * k * (M / (RADIX * NS))) & (M - 1)));
         }
-        dft8(v);
-        wave_lds_fence();
-        const int j0 = (lane >> 3) * 64 + k;
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-            z[j0 + 8 * r] = v[r];
-        wave_lds_fence();
+        dft<RADIX>(v[p]);
     }
-    // stage Ns = 64
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        v[r] = z[lane + 64 * r];
-        if (r)
-            v[r] = cmul(v[r], tw512_at(tw, (r * lane) & 511));
-    }
-    dft8(v);
     wave_lds_fence();
 #pragma unroll
-    for (int r = 0; r < 8; ++r)
-        z[lane + 64 * r] = v[r];
+    for (int p = 0; p < PER; ++p) {
+        const int j = lane + 64 * p;
+        const int k = j & (NS - 1);
+        const int j0 = (j - k) * RADIX + k;
+#pragma unroll
+        for (int r = 0; r < RADIX; ++r)
+            z[j0 + r * NS] = v[p][r];
+    }
     wave_lds_fence();
+}
+
+// In-place forward M-point transform of z[0..M) (LDS) by one wave.  tw: exp(-2 pi i m / M),
+// m < M / 2, in LDS (global twiddle loads would share the vmcnt queue with the streaming loads
+// of the callers and make every transform wait for HBM).
+template <int M> __device__ __forceinline__ void fft_wave(double2 *z, const double2 *tw, int lane, int n_live)
+{
+    static_assert(M == 512 || M == 1024, "supported transform lengths");
+    stockham_stage<M, 8, 1, true>(z, tw, lane, n_live);
+    stockham_stage<M, 8, 8, false>(z, tw, lane, n_live);
+    if (M == 512)
+        stockham_stage<M, 8, 64, false>(z, tw, lane, n_live);
+    else
+        stockham_stage<M, M / 64, 64, false>(z, tw, lane, n_live);   // radix 16
 }
 
 // Pass A.  grid (pair groups, COLS_SPLIT column ranges, blocks of the trajectory), 512 threads.
 // pos: float64 [B * t_block][n_total][3]; the chunk's coordinates are e in [0, n_elem) behind
 // particle `first`; coordinate e belongs to pair e / 2 (real part: even e).
 // A block walks its columns in order: while one column is transformed the next column's rows
-// are already in flight (registers).
+// are already in flight (registers).  t_block <= N / 2: at most R1 / 2 live rows.
 constexpr int COLS_SPLIT = 4;
-constexpr int COLS_PER_BLOCK = R / COLS_SPLIT;
 
-__global__ __launch_bounds__(THREADS, 4) void msd_fft_cols_kernel(
+template <int R1, int R2>
+__global__ __launch_bounds__(THREADS, R1 == 512 ? 4 : 2) void msd_fft_cols_kernel(
     const double *__restrict__ pos, int64_t n_total, int64_t first, int64_t n_elem, int64_t t_block,
-    int zero_dims, int p_pad, const double2 *__restrict__ tw512, const double2 *__restrict__ twN,
+    int zero_dims, int p_pad, const double2 *__restrict__ tw_r1, const double2 *__restrict__ twN,
     double2 *__restrict__ Y)
 {
-    __shared__ double2 zb[PG][ZSTRIDE];
-    __shared__ double2 s_h[R / 2];   // exp(-2 pi i m / 512), m < 256
-    __shared__ double2 s_n[R];       // exp(-2 pi i m / N),   m < 512
+    constexpr int ZS = R1 + 1;                  // +1: bank spread of the transposed reads
+    constexpr int LOADS = R1 / 2 / 32;          // rows per thread and column (8 or 16)
+    constexpr int OUTS = R1 / 64;               // k1 values per thread (8 or 16)
+    __shared__ double2 zb[PG][ZS];
+    __shared__ double2 s_h[R1 / 2];   // exp(-2 pi i m / R1), m < R1 / 2
+    __shared__ double2 s_n[R2];       // exp(-2 pi i m / N),  m < R2
     const int pg = blockIdx.x, b = blockIdx.z;
-    const int n2_begin = blockIdx.y * COLS_PER_BLOCK;
+    const int n2_begin = blockIdx.y * (R2 / COLS_SPLIT);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < R / 2)
-        s_h[tid] = tw512[tid];
-    s_n[tid] = twN[tid];
+    for (int i = tid; i < R1 / 2; i += THREADS)
+        s_h[i] = tw_r1[i];
+    for (int i = tid; i < R2; i += THREADS)
+        s_n[i] = twN[i];
 
     const int s = tid & 15, row0 = tid >> 4;
     const int64_t e = int64_t(pg) * 16 + s;
@@ -162,120 +196,169 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols_kernel(
     const int64_t row_stride = n_total * 3;
     double *dst = reinterpret_cast<double *>(&zb[s >> 1][0]) + (s & 1);
     const int p = tid & 7, kbase = tid >> 3;
-    double2 *out = Y + ((int64_t(b) * R * (p_pad / PG) + pg) * R) * PG + p;
-    const int64_t k1_stride = int64_t(p_pad / PG) * R * PG;
+    double2 *out = Y + ((int64_t(b) * R1 * (p_pad / PG) + pg) * R2) * PG + p;
+    const int64_t k1_stride = int64_t(p_pad / PG) * R2 * PG;
 
-    // rows n1 = row0 + 32 i of column n2, i < 8 (t_block <= N / 2: at most 256 live rows)
-    double x0, x1, x2, x3, x4, x5, x6, x7;
-#define MDX_COLS_LOAD1(X, I, N2)                                                  \
-    {                                                                             \
-        const int64_t t = int64_t(row0 + 32 * (I)) * R + (N2);                    \
-        X = (live && t < t_block) ? src[t * row_stride] : 0.0;                    \
+    // rows n1 = row0 + 32 i of the current column (indexed by unrolled constants only)
+    double x[LOADS];
+#define MDX_COLS_LOAD(N2)                                                           \
+    _Pragma("unroll") for (int i = 0; i < LOADS; ++i)                               \
+    {                                                                               \
+        const int64_t t = int64_t(row0 + 32 * i) * R2 + (N2);                       \
+        x[i] = (live && t < t_block) ? src[t * row_stride] : 0.0;                   \
     }
-#define MDX_COLS_LOAD(N2)                                                         \
-    MDX_COLS_LOAD1(x0, 0, N2) MDX_COLS_LOAD1(x1, 1, N2) MDX_COLS_LOAD1(x2, 2, N2) \
-    MDX_COLS_LOAD1(x3, 3, N2) MDX_COLS_LOAD1(x4, 4, N2) MDX_COLS_LOAD1(x5, 5, N2) \
-    MDX_COLS_LOAD1(x6, 6, N2) MDX_COLS_LOAD1(x7, 7, N2)
-#define MDX_COLS_PUT()                                                            \
-    dst[2 * (row0)] = x0, dst[2 * (row0 + 32)] = x1, dst[2 * (row0 + 64)] = x2,   \
-    dst[2 * (row0 + 96)] = x3, dst[2 * (row0 + 128)] = x4, dst[2 * (row0 + 160)] = x5, \
-    dst[2 * (row0 + 192)] = x6, dst[2 * (row0 + 224)] = x7
-// result of column N2 for k1 = kbase + 64 I, twiddled by W_N^(N2 k1)
-#define MDX_COLS_OUT(I, N2)                                                       \
-    ([&]() {                                                                      \
-        const int k1 = kbase + 64 * (I);                                          \
-        const unsigned m = unsigned(k1) * unsigned(N2);                           \
-        return cmul(zb[p][k1], cmul(tw512_at(s_h, int(m >> 9)), s_n[m & 511]));   \
-    }())
-
     MDX_COLS_LOAD(n2_begin)
     __syncthreads();
-    for (int n2 = n2_begin; n2 < n2_begin + COLS_PER_BLOCK; ++n2) {
-        MDX_COLS_PUT();
+    for (int n2 = n2_begin; n2 < n2_begin + R2 / COLS_SPLIT; ++n2) {
+#pragma unroll
+        for (int i = 0; i < LOADS; ++i)
+            dst[2 * (row0 + 32 * i)] = x[i];
         __syncthreads();
         {
-            const int nxt = min(n2 + 1, R - 1);   // the last column reloads itself
+            const int nxt = min(n2 + 1, R2 - 1);   // the last column reloads itself
             MDX_COLS_LOAD(nxt)
         }
-        fft512_wave(zb[wave], s_h, lane, 256);
+        fft_wave<R1>(zb[wave], s_h, lane, R1 / 2);
         __syncthreads();
         double2 *o = out + int64_t(kbase) * k1_stride + int64_t(n2) * PG;
-#define MDX_COLS_STORE(I) o[int64_t(64 * (I)) * k1_stride] = MDX_COLS_OUT(I, n2);
-        MDX_COLS_STORE(0) MDX_COLS_STORE(1) MDX_COLS_STORE(2) MDX_COLS_STORE(3)
-        MDX_COLS_STORE(4) MDX_COLS_STORE(5) MDX_COLS_STORE(6) MDX_COLS_STORE(7)
-#undef MDX_COLS_STORE
+#pragma unroll
+        for (int i = 0; i < OUTS; ++i) {
+            const int k1 = kbase + 64 * i;
+            // W_N^(n2 k1) = W_R1^(m / R2) * W_N^(m mod R2), m = n2 k1 < N
+            const unsigned m = unsigned(k1) * unsigned(n2);
+            const double2 w = cmul(tw_at<R1>(s_h, int(m / R2)), s_n[m & (R2 - 1)]);
+            o[int64_t(64 * i) * k1_stride] = cmul(zb[p][k1], w);
+        }
         __syncthreads();
     }
-#undef MDX_COLS_LOAD1
 #undef MDX_COLS_LOAD
-#undef MDX_COLS_PUT
-#undef MDX_COLS_OUT
 }
 
-// Pass B.  grid (k1 = 512, blocks of the trajectory), 512 threads; thread = k2.
-// Pfull[b][k1][k2] = sum over all pairs of |Z_{k1 + 512 k2}|^2  (overwritten).
-__global__ __launch_bounds__(THREADS, 4) void msd_fft_rows_power_kernel(
-    const double2 *__restrict__ Y, int p_pad, const double2 *__restrict__ tw512,
+// Pass B.  grid (k1 < R1, blocks of the trajectory), 512 threads; thread = k2 (and k2 + 512).
+// Pfull[b][k1][k2] = sum over all pairs of |Z_{k1 + R1 k2}|^2  (overwritten).
+template <int R1, int R2>
+__global__ __launch_bounds__(THREADS, R2 == 512 ? 4 : 2) void msd_fft_rows_power_kernel(
+    const double2 *__restrict__ Y, int p_pad, const double2 *__restrict__ tw_r2,
     double *__restrict__ Pfull)
 {
-    __shared__ double2 zb[PG][ZSTRIDE];
-    __shared__ double2 s_tw[R / 2];
+    constexpr int ZS = R2 + 1;
+    constexpr int LOADS = R2 * PG / THREADS;    // 8 or 16 complex values per thread and group
+    constexpr int OUTS = R2 / THREADS;          // 1 or 2 spectrum lines per thread
+    __shared__ double2 zb[PG][ZS];
+    __shared__ double2 s_tw[R2 / 2];
     const int k1 = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < R / 2)
-        s_tw[tid] = tw512[tid];
-    // Y[b][k1][pair group][n2][pair]: one group's 512 x 8 values are 64 KB contiguous
+    for (int i = tid; i < R2 / 2; i += THREADS)
+        s_tw[i] = tw_r2[i];
+    // Y[b][k1][pair group][n2][pair]: one group's R2 x 8 values are contiguous
     const int n_groups = p_pad / PG;
-    const double2 *src = Y + (int64_t(b) * R + k1) * n_groups * (R * PG) + tid;
-    double acc = 0.0;
-    // eight named registers (an indexed array ends up in scratch memory here)
-#define MDX_ROWS_LOAD(OFF)                                                               \
-    p0 = src[(OFF)], p1 = src[(OFF) + THREADS], p2 = src[(OFF) + 2 * THREADS],            \
-    p3 = src[(OFF) + 3 * THREADS], p4 = src[(OFF) + 4 * THREADS], p5 = src[(OFF) + 5 * THREADS], \
-    p6 = src[(OFF) + 6 * THREADS], p7 = src[(OFF) + 7 * THREADS]
+    const double2 *src = Y + (int64_t(b) * R1 + k1) * n_groups * (R2 * PG) + tid;
+    double acc[OUTS];
+#pragma unroll
+    for (int i = 0; i < OUTS; ++i)
+        acc[i] = 0.0;
+    // LOADS named registers (an indexed array of them is placed in scratch memory here)
+    double2 p0, p1, p2, p3, p4, p5, p6, p7, p8, p9, p10, p11, p12, p13, p14, p15;
+#define MDX_ROWS_EACH(OP)                                                                          \
+    OP(0, p0) OP(1, p1) OP(2, p2) OP(3, p3) OP(4, p4) OP(5, p5) OP(6, p6) OP(7, p7)                 \
+    if (LOADS > 8) { OP(8, p8) OP(9, p9) OP(10, p10) OP(11, p11) OP(12, p12) OP(13, p13)            \
+                     OP(14, p14) OP(15, p15) }
+#define MDX_ROWS_LOAD(I, V) V = src[off + THREADS * (I)];
 #define MDX_ROWS_PUT(I, V)                       \
     {                                            \
         const int idx = tid + THREADS * (I);     \
-        zb[idx & 7][idx >> 3] = (V);             \
+        zb[idx & 7][idx >> 3] = V;               \
     }
-    double2 p0, p1, p2, p3, p4, p5, p6, p7;
-    MDX_ROWS_LOAD(0);
+    {
+        const int64_t off = 0;
+        MDX_ROWS_EACH(MDX_ROWS_LOAD)
+    }
     for (int pg = 0; pg < n_groups; ++pg) {
-        MDX_ROWS_PUT(0, p0) MDX_ROWS_PUT(1, p1) MDX_ROWS_PUT(2, p2) MDX_ROWS_PUT(3, p3)
-        MDX_ROWS_PUT(4, p4) MDX_ROWS_PUT(5, p5) MDX_ROWS_PUT(6, p6) MDX_ROWS_PUT(7, p7)
+        MDX_ROWS_EACH(MDX_ROWS_PUT)
         __syncthreads();
         {   // the next group's rows are in flight during this transform (the last iteration
             // reloads its own group: no branch)
-            const int64_t nxt = int64_t(min(pg + 1, n_groups - 1)) * (R * PG);
-            MDX_ROWS_LOAD(nxt);
+            const int64_t off = int64_t(min(pg + 1, n_groups - 1)) * (R2 * PG);
+            MDX_ROWS_EACH(MDX_ROWS_LOAD)
         }
-        fft512_wave(zb[wave], s_tw, lane, R);
+        fft_wave<R2>(zb[wave], s_tw, lane, R2);
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < PG; ++q) {
-            const double2 v = zb[q][tid];
-            acc = fma(v.x, v.x, fma(v.y, v.y, acc));
-        }
+        for (int i = 0; i < OUTS; ++i)
+#pragma unroll
+            for (int q = 0; q < PG; ++q) {
+                const double2 v = zb[q][tid + THREADS * i];
+                acc[i] = fma(v.x, v.x, fma(v.y, v.y, acc[i]));
+            }
         __syncthreads();
     }
+#undef MDX_ROWS_EACH
 #undef MDX_ROWS_LOAD
 #undef MDX_ROWS_PUT
-    Pfull[(int64_t(b) * R + k1) * R + tid] = acc;
+#pragma unroll
+    for (int i = 0; i < OUTS; ++i)
+        Pfull[(int64_t(b) * R1 + k1) * R2 + tid + THREADS * i] = acc[i];
 }
 
 // P[b][k] += (Pfull[b][k] + Pfull[b][N - k]) / 2 for the half spectrum k <= N/2, with Pfull
-// stored as [k1][k2], k = k1 + 512 k2.
+// stored as [k1][k2], k = k1 + R1 k2.
 __global__ __launch_bounds__(256) void msd_power_fold_kernel(const double *__restrict__ Pfull,
-                                                            int64_t nc, double *__restrict__ P)
+                                                            int r1, int r2, int64_t nc,
+                                                            double *__restrict__ P)
 {
     const int64_t k = int64_t(blockIdx.x) * 256 + threadIdx.x;
     const int b = blockIdx.y;
     if (k >= nc)
         return;
-    const int64_t km = (N - k) & (N - 1);
-    const double *pf = Pfull + int64_t(b) * N;
-    const double s = 0.5 * (pf[(k & (R - 1)) * R + (k >> 9)] + pf[(km & (R - 1)) * R + (km >> 9)]);
+    const int64_t n = int64_t(r1) * r2;
+    const int64_t km = (n - k) & (n - 1);
+    const double *pf = Pfull + int64_t(b) * n;
+    const double s = 0.5 * (pf[(k & (r1 - 1)) * r2 + k / r1] + pf[(km & (r1 - 1)) * r2 + km / r1]);
     P[int64_t(b) * nc + k] += s;
+}
+
+// ------------------------------------------------------------------------------ host side
+
+struct Shape {
+    int r1 = 0, r2 = 0;   // 0: no own transform for this length
+    int64_t n() const { return int64_t(r1) * r2; }
+};
+
+inline Shape shape_for(int64_t n_fft)
+{
+    Shape s;
+    if (n_fft == (int64_t(1) << 18))
+        s.r1 = 512, s.r2 = 512;
+    else if (n_fft == (int64_t(1) << 19))
+        s.r1 = 1024, s.r2 = 512;
+    else if (n_fft == (int64_t(1) << 20))
+        s.r1 = 1024, s.r2 = 1024;
+    return s;
+}
+
+// tw_r1 / tw_r2: half tables exp(-2 pi i m / R), m < R / 2; twN: exp(-2 pi i m / N), m < R2
+inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64_t n_total,
+                   int64_t first, int64_t n_elem, int64_t t_block, int n_blocks, int zero_dims,
+                   int p_pad, const double2 *tw_r1, const double2 *tw_r2, const double2 *twN,
+                   double2 *Y, double *Pfull, int64_t nc, double *P)
+{
+    const dim3 ga((unsigned)(p_pad / PG), COLS_SPLIT, (unsigned)n_blocks);
+    const dim3 gb((unsigned)sh.r1, (unsigned)n_blocks);
+#define MDX_MSDFFT_LAUNCH(A, B)                                                                    \
+    hipLaunchKernelGGL((msd_fft_cols_kernel<A, B>), ga, dim3(THREADS), 0, stream, pos, n_total, first, \
+                       n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y);                          \
+    hipLaunchKernelGGL((msd_fft_rows_power_kernel<A, B>), gb, dim3(THREADS), 0, stream, Y, p_pad,     \
+                       tw_r2, Pfull)
+    if (sh.r1 == 512 && sh.r2 == 512) {
+        MDX_MSDFFT_LAUNCH(512, 512);
+    } else if (sh.r1 == 1024 && sh.r2 == 512) {
+        MDX_MSDFFT_LAUNCH(1024, 512);
+    } else {
+        MDX_MSDFFT_LAUNCH(1024, 1024);
+    }
+#undef MDX_MSDFFT_LAUNCH
+    hipLaunchKernelGGL(msd_power_fold_kernel, dim3((unsigned)((nc + 255) / 256), (unsigned)n_blocks),
+                       dim3(256), 0, stream, Pfull, sh.r1, sh.r2, nc, P);
 }
 
 }  // namespace msdfft
