@@ -394,7 +394,7 @@ struct mdx_rdf {
     DeviceBuffer d_stage1[2], d_stage2[2], d_boxes[2], d_index[2];
     StagePipeline pipe;
     DeviceBuffer d_pw1, d_po1, d_bb1, d_pw2, d_po2, d_bb2;   // cell path: sorted copies + tile boxes
-    DeviceBuffer d_bb16_1, d_bb16_2;                         // boxes of the 16-particle chunks
+    DeviceBuffer d_bb16_1, d_bb16_2;                         // boxes of the CELL_CHUNK-particle chunks
     StreamTimer timer;
     int64_t pairs_evaluated = 0;    // ordered pair space covered: frames * n1 * n2
     int64_t pairs_bruteforce = 0;   // distance evaluations executed by the brute-force tiles
@@ -457,15 +457,15 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
 {
     const int64_t n1p = ceil_div(n1, 128) * 128, n2p = ceil_div(n2, 128) * 128;
     // per frame: wrapped + original float4 copies, one box per 64 and per 16 particles
-    const int64_t per_frame = (32 + 3) * (n1p + (self ? 0 : n2p));
+    const int64_t per_frame = (32 + 1 + 32 / CELL_CHUNK) * (n1p + (self ? 0 : n2p));
     int64_t slab = std::max<int64_t>(1, (int64_t(1) << 30) / per_frame);
     slab = std::min<int64_t>(std::min<int64_t>(slab, 32768), n_frames);
     MDX_TRY(h->d_pw1.ensure(size_t(16) * n1p * slab));
     MDX_TRY(h->d_po1.ensure(size_t(16) * n1p * slab));
     MDX_TRY(h->d_bb1.ensure(size_t(32) * (n1p / 64) * slab));
-    MDX_TRY(h->d_bb16_1.ensure(size_t(32) * (n1p / 16) * slab));
+    MDX_TRY(h->d_bb16_1.ensure(size_t(32) * (n1p / CELL_CHUNK) * slab));
     if (!self) {
-        MDX_TRY(h->d_bb16_2.ensure(size_t(32) * (n2p / 16) * slab));
+        MDX_TRY(h->d_bb16_2.ensure(size_t(32) * (n2p / CELL_CHUNK) * slab));
         MDX_TRY(h->d_pw2.ensure(size_t(16) * n2p * slab));
         MDX_TRY(h->d_po2.ensure(size_t(16) * n2p * slab));
         MDX_TRY(h->d_bb2.ensure(size_t(32) * (n2p / 64) * slab));
@@ -1111,7 +1111,7 @@ int mdx_rdf_stats(mdx_rdf_t h, int64_t *launches, double *kernel_ms, int64_t *pa
         unsigned long long tp = 0;
         if (set_device(h->dev) == MDX_OK && hipStreamSynchronize(h->stream) == hipSuccess &&
             hipMemcpy(&tp, h->d_misc.as<unsigned>() + 4, 8, hipMemcpyDeviceToHost) == hipSuccess)
-            *pairs_computed = h->pairs_bruteforce + (int64_t)tp * 64 * 16;
+            *pairs_computed = h->pairs_bruteforce + (int64_t)tp * 64 * CELL_CHUNK;
     }
     MDX_REQUIRE(h, "NULL handle");
     MDX_TRY(set_device(h->dev));

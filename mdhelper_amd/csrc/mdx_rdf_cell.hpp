@@ -32,13 +32,13 @@ struct CellArgs {
     // per set (1 = i side, 2 = j side; identical pointers for a self histogram)
     const float4 *pw1, *po1, *bb1;
     const float4 *pw2, *po2, *bb2;
-    const float4 *bb16_2;        // boxes of the 16-particle chunks of the j side
+    const float4 *bb16_2;        // boxes of the CELL_CHUNK-particle chunks of the j side
     const float *boxes;          // [frames][6]
     const double *thresh;        // [n_bins+1]
     unsigned long long *counts;  // [n_rep][n_bins]
     const unsigned *maxabs_bits;
     unsigned long long *exact_counter;
-    unsigned long long *tilepair_counter;   // (64 i) x (16 j) units actually evaluated
+    unsigned long long *tilepair_counter;   // (64 i) x (CELL_CHUNK j) units actually evaluated
     double t_lo, t_hi, r0, r1;
     int n1p, n2p;                // padded particle counts (multiples of 128)
     int n_bins, n_hist, n_rep;
@@ -50,6 +50,8 @@ struct CellArgs {
 constexpr int CELL_MAX = 16384;   // cells per frame (64 KiB of LDS counters)
 constexpr int SORT_THREADS = 1024;
 constexpr int CELL_QCAP = 1024;   // surviving j tiles queued per round of the pair kernel
+constexpr int CELL_CHUNK = 8;     // particles per j chunk of the second-level cull (8 or 16)
+constexpr int CELL_NCHUNK = 64 / CELL_CHUNK;
 constexpr int CELL_TODO = 128;    // per-wave list of pairs waiting for the exact arithmetic
 
 struct CellGrid {
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(SORT_THREADS) void rdf_cell_sort_kernel(
     const int lane = tid & 63, wave = tid >> 6;
     const int n_tiles = n_pad / 64;
     float4 *BB = bb + int64_t(frame) * n_tiles * 2;
-    float4 *BB16 = bb16 + int64_t(frame) * n_tiles * 8;
+    float4 *BB16 = bb16 + int64_t(frame) * n_tiles * 2 * CELL_NCHUNK;
     for (int t = wave; t < n_tiles; t += SORT_THREADS / 64) {
         float4 v = PW[t * 64 + lane];
         const float inf = __int_as_float(0x7f800000);
@@ -205,9 +207,10 @@ __global__ __launch_bounds__(SORT_THREADS) void rdf_cell_sort_kernel(
                 lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
                 hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
             }
-            if (off == 8 && (lane & 15) == 0) {
-                BB16[(t * 4 + (lane >> 4)) * 2] = make_float4(lo[0], lo[1], lo[2], 0.f);
-                BB16[(t * 4 + (lane >> 4)) * 2 + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+            if (off == CELL_CHUNK / 2 && (lane & (CELL_CHUNK - 1)) == 0) {
+                const int c = t * CELL_NCHUNK + lane / CELL_CHUNK;
+                BB16[c * 2] = make_float4(lo[0], lo[1], lo[2], 0.f);
+                BB16[c * 2 + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
             }
         }
         if (lane == 0) {
@@ -501,7 +504,7 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
     const float4 *PW2 = a.pw2 + int64_t(frame) * a.n2p;
     const float4 *PO2 = a.po2 + int64_t(frame) * a.n2p;
     const float4 *BB2 = a.bb2 + int64_t(frame) * t64_2 * 2;
-    const float4 *BB16 = a.bb16_2 + int64_t(frame) * t64_2 * 8;
+    const float4 *BB16 = a.bb16_2 + int64_t(frame) * t64_2 * 2 * CELL_NCHUNK;
     const float4 p0 = PW1[lane], p1 = PW1[64 + lane];
 
     float4 *sJw = sJ + wave * 64;
@@ -581,13 +584,14 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
                 pj.y -= sy;
                 pj.z -= sz;
             }
-            // second-level cull: lane l < 8 tests (16-particle chunk l>>1) x (i half l&1)
-            unsigned sub = 0xffu;
+            // second-level cull: lane l < 2 CELL_NCHUNK tests (j chunk l>>1) x (i half l&1)
+            unsigned sub = (1u << (2 * CELL_NCHUNK)) - 1u;
             if (!gen) {
                 float sg2 = __int_as_float(0x7f800000);
-                if (lane < 8) {
+                if (lane < 2 * CELL_NCHUNK) {
                     const int s = lane >> 1, h = lane & 1;
-                    const float4 lo = BB16[(Jt * 4 + s) * 2], hi = BB16[(Jt * 4 + s) * 2 + 1];
+                    const float4 lo = BB16[(Jt * CELL_NCHUNK + s) * 2],
+                                 hi = BB16[(Jt * CELL_NCHUNK + s) * 2 + 1];
                     const float cJ[3] = {0.5f * (lo.x + hi.x) - sx, 0.5f * (lo.y + hi.y) - sy,
                                          0.5f * (lo.z + hi.z) - sz};
                     const float hJ[3] = {0.5f * (hi.x - lo.x), 0.5f * (hi.y - lo.y), 0.5f * (hi.z - lo.z)};
@@ -599,7 +603,7 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
                         sg2 = __fmaf_rn(gap, gap, sg2);
                     }
                 }
-                sub = (unsigned)__ballot(sg2 <= s_geo[7]) & 0xffu;
+                sub = (unsigned)__ballot(sg2 <= s_geo[7]) & ((1u << (2 * CELL_NCHUNK)) - 1u);
             }
             // wave-private slab: LDS operations of one wave execute in order
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -612,7 +616,7 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
             // exclusion tags can only collide inside the diagonal tiles when exclusion == (1, 1)
             const bool tags = EXCL && (a.tags_everywhere || diag);
             if (!gen) {
-                for (int s = 0; s < 4; ++s) {
+                for (int s = 0; s < CELL_NCHUNK; ++s) {
                     const unsigned bits = (sub >> (2 * s)) & 3u;
                     if (!bits)
                         continue;
@@ -630,8 +634,8 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
     /* the global j index lives in a scalar register of its own: derived from the loop counter  \
        it would be recomputed with a vector add at every step although only the cold block      \
        reads it */                                                                              \
-    unsigned jg = __builtin_amdgcn_readfirstlane(jbase + 16u * unsigned(s));                       \
-    for (int jj = 16 * s; jj < 16 * s + 16; jj += 4, jg += 4u) {                                   \
+    unsigned jg = __builtin_amdgcn_readfirstlane(jbase + unsigned(CELL_CHUNK * s));                \
+    for (int jj = CELL_CHUNK * s; jj < CELL_CHUNK * (s + 1); jj += 4, jg += 4u) {                  \
         const float4 q0 = sJw[jj], q1 = sJw[jj + 1], q2 = sJw[jj + 2], q3 = sJw[jj + 3];           \
         /* keep the 16-byte reads whole: ds_read_b96 costs 8 LDS cycles, ds_read_b128 4 */        \
         asm volatile("" ::"v"(q0.w), "v"(q1.w), "v"(q2.w), "v"(q3.w));                             \
@@ -655,14 +659,14 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
                     if (__builtin_expect(wv.overflow != 0u, 0)) {
                         wv.overflow = 0u;
                         wv.n_todo = mark;
-                        if (GH) cell_slow_unit<LOWER, EXCL>(hot, a, thr, hg, sJw, 16 * s, 16, bits, tags, false, s_geo, p0, p1, PO1f, PO2, i_idx0, jbase, w, wv);
-                        else cell_slow_unit<LOWER, EXCL>(hot, a, thr, hl, sJw, 16 * s, 16, bits, tags, false, s_geo, p0, p1, PO1f, PO2, i_idx0, jbase, w, wv);
+                        if (GH) cell_slow_unit<LOWER, EXCL>(hot, a, thr, hg, sJw, CELL_CHUNK * s, CELL_CHUNK, bits, tags, false, s_geo, p0, p1, PO1f, PO2, i_idx0, jbase, w, wv);
+                        else cell_slow_unit<LOWER, EXCL>(hot, a, thr, hl, sJw, CELL_CHUNK * s, CELL_CHUNK, bits, tags, false, s_geo, p0, p1, PO1f, PO2, i_idx0, jbase, w, wv);
                     }
                 }
             } else {
                 // tile pair that straddles half a box: per-pair image search (float32), rare
-                n_units += 8;
-                n_general += 8;
+                n_units += 2 * CELL_NCHUNK;
+                n_general += 2 * CELL_NCHUNK;
                 const unsigned mark = wv.n_todo;
 #pragma unroll 2
                 for (int jj = 0; jj < 64; ++jj) {
