@@ -50,7 +50,7 @@ struct CellArgs {
 constexpr int CELL_MAX = 16384;   // cells per frame (64 KiB of LDS counters)
 constexpr int SORT_THREADS = 1024;
 constexpr int CELL_QCAP = 1024;   // surviving j tiles queued per round of the pair kernel
-constexpr int CELL_CHUNK = 8;     // particles per j chunk of the second-level cull (8 or 16)
+constexpr int CELL_CHUNK = 4;     // particles per j chunk of the second-level cull (8 or 16)
 constexpr int CELL_NCHUNK = 64 / CELL_CHUNK;
 constexpr int CELL_TODO = 128;    // per-wave list of pairs waiting for the exact arithmetic
 
@@ -585,7 +585,8 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
                 pj.z -= sz;
             }
             // second-level cull: lane l < 2 CELL_NCHUNK tests (j chunk l>>1) x (i half l&1)
-            unsigned sub = (1u << (2 * CELL_NCHUNK)) - 1u;
+            constexpr unsigned SUB_ALL = CELL_NCHUNK == 16 ? 0xffffffffu : ((1u << (2 * (CELL_NCHUNK & 15))) - 1u);
+            unsigned sub = SUB_ALL;
             if (!gen) {
                 float sg2 = __int_as_float(0x7f800000);
                 if (lane < 2 * CELL_NCHUNK) {
@@ -603,7 +604,7 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
                         sg2 = __fmaf_rn(gap, gap, sg2);
                     }
                 }
-                sub = (unsigned)__ballot(sg2 <= s_geo[7]) & ((1u << (2 * CELL_NCHUNK)) - 1u);
+                sub = (unsigned)__ballot(sg2 <= s_geo[7]) & SUB_ALL;
             }
             // wave-private slab: LDS operations of one wave execute in order
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
