@@ -457,15 +457,17 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
 {
     const int64_t n1p = ceil_div(n1, 128) * 128, n2p = ceil_div(n2, 128) * 128;
     // per frame: wrapped + original float4 copies, one box per 64 and per 16 particles
-    const int64_t per_frame = (32 + 1 + 32 / CELL_CHUNK) * (n1p + (self ? 0 : n2p));
+    // (two-particle chunks take their boxes from the staged rows: no chunk-box array)
+    constexpr int64_t CHUNK_BOX_BYTES = CELL_CHUNK >= 4 ? 32 / CELL_CHUNK : 0;
+    const int64_t per_frame = (32 + 1 + CHUNK_BOX_BYTES) * (n1p + (self ? 0 : n2p));
     int64_t slab = std::max<int64_t>(1, (int64_t(1) << 30) / per_frame);
     slab = std::min<int64_t>(std::min<int64_t>(slab, 32768), n_frames);
     MDX_TRY(h->d_pw1.ensure(size_t(16) * n1p * slab));
     MDX_TRY(h->d_po1.ensure(size_t(16) * n1p * slab));
     MDX_TRY(h->d_bb1.ensure(size_t(32) * (n1p / 64) * slab));
-    MDX_TRY(h->d_bb16_1.ensure(size_t(32) * (n1p / CELL_CHUNK) * slab));
+    MDX_TRY(h->d_bb16_1.ensure(CELL_CHUNK >= 4 ? size_t(32) * (n1p / CELL_CHUNK) * slab : 256));
     if (!self) {
-        MDX_TRY(h->d_bb16_2.ensure(size_t(32) * (n2p / CELL_CHUNK) * slab));
+        MDX_TRY(h->d_bb16_2.ensure(CELL_CHUNK >= 4 ? size_t(32) * (n2p / CELL_CHUNK) * slab : 256));
         MDX_TRY(h->d_pw2.ensure(size_t(16) * n2p * slab));
         MDX_TRY(h->d_po2.ensure(size_t(16) * n2p * slab));
         MDX_TRY(h->d_bb2.ensure(size_t(32) * (n2p / 64) * slab));

@@ -50,7 +50,7 @@ struct CellArgs {
 constexpr int CELL_MAX = 16384;   // cells per frame (64 KiB of LDS counters)
 constexpr int SORT_THREADS = 1024;
 constexpr int CELL_QCAP = 1024;   // surviving j tiles queued per round of the pair kernel
-constexpr int CELL_CHUNK = 4;     // particles per j chunk of the second-level cull (8 or 16)
+constexpr int CELL_CHUNK = 2;     // particles per j chunk of the second-level cull (2, 4, 8, 16)
 constexpr int CELL_NCHUNK = 64 / CELL_CHUNK;
 constexpr int CELL_TODO = 128;    // per-wave list of pairs waiting for the exact arithmetic
 
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(SORT_THREADS) void rdf_cell_sort_kernel(
                 lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
                 hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
             }
-            if (off == CELL_CHUNK / 2 && (lane & (CELL_CHUNK - 1)) == 0) {
+            if (CELL_CHUNK >= 4 && off == CELL_CHUNK / 2 && (lane & (CELL_CHUNK - 1)) == 0) {
                 const int c = t * CELL_NCHUNK + lane / CELL_CHUNK;
                 BB16[c * 2] = make_float4(lo[0], lo[1], lo[2], 0.f);
                 BB16[c * 2 + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
@@ -584,12 +584,28 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
                 pj.y -= sy;
                 pj.z -= sz;
             }
-            // second-level cull: lane l < 2 CELL_NCHUNK tests (j chunk l>>1) x (i half l&1)
-            constexpr unsigned SUB_ALL = CELL_NCHUNK == 16 ? 0xffffffffu : ((1u << (2 * (CELL_NCHUNK & 15))) - 1u);
-            unsigned sub = SUB_ALL;
+            // second-level cull: lane l tests (j chunk l>>1) x (i half l&1) — 2 CELL_NCHUNK tests
+            constexpr unsigned long long SUB_ALL =
+                CELL_NCHUNK == 32 ? ~0ull : ((1ull << (2 * (CELL_NCHUNK & 31))) - 1ull);
+            unsigned long long sub = SUB_ALL;
             if (!gen) {
                 float sg2 = __int_as_float(0x7f800000);
-                if (lane < 2 * CELL_NCHUNK) {
+                if (CELL_CHUNK == 2) {
+                    // chunk = lane pair: its box comes from the staged rows themselves (one
+                    // cross-lane exchange), no box array; NaN padding drops out of fmin / fmax,
+                    // a chunk of two padding rows gives NaN and fails the comparison below
+                    const int h = lane & 1;
+                    const float ox = __shfl_xor(pj.x, 1), oy = __shfl_xor(pj.y, 1), oz = __shfl_xor(pj.z, 1);
+                    const float lo[3] = {fminf(pj.x, ox), fminf(pj.y, oy), fminf(pj.z, oz)};
+                    const float hi[3] = {fmaxf(pj.x, ox), fmaxf(pj.y, oy), fmaxf(pj.z, oz)};
+                    sg2 = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        float gap = fmaxf(0.f, fabsf(0.5f * (lo[k] + hi[k]) - s_geo[14 + 3 * h + k]) -
+                                                   (s_geo[20 + 3 * h + k] + 0.5f * (hi[k] - lo[k])));
+                        sg2 = __fmaf_rn(gap, gap, sg2);
+                    }
+                } else if (lane < 2 * CELL_NCHUNK) {
                     const int s = lane >> 1, h = lane & 1;
                     const float4 lo = BB16[(Jt * CELL_NCHUNK + s) * 2],
                                  hi = BB16[(Jt * CELL_NCHUNK + s) * 2 + 1];
@@ -604,7 +620,7 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
                         sg2 = __fmaf_rn(gap, gap, sg2);
                     }
                 }
-                sub = (unsigned)__ballot(sg2 <= s_geo[7]) & SUB_ALL;
+                sub = __ballot(sg2 <= s_geo[7]) & SUB_ALL;
             }
             // wave-private slab: LDS operations of one wave execute in order
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -617,49 +633,56 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
             // exclusion tags can only collide inside the diagonal tiles when exclusion == (1, 1)
             const bool tags = EXCL && (a.tags_everywhere || diag);
             if (!gen) {
-                for (int s = 0; s < CELL_NCHUNK; ++s) {
-                    const unsigned bits = (sub >> (2 * s)) & 3u;
-                    if (!bits)
-                        continue;
-                    n_units += (bits & 1u) + (bits >> 1);
-#define MDX_CELL_ONE(TG, U0, U1, Q, JJ)                                                            \
-    if (GH) {                                                                                      \
-        if (U0) cell_step<LOWER, TG, MODE>(hot, a, hg, Q.x - p0.x, Q.y - p0.y, Q.z - p0.z, __float_as_int(p0.w), __float_as_int(Q.w), i_base0, (JJ), w, wv); \
-        if (U1) cell_step<LOWER, TG, MODE>(hot, a, hg, Q.x - p1.x, Q.y - p1.y, Q.z - p1.z, __float_as_int(p1.w), __float_as_int(Q.w), i_base0 + 64u, (JJ), w, wv); \
-    } else {                                                                                       \
-        if (U0) cell_step<LOWER, TG, MODE>(hot, a, hl, Q.x - p0.x, Q.y - p0.y, Q.z - p0.z, __float_as_int(p0.w), __float_as_int(Q.w), i_base0, (JJ), w, wv); \
-        if (U1) cell_step<LOWER, TG, MODE>(hot, a, hl, Q.x - p1.x, Q.y - p1.y, Q.z - p1.z, __float_as_int(p1.w), __float_as_int(Q.w), i_base0 + 64u, (JJ), w, wv); \
+                // The surviving (chunk, half) units of this tile.  Bookkeeping is per tile, not per
+                // unit: one roll-back mark, one overflow test, one popcount for the statistics.
+                const unsigned mark = wv.n_todo;
+                n_units += (unsigned)__popcll(sub);
+#define MDX_CELL_HALF(TG, P, IB, Q, JJ)                                                            \
+    if (GH) cell_step<LOWER, TG, MODE>(hot, a, hg, Q.x - P.x, Q.y - P.y, Q.z - P.z, __float_as_int(P.w), __float_as_int(Q.w), IB, (JJ), w, wv); \
+    else cell_step<LOWER, TG, MODE>(hot, a, hl, Q.x - P.x, Q.y - P.y, Q.z - P.z, __float_as_int(P.w), __float_as_int(Q.w), IB, (JJ), w, wv);
+// one unit: CELL_CHUNK slab rows (whole 16-byte reads: ds_read_b96 costs 8 LDS cycles,
+// ds_read_b128 4) against the i halves that survived; the global j index is scalar
+#define MDX_CELL_UNITS(TG)                                                                         \
+    for (unsigned long long rem = sub; rem;) {                                                     \
+        const int s = __builtin_ctzll(rem) >> 1;                                                   \
+        const unsigned bits = unsigned(rem >> (2 * s)) & 3u;                                       \
+        rem &= ~(3ull << (2 * s));                                                                 \
+        const unsigned jg = jbase + unsigned(CELL_CHUNK * s);                                      \
+        float4 q[CELL_CHUNK];                                                                      \
+        _Pragma("unroll") for (int c = 0; c < CELL_CHUNK; ++c)                                     \
+        {                                                                                          \
+            q[c] = sJw[CELL_CHUNK * s + c];                                                        \
+            asm volatile("" ::"v"(q[c].w));                                                        \
+        }                                                                                          \
+        if (bits & 1u) {                                                                           \
+            _Pragma("unroll") for (int c = 0; c < CELL_CHUNK; ++c)                                 \
+            {                                                                                      \
+                MDX_CELL_HALF(TG, p0, i_base0, q[c], jg + unsigned(c))                             \
+            }                                                                                      \
+        }                                                                                          \
+        if (bits & 2u) {                                                                           \
+            _Pragma("unroll") for (int c = 0; c < CELL_CHUNK; ++c)                                 \
+            {                                                                                      \
+                MDX_CELL_HALF(TG, p1, i_base0 + 64u, q[c], jg + unsigned(c))                       \
+            }                                                                                      \
+        }                                                                                          \
     }
-// four slab entries are fetched ahead of their use so the LDS latency overlaps the arithmetic
-#define MDX_CELL_RUN(TG, U0, U1)                                                                   \
-    /* the global j index lives in a scalar register of its own: derived from the loop counter  \
-       it would be recomputed with a vector add at every step although only the cold block      \
-       reads it */                                                                              \
-    unsigned jg = __builtin_amdgcn_readfirstlane(jbase + unsigned(CELL_CHUNK * s));                \
-    for (int jj = CELL_CHUNK * s; jj < CELL_CHUNK * (s + 1); jj += 4, jg += 4u) {                  \
-        const float4 q0 = sJw[jj], q1 = sJw[jj + 1], q2 = sJw[jj + 2], q3 = sJw[jj + 3];           \
-        /* keep the 16-byte reads whole: ds_read_b96 costs 8 LDS cycles, ds_read_b128 4 */        \
-        asm volatile("" ::"v"(q0.w), "v"(q1.w), "v"(q2.w), "v"(q3.w));                             \
-        MDX_CELL_ONE(TG, U0, U1, q0, jg)                                                           \
-        MDX_CELL_ONE(TG, U0, U1, q1, jg + 1u)                                                      \
-        MDX_CELL_ONE(TG, U0, U1, q2, jg + 2u)                                                      \
-        MDX_CELL_ONE(TG, U0, U1, q3, jg + 3u)                                                      \
-    }
-                    const unsigned mark = wv.n_todo;
-                    if (tags) {
-                        if (bits == 3u) { MDX_CELL_RUN(1, true, true) }
-                        else if (bits == 1u) { MDX_CELL_RUN(1, true, false) }
-                        else { MDX_CELL_RUN(1, false, true) }
-                    } else {
-                        if (bits == 3u) { MDX_CELL_RUN(0, true, true) }
-                        else if (bits == 1u) { MDX_CELL_RUN(0, true, false) }
-                        else { MDX_CELL_RUN(0, false, true) }
-                    }
-#undef MDX_CELL_RUN
-#undef MDX_CELL_ONE
-                    if (__builtin_expect(wv.overflow != 0u, 0)) {
-                        wv.overflow = 0u;
-                        wv.n_todo = mark;
+                if (tags) {
+                    MDX_CELL_UNITS(1)
+                } else {
+                    MDX_CELL_UNITS(0)
+                }
+#undef MDX_CELL_UNITS
+#undef MDX_CELL_HALF
+                if (__builtin_expect(wv.overflow != 0u, 0)) {
+                    // the list filled up somewhere in this tile (adversarial inputs): back to the
+                    // mark, then every unit again, undecided pairs only, flushing as needed
+                    wv.overflow = 0u;
+                    wv.n_todo = mark;
+                    for (unsigned long long rem = sub; rem;) {
+                        const int s = __builtin_ctzll(rem) >> 1;
+                        const unsigned bits = unsigned(rem >> (2 * s)) & 3u;
+                        rem &= ~(3ull << (2 * s));
                         if (GH) cell_slow_unit<LOWER, EXCL>(hot, a, thr, hg, sJw, CELL_CHUNK * s, CELL_CHUNK, bits, tags, false, s_geo, p0, p1, PO1f, PO2, i_idx0, jbase, w, wv);
                         else cell_slow_unit<LOWER, EXCL>(hot, a, thr, hl, sJw, CELL_CHUNK * s, CELL_CHUNK, bits, tags, false, s_geo, p0, p1, PO1f, PO2, i_idx0, jbase, w, wv);
                     }
