@@ -649,11 +649,10 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
         rem &= ~(3ull << (2 * s));                                                                 \
         const unsigned jg = jbase + unsigned(CELL_CHUNK * s);                                      \
         float4 q[CELL_CHUNK];                                                                      \
-        _Pragma("unroll") for (int c = 0; c < CELL_CHUNK; ++c)                                     \
-        {                                                                                          \
-            q[c] = sJw[CELL_CHUNK * s + c];                                                        \
-            asm volatile("" ::"v"(q[c].w));                                                        \
-        }                                                                                          \
+        _Pragma("unroll") for (int c = 0; c < CELL_CHUNK; ++c) q[c] = sJw[CELL_CHUNK * s + c];     \
+        /* all reads issued before any is waited for; .w kept alive = whole 16-byte reads */       \
+        if (CELL_CHUNK == 2) asm volatile("" ::"v"(q[0].w), "v"(q[1].w));                          \
+        else _Pragma("unroll") for (int c = 0; c < CELL_CHUNK; ++c) asm volatile("" ::"v"(q[c].w)); \
         if (bits & 1u) {                                                                           \
             _Pragma("unroll") for (int c = 0; c < CELL_CHUNK; ++c)                                 \
             {                                                                                      \
