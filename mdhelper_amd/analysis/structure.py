@@ -546,6 +546,8 @@ class StructureFactor(NumbaAnalysisBase):
         block = 4096 if native is not None else self._batch.capacity
         for b0 in np.arange(0, len(mine), block):
             sel = mine[b0:b0 + block]
+            if self._engine is None:       # an ISF rank without wavevectors of its own
+                break
             if native is not None:
                 self._engine.accumulate_traj(native, sel, None if identity else index)
             else:
@@ -636,10 +638,17 @@ class IntermediateScatteringFunction(StructureFactor):
         self.results.wavenumbers = (np.unique(self._wavenumbers.round(11))
                                     if self._unique else self._wavenumbers)
         self.results.units = {"results.times": "picosecond", "results.wavenumbers": "angstrom^-1"}
-        self._engine = _core.IsfEngine(self._wavevectors, self._Ns, self.results.pairs,
-                                       self._n_lags, self._incoherent, dev=self._device)
-        self._batch = FrameBatcher(int(self._N), lambda p, b: self._engine.accumulate(p[0]),
-                                   with_box=False, max_bytes=64 << 20)
+        # multi-GPU: the lag products of different wavevectors never meet, so every rank sees all
+        # frames and owns a contiguous block of wavevectors (frames cannot shard: every lag is needed)
+        self._q_mine = shard_range(len(self._wavevectors), self._comm.rank, self._comm.world_size)
+        lo, hi = self._q_mine
+        self._engine = None
+        if hi > lo:
+            self._engine = _core.IsfEngine(self._wavevectors[lo:hi], self._Ns, self.results.pairs,
+                                           self._n_lags, self._incoherent, dev=self._device)
+        self._batch = FrameBatcher(
+            int(self._N), lambda p, b: self._engine.accumulate(p[0]) if self._engine else None,
+            with_box=False, max_bytes=64 << 20)
         self._positions = np.empty((self._N, 3), dtype=np.float32)
 
     def _single_frame(self) -> None:
@@ -649,8 +658,22 @@ class IntermediateScatteringFunction(StructureFactor):
 
     def _conclude(self) -> None:
         self._batch.flush()
-        cisf, iisf = self._engine.result()
-        self._engine.close()
+        n_q = len(self._wavevectors)
+        n_p = 1 if self._mode is None else len(self.results.pairs)
+        n_s = 1 if self._mode is None else self._n_groups
+        cisf = np.zeros((self._n_lags, n_p, n_q))
+        iisf = np.zeros((self._n_lags, n_s, n_q)) if self._incoherent else None
+        lo, hi = self._q_mine
+        if self._engine is not None:
+            c, i = self._engine.result()
+            self._engine.close()
+            cisf[:, :, lo:hi] = c
+            if self._incoherent:
+                iisf[:, :, lo:hi] = i
+        if self._comm.world_size > 1:      # disjoint blocks: the sum is a gather
+            cisf = self._comm.allreduce(cisf)
+            if self._incoherent:
+                iisf = self._comm.allreduce(iisf)
         normalization = (self._N * np.arange(self.n_frames, self.n_frames - self._n_lags, -1)
                          [:, None, None])
         self.results.cisf = cisf / normalization
