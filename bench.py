@@ -318,8 +318,9 @@ def bench_sq(args, world):
         "frames_per_sec": args.steps * F * world.world / dt,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "sq_rho_lattice_kernel (grid wavevectors: separable phase tables in LDS)",
-                     "note": "fp64 VALU / LDS bound: two complex multiplies + three 16-B LDS reads per "
+                     "kernel": "sq_rho_columns_kernel (grid wavevectors: separable phase tables in LDS, "
+                               "columns of common (m_x, m_y))",
+                     "note": "fp64 VALU / LDS bound: 4.5 FMA-class operations + 1.25 16-B LDS reads per "
                              "evaluation; non-lattice wavevector sets take sq_rho_kernel (~40 fp64 instr each)",
                      "valu": {"evaluations_per_sec_kernel": evals / max(kernel_s, 1e-9)}},
         "checksum": float(ssf.sum()),

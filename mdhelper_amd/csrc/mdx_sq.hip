@@ -125,6 +125,12 @@ struct mdx_sq {
     bool lattice = false;        // wavevectors are integer multiples of one base per axis
     SqLattice lat{};
     size_t lat_lds = 0;
+    // column form of the lattice path (mdx_sq_device.hpp): items, block size, its own tile
+    bool columns = false;
+    int n_items = 0, col_threads = 0;
+    SqLattice col_lat{};
+    size_t col_lds = 0;
+    DeviceBuffer d_items;
 };
 
 static int sq_accumulate_device(mdx_sq *h, const float *d_pos, int64_t n, int64_t n_frames)
@@ -133,7 +139,8 @@ static int sq_accumulate_device(mdx_sq *h, const float *d_pos, int64_t n, int64_
         return MDX_OK;
     MDX_REQUIRE(n >= h->n_total, "positions hold %lld particles but the groups span %lld",
                 (long long)n, (long long)h->n_total);
-    const int qblocks = (int)ceil_div(h->n_q, SQ_QPB);
+    const int qblocks = h->columns ? (int)ceil_div(h->n_items, h->col_threads)
+                                   : (int)ceil_div(h->n_q, SQ_QPB);
     // split the particles when frames x q-blocks x groups alone would not fill 256 CUs
     int64_t max_group = 0;
     for (int g = 0; g < h->n_groups; ++g)
@@ -150,7 +157,13 @@ static int sq_accumulate_device(mdx_sq *h, const float *d_pos, int64_t n, int64_
     hipEvent_t ev = h->timer.begin();
     for (int64_t f0 = 0; f0 < n_frames; f0 += slab) {
         const int64_t nf = std::min(slab, n_frames - f0);
-        if (h->lattice)
+        if (h->columns)
+            hipLaunchKernelGGL(sq_rho_columns_kernel, dim3(qblocks, h->n_groups * n_split, (unsigned)nf),
+                               dim3(h->col_threads), h->col_lds, h->stream, d_pos + f0 * n * 3, n,
+                               h->d_items.as<SqColumnItem>(), h->n_items, (int)h->n_q, h->col_lat,
+                               h->d_offsets.as<int64_t>(), h->n_groups, n_split,
+                               h->d_rho.as<double2>());
+        else if (h->lattice)
             hipLaunchKernelGGL(sq_rho_lattice_kernel, dim3(qblocks, h->n_groups * n_split, (unsigned)nf),
                                dim3(SQ_THREADS), h->lat_lds, h->stream, d_pos + f0 * n * 3, n,
                                h->d_mtrip.as<short4>(), (int)h->n_q, h->lat,
@@ -228,6 +241,28 @@ int mdx_sq_create(mdx_sq_t *out, int dev, const double *wavevectors, int64_t n_q
                 rc = fail(MDX_ERR_HIP, "lattice table setup failed");
                 break;
             }
+            std::vector<SqColumnItem> items;
+            if (!getenv("MDX_SQ_NO_COLUMNS") && sq_build_columns(trip, n_q, h->lat, items)) {
+                h->n_items = (int)items.size();
+                const int waves = (int)std::min<int64_t>(4, ceil_div(h->n_items, 64));
+                h->col_threads = 64 * waves;
+                // tables sized for ~24 waves per CU: 150 KB / (24 / waves) per block
+                const int total_r = h->lat.R[0] + h->lat.R[1] + h->lat.R[2];
+                const size_t budget = size_t(150) * 1024 * waves / 24;
+                const int tile = (int)std::min<size_t>(64, budget / (size_t(16) * total_r));
+                if (tile >= 4) {
+                    h->col_lat = h->lat;
+                    h->col_lat.tile = tile;
+                    h->col_lds = size_t(16) * tile * total_r;
+                    if ((rc = h->d_items.ensure(sizeof(SqColumnItem) * items.size())) != MDX_OK) break;
+                    if (hipMemcpy(h->d_items.ptr, items.data(), sizeof(SqColumnItem) * items.size(),
+                                  hipMemcpyHostToDevice) != hipSuccess) {
+                        rc = fail(MDX_ERR_HIP, "column table upload failed");
+                        break;
+                    }
+                    h->columns = true;
+                }
+            }
         }
     } while (0);
     if (rc != MDX_OK) {
@@ -248,7 +283,7 @@ int mdx_sq_destroy(mdx_sq_t h)
     h->timer.destroy();
     h->pipe.destroy();
     for (DeviceBuffer *b : {&h->d_q, &h->d_offsets, &h->d_pairs, &h->d_acc, &h->d_rho, &h->d_stage[0],
-                            &h->d_stage[1], &h->d_index, &h->d_mtrip})
+                            &h->d_stage[1], &h->d_index, &h->d_mtrip, &h->d_items})
         b->release();
     if (h->stream)
         (void)hipStreamDestroy(h->stream);

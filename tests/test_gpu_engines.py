@@ -551,3 +551,35 @@ def test_isf_lattice_tables_equal_general_sincos_path(mode, monkeypatch):
     norm = N * np.arange(F, F - 6, -1)[:, None, None]
     assert np.allclose(out["lattice"][0] / norm, ref["cisf"], rtol=1e-6, atol=1e-9 * np.abs(ref["cisf"]).max())
     assert np.allclose(out["lattice"][1] / norm, ref["iisf"], rtol=1e-6, atol=1e-9)
+
+
+def test_sq_column_form_equals_lattice_and_general_kernels(monkeypatch):
+    """Grid wavevector sets through the three S(q) kernels: column form (default), per-q lattice
+    tables (MDX_SQ_NO_COLUMNS) and general fp64 sincos (MDX_SQ_NO_LATTICE)."""
+    rng = np.random.default_rng(81)
+    F, sizes, L = 5, (1700, 1301), np.array([31.0, 29.5, 33.25])
+    N = sum(sizes)
+    pos = (rng.random((F, N, 3)) * L).astype(np.float32)
+    grid = np.stack(np.meshgrid(*[2 * np.pi * np.arange(-3, 4) / x for x in L], indexing="ij"), -1).reshape(-1, 3)
+    sets = {"full 7^3 grid": grid,
+            "sphere |q| < 0.5": grid[np.linalg.norm(grid, axis=1) < 0.5],
+            "ragged columns": grid[rng.random(len(grid)) < 0.6]}
+    pairs = of.ssf_pairs(2, "partial")
+    for name, q in sets.items():
+        out = {}
+        for kind, env in (("columns", {}), ("lattice", {"MDX_SQ_NO_COLUMNS": "1"}),
+                          ("general", {"MDX_SQ_NO_LATTICE": "1"})):
+            for k in ("MDX_SQ_NO_COLUMNS", "MDX_SQ_NO_LATTICE"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            eng = _core.SqEngine(q, sizes, pairs)
+            eng.accumulate(pos)
+            out[kind] = eng.result()
+            eng.close()
+        scale = np.abs(out["general"]).max()
+        assert np.allclose(out["columns"], out["general"], rtol=1e-9, atol=1e-9 * scale), name
+        assert np.allclose(out["lattice"], out["general"], rtol=1e-9, atol=1e-9 * scale), name
+    slices = [slice(0, sizes[0]), slice(sizes[0], N)]
+    ref = sum(of.ssf_frame_ref(q, pos[f].astype(np.float64), slices, pairs, "partial") for f in range(F))
+    assert np.allclose(out["columns"], ref, rtol=1e-6, atol=1e-9 * np.abs(ref).max())
