@@ -167,6 +167,8 @@ def bench_rdf(args, world, wide=False):
 
     for _ in range(args.warmup):
         step()
+    if world.comm is not None and args.warmup:
+        eng.allreduce(world.comm)      # the collective's first call (connection set-up) is warm-up too
     eng.synchronize()
     eng.reset()
 
@@ -295,6 +297,8 @@ def bench_sq(args, world):
 
     for _ in range(args.warmup):
         step()
+    if world.comm is not None and args.warmup:
+        eng.allreduce(world.comm)
     eng.result()
     eng.reset()
 
