@@ -26,5 +26,9 @@ Pinning status:
   brute-force/orthorhombic algorithm of ``MDAnalysis/lib/src/calc_distances.h``
   as stated in SURVEY.md §8(a-1) and is anchored on the reference's own
   call site (``structure.py:92-104``) and its ``radial_histogram`` test
-  geometry (``tests/test_analysis_structure.py:21-40``).
+  geometry (``tests/test_analysis_structure.py:21-40``).  The same holds for
+  triclinic cells (``triclinic_vectors`` / ``triclinic_wrap`` /
+  ``pair_distances_triclinic``: MDAnalysis' ``_triclinic_pbc`` +
+  ``minimum_image_triclinic`` restated, **parity unpinned**; checked against a wide
+  lattice search for the true minimum image in ``tests/test_oracle_rdf.py``).
 """
