@@ -452,9 +452,12 @@ static int launch_tiles(mdx_rdf *h, RdfArgs &a, int mode, int ipt, bool pbc, boo
 }
 
 // Cell-sorted path (mdx_rdf_cell.hpp): sort + tile boxes per frame, then the culled pair kernel.
+// d_tri != nullptr: triclinic frames, d_tri = their cell matrices [n_frames][9] (d_boxes unused)
 static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const float *d_pos2,
-                           int64_t n2, const float *d_boxes, int64_t n_frames, bool self, bool excl)
+                           int64_t n2, const float *d_boxes, int64_t n_frames, bool self, bool excl,
+                           const float *d_tri = nullptr)
 {
+    const bool tri = d_tri != nullptr;
     const int64_t n1p = ceil_div(n1, 128) * 128, n2p = ceil_div(n2, 128) * 128;
     // per frame: wrapped + original float4 copies, one box per 64 and per 16 particles
     // (two-particle chunks take their boxes from the staged rows: no chunk-box array)
@@ -473,8 +476,9 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
         MDX_TRY(h->d_bb2.ensure(size_t(32) * (n2p / 64) * slab));
     }
     unsigned *d_misc = h->d_misc.as<unsigned>();
-    hipLaunchKernelGGL(rdf_check_boxes_kernel, dim3((unsigned)ceil_div(n_frames, 256)), dim3(256), 0,
-                       h->stream, d_boxes, n_frames, d_misc + 1);
+    if (!tri)
+        hipLaunchKernelGGL(rdf_check_boxes_kernel, dim3((unsigned)ceil_div(n_frames, 256)), dim3(256),
+                           0, h->stream, d_boxes, n_frames, d_misc + 1);
 
     // LDS of the pair kernel: 4 wave slabs + thresholds + per-wave histograms
     size_t base = sizeof(float4) * 256 + sizeof(double) * (h->n_bins + 1);
@@ -488,7 +492,9 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
         lds = sizeof(float4) * 256;
     const bool lower = h->edges.front() > 0.0;
     void (*kern)(CellArgs) = nullptr;
-#define MDX_CELL_PICK(E, L) kern = gh ? rdf_cell_pair_kernel<E, L, 1> : rdf_cell_pair_kernel<E, L, 0>
+#define MDX_CELL_PICK(E, L)                                                                     \
+    kern = tri ? (gh ? rdf_cell_pair_kernel<E, L, 1, true> : rdf_cell_pair_kernel<E, L, 0, true>) \
+               : (gh ? rdf_cell_pair_kernel<E, L, 1> : rdf_cell_pair_kernel<E, L, 0>)
     if (excl && lower) MDX_CELL_PICK(true, true);
     else if (excl) MDX_CELL_PICK(true, false);
     else if (lower) MDX_CELL_PICK(false, true);
@@ -497,15 +503,19 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
 
     for (int64_t f0 = 0; f0 < n_frames; f0 += slab) {
         const int64_t nf = std::min(slab, n_frames - f0);
-        hipLaunchKernelGGL(rdf_cell_sort_kernel, dim3((unsigned)nf), dim3(SORT_THREADS), 0, h->stream,
-                           d_pos1 + f0 * n1 * 3, d_boxes + f0 * 6, (int)n1, (int)n1p,
-                           excl ? h->excl1 : 0, h->d_pw1.as<float4>(), h->d_po1.as<float4>(),
-                           h->d_bb1.as<float4>(), h->d_bb16_1.as<float4>(), d_misc);
-        if (!self)
-            hipLaunchKernelGGL(rdf_cell_sort_kernel, dim3((unsigned)nf), dim3(SORT_THREADS), 0,
-                               h->stream, d_pos2 + f0 * n2 * 3, d_boxes + f0 * 6, (int)n2, (int)n2p,
-                               excl ? h->excl2 : 0, h->d_pw2.as<float4>(), h->d_po2.as<float4>(),
-                               h->d_bb2.as<float4>(), h->d_bb16_2.as<float4>(), d_misc);
+        {
+            auto sort = tri ? rdf_cell_sort_kernel<true> : rdf_cell_sort_kernel<false>;
+            const float *cells = tri ? d_tri + f0 * 9 : d_boxes + f0 * 6;
+            hipLaunchKernelGGL(sort, dim3((unsigned)nf), dim3(SORT_THREADS), 0, h->stream,
+                               d_pos1 + f0 * n1 * 3, cells, (int)n1, (int)n1p, excl ? h->excl1 : 0,
+                               h->d_pw1.as<float4>(), h->d_po1.as<float4>(), h->d_bb1.as<float4>(),
+                               h->d_bb16_1.as<float4>(), d_misc);
+            if (!self)
+                hipLaunchKernelGGL(sort, dim3((unsigned)nf), dim3(SORT_THREADS), 0, h->stream,
+                                   d_pos2 + f0 * n2 * 3, cells, (int)n2, (int)n2p,
+                                   excl ? h->excl2 : 0, h->d_pw2.as<float4>(), h->d_po2.as<float4>(),
+                                   h->d_bb2.as<float4>(), h->d_bb16_2.as<float4>(), d_misc);
+        }
         CellArgs a{};
         a.pw1 = h->d_pw1.as<float4>();
         a.po1 = h->d_po1.as<float4>();
@@ -515,7 +525,8 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
         a.bb2 = self ? a.bb1 : h->d_bb2.as<float4>();
         a.bb16_2 = self ? h->d_bb16_1.as<float4>() : h->d_bb16_2.as<float4>();
         a.tags_everywhere = (self && h->excl1 == 1 && h->excl2 == 1) ? 0 : 1;
-        a.boxes = d_boxes + f0 * 6;
+        a.boxes = tri ? nullptr : d_boxes + f0 * 6;
+        a.tri = tri ? d_tri + f0 * 9 : nullptr;
         a.thresh = h->d_thresh.as<double>();
         a.counts = h->d_counts.as<unsigned long long>();
         a.maxabs_bits = d_misc;
@@ -675,18 +686,39 @@ static int accumulate_triclinic(mdx_rdf *h, const float *d_pos1, int64_t n1, con
             return fail(MDX_ERR_INVALID_VALUE, "frame %lld: the cell angles do not span a volume",
                         (long long)f);
     }
-    const int64_t n1p = ceil_div(n1, 256) * 256, n2p = ceil_div(n2, 256) * 256;
-    int64_t slab = std::max<int64_t>(1, (int64_t(1) << 30) / (int64_t(16) * (n1p + (self ? 0 : n2p))));
-    slab = std::min<int64_t>(std::min<int64_t>(slab, 32768), n_frames);
-    MDX_TRY(h->d_pack1.ensure(size_t(16) * n1p * slab));
-    if (!self)
-        MDX_TRY(h->d_pack2.ensure(size_t(16) * n2p * slab));
     // the previous call's kernels may still read the cell matrices
     MDX_HIP(hipStreamSynchronize(h->stream));
     MDX_TRY(h->d_tri.ensure(size_t(36) * n_frames));
     MDX_HIP(hipMemcpyAsync(h->d_tri.ptr, tri.data(), size_t(36) * n_frames, hipMemcpyHostToDevice,
                            h->stream));
     MDX_HIP(hipStreamSynchronize(h->stream));   // `tri` leaves scope
+
+    // Culled cell-sorted kernel (27 tile images, float32 filter, 27-image contract for the
+    // undecided pairs) when the range ends below half the smallest cell height in every frame:
+    // then at most one image of a pair can come within the cut.  Otherwise (or for small
+    // systems, or algo = exact / filter) the brute-force 27-image kernel below.
+    bool culled = h->algo == MDX_RDF_ALGO_AUTO || h->algo == MDX_RDF_ALGO_CELL;
+    culled = culled && std::max(n1, n2) >= 1024 && !getenv("MDX_RDF_TRI_BRUTE");
+    for (int64_t f = 0; culled && f < n_frames; ++f) {
+        const float *B = tri.data() + 9 * f;
+        const double b00 = B[0], b10 = B[3], b11 = B[4], b20 = B[6], b21 = B[7], b22 = B[8];
+        const double vol = b00 * b11 * b22;
+        const double bcx = b11 * b22, bcy = -b10 * b22, bcz = b10 * b21 - b11 * b20;
+        const double hx = vol / std::sqrt(bcx * bcx + bcy * bcy + bcz * bcz);
+        const double hy = b11 * b22 / std::sqrt(b22 * b22 + b21 * b21);
+        const double r_in = 0.5 * std::min(hx, std::min(hy, b22));
+        culled = h->edges.back() * 1.02 + 1e-3 < r_in;
+    }
+    if (culled)
+        return accumulate_cell(h, d_pos1, n1, d_pos2, n2, nullptr, n_frames, self,
+                               excl, h->d_tri.as<float>());
+
+    const int64_t n1p = ceil_div(n1, 256) * 256, n2p = ceil_div(n2, 256) * 256;
+    int64_t slab = std::max<int64_t>(1, (int64_t(1) << 30) / (int64_t(16) * (n1p + (self ? 0 : n2p))));
+    slab = std::min<int64_t>(std::min<int64_t>(slab, 32768), n_frames);
+    MDX_TRY(h->d_pack1.ensure(size_t(16) * n1p * slab));
+    if (!self)
+        MDX_TRY(h->d_pack2.ensure(size_t(16) * n2p * slab));
 
     size_t base = sizeof(float4) * 256 + sizeof(double) * (h->n_bins + 1);
     int n_hist = 4;

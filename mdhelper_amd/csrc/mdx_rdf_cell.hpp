@@ -33,7 +33,8 @@ struct CellArgs {
     const float4 *pw1, *po1, *bb1;
     const float4 *pw2, *po2, *bb2;
     const float4 *bb16_2;        // boxes of the CELL_CHUNK-particle chunks of the j side
-    const float *boxes;          // [frames][6]
+    const float *boxes;          // [frames][6] (orthorhombic frames)
+    const float *tri;            // [frames][9] cell matrices (triclinic kernel variant)
     const double *thresh;        // [n_bins+1]
     unsigned long long *counts;  // [n_rep][n_bins]
     const unsigned *maxabs_bits;
@@ -109,6 +110,53 @@ struct CellGrid {
     }
 };
 
+// Triclinic frames (TRI): `boxes` holds the 9-float cell matrices B (rows a, b, c).  A particle
+// is moved into the central cell exactly as the contract prescribes (c, b, a in turn, double
+// arithmetic, float32 result: DESIGN.md §4.5) — that wrapped position is BOTH sorted copies —
+// and it is binned by its fractional coordinates, on a grid sized from the cell heights.
+struct TriCell {
+    double B[9];
+    double h[3];   // perpendicular heights
+    __device__ inline void init(const float *b)
+    {
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+            B[i] = (double)b[i];
+        const double vol = B[0] * B[4] * B[8];
+        const double bcx = B[4] * B[8], bcy = -B[3] * B[8], bcz = B[3] * B[7] - B[4] * B[6];
+        h[0] = vol / sqrt(bcx * bcx + bcy * bcy + bcz * bcz);
+        h[1] = B[4] * B[8] / sqrt(B[8] * B[8] + B[7] * B[7]);
+        h[2] = B[8];
+    }
+    // contract wrap (the arithmetic of rdf_tri_pack_kernel)
+    __device__ inline void wrap(float x, float y, float z, float &wx, float &wy, float &wz) const
+    {
+        double r[3] = {(double)x, (double)y, (double)z};
+#pragma unroll
+        for (int k = 2; k >= 0; --k) {
+            const double s = floor(r[k] / B[4 * k]);
+#pragma unroll
+            for (int c = 0; c <= k; ++c)
+                r[c] -= s * B[3 * k + c];
+        }
+        wx = (float)r[0];
+        wy = (float)r[1];
+        wz = (float)r[2];
+    }
+    // cell of a wrapped position on an nc[0] x nc[1] x nc[2] grid in fractional coordinates
+    __device__ inline void cell(float wx, float wy, float wz, const int *nc, int &cx, int &cy,
+                                int &cz) const
+    {
+        const double sz = (double)wz / B[8];
+        const double sy = ((double)wy - sz * B[7]) / B[4];
+        const double sx = ((double)wx - sy * B[3] - sz * B[6]) / B[0];
+        cx = min(max((int)floor(sx * nc[0]), 0), nc[0] - 1);
+        cy = min(max((int)floor(sy * nc[1]), 0), nc[1] - 1);
+        cz = min(max((int)floor(sz * nc[2]), 0), nc[2] - 1);
+    }
+};
+
+template <bool TRI>
 __global__ __launch_bounds__(SORT_THREADS) void rdf_cell_sort_kernel(
     const float *__restrict__ pos, const float *__restrict__ boxes, int n, int n_pad, int64_t excl,
     float4 *__restrict__ pw, float4 *__restrict__ po, float4 *__restrict__ bb,
@@ -122,7 +170,14 @@ __global__ __launch_bounds__(SORT_THREADS) void rdf_cell_sort_kernel(
     float4 *PW = pw + int64_t(frame) * n_pad;
     float4 *PO = po + int64_t(frame) * n_pad;
     CellGrid g;
-    g.init(boxes + int64_t(frame) * 6, n);
+    TriCell tc;
+    if (TRI) {
+        tc.init(boxes + int64_t(frame) * 9);
+        const float hb[3] = {(float)tc.h[0], (float)tc.h[1], (float)tc.h[2]};
+        g.init(hb, n);   // grid dimensions from the heights
+    } else {
+        g.init(boxes + int64_t(frame) * 6, n);
+    }
     const int ncell = g.n_cells();
 
     for (int c = tid; c < ncell; c += SORT_THREADS)
@@ -133,9 +188,14 @@ __global__ __launch_bounds__(SORT_THREADS) void rdf_cell_sort_kernel(
     for (int a = tid; a < n; a += SORT_THREADS) {
         float x = P[3 * a], y = P[3 * a + 1], z = P[3 * a + 2];
         int cx, cy, cz;
-        g.wrap(x, 0, cx);
-        g.wrap(y, 1, cy);
-        g.wrap(z, 2, cz);
+        if (TRI) {
+            tc.wrap(x, y, z, x, y, z);   // the bound below is on the WRAPPED coordinates
+            tc.cell(x, y, z, g.nc, cx, cy, cz);
+        } else {
+            g.wrap(x, 0, cx);
+            g.wrap(y, 1, cy);
+            g.wrap(z, 2, cz);
+        }
         atomicAdd(&cnt[g.key(cx, cy, cz)], 1u);
         float am = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
         m = fmaxf(m, am == am ? am : __int_as_float(0x7f800000));
@@ -175,7 +235,14 @@ __global__ __launch_bounds__(SORT_THREADS) void rdf_cell_sort_kernel(
     for (int a = tid; a < n; a += SORT_THREADS) {
         float x = P[3 * a], y = P[3 * a + 1], z = P[3 * a + 2];
         int cx, cy, cz;
-        float wx = g.wrap(x, 0, cx), wy = g.wrap(y, 1, cy), wz = g.wrap(z, 2, cz);
+        float wx, wy, wz;
+        if (TRI) {
+            tc.wrap(x, y, z, wx, wy, wz);
+            tc.cell(wx, wy, wz, g.nc, cx, cy, cz);
+            x = wx, y = wy, z = wz;   // the contract evaluates the wrapped positions
+        } else {
+            wx = g.wrap(x, 0, cx), wy = g.wrap(y, 1, cy), wz = g.wrap(z, 2, cz);
+        }
         unsigned slot = atomicAdd(&cnt[g.key(cx, cy, cz)], 1u);
         float tag = __int_as_float(excl > 0 ? int(int64_t(a) / excl) : a);
         PW[slot] = make_float4(wx, wy, wz, tag);
@@ -221,12 +288,41 @@ __global__ __launch_bounds__(SORT_THREADS) void rdf_cell_sort_kernel(
 }
 
 // Exact re-evaluation of one pair with the contract arithmetic on the ORIGINAL coordinates.
+// Triclinic contract: the strictly smallest of the 27 images, in double.
+__device__ inline double rdf_rsq_contract_tri(const float *Bf, const float4 &pi, const float4 &pj)
+{
+    const double b00 = Bf[0], b10 = Bf[3], b11 = Bf[4], b20 = Bf[6], b21 = Bf[7], b22 = Bf[8];
+    const double dx = (double)(pj.x - pi.x), dy = (double)(pj.y - pi.y), dz = (double)(pj.z - pi.z);
+    double best = 1.0e300;
+    // rolled loops: this is cold code and must not raise the register count of the hot loop
+#pragma unroll 1
+    for (int ix = -1; ix < 2; ++ix) {
+        const double rx = dx + b00 * (double)ix;
+#pragma unroll 1
+        for (int iy = -1; iy < 2; ++iy) {
+            const double ry0 = rx + b10 * (double)iy;
+            const double ry1 = dy + b11 * (double)iy;
+#pragma unroll 1
+            for (int iz = -1; iz < 2; ++iz) {
+                const double rz0 = ry0 + b20 * (double)iz;
+                const double rz1 = ry1 + b21 * (double)iz;
+                const double rz2 = dz + b22 * (double)iz;
+                const double dsq = (rz0 * rz0 + rz1 * rz1) + rz2 * rz2;
+                best = dsq < best ? dsq : best;
+            }
+        }
+    }
+    return best;
+}
+
 template <typename Hist>
 __device__ inline void cell_pair_exact(const PairCtx<true> &c, const CellArgs &a,
                                              const double *sT, const Hist &hist, const float4 *po_i,
-                                             const float4 *po_j, unsigned w)
+                                             const float4 *po_j, unsigned w,
+                                             const float *tri = nullptr)
 {
-    double rsq = rdf_rsq_contract<true>(c, *po_i, *po_j);
+    double rsq = tri ? rdf_rsq_contract_tri(tri, *po_i, *po_j)
+                     : rdf_rsq_contract<true>(c, *po_i, *po_j);
     if ((rsq >= a.t_lo) && (rsq < a.t_hi))
         hist.add(rdf_bin_exact(rsq, sT, a.n_bins, c.r0f, c.inv_wf), w);
 }
@@ -236,6 +332,7 @@ struct CellHot {
     float cand_hi, cand_lo, inv_w, sure_w;   // sure_w = 1 - 2 eta
     float pos0;   // -r0/width - eta; kept in a VECTOR register (an fma takes one scalar operand)
     float L[3], invL[3];   // box lengths and fl32(1/L): widened to fp64 only by the exact passes
+    const float *tri;      // triclinic variant: the frame's cell matrix (LDS), else nullptr
 };
 
 __device__ inline float cell_uniform(float v)
@@ -344,7 +441,7 @@ __device__ inline void cell_flush(const CellHot &c, const CellArgs &a, const dou
         if (e0 + lane < wv.n_todo) {
             const uint2 e = wv.todo[e0 + lane];
             cell_pair_exact(cx, a, sT, hist, po1f + e.x, po2f + (e.y & 0x7fffffffu),
-                            (e.y >> 31) + 1u);
+                            (e.y >> 31) + 1u, c.tri);
         }
     }
     wv.n_exact += wv.n_todo;
@@ -400,7 +497,7 @@ __device__ inline void cell_slow_unit(const CellHot &c, const CellArgs &a, const
     }
 }
 
-template <bool EXCL, bool LOWER, int MODE>
+template <bool EXCL, bool LOWER, int MODE, bool TRI = false>
 __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
 {
     constexpr bool GH = MODE == 1;
@@ -411,7 +508,8 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
     __shared__ unsigned s_exact, s_units, s_general, s_qn, s_qnext;
     __shared__ unsigned sQ[CELL_QCAP];
     __shared__ uint2 s_todo[4][CELL_TODO];
-    __shared__ float s_geo[32];
+    __shared__ float s_geo[48];
+    __shared__ unsigned sQimg[TRI ? CELL_QCAP : 1];   // triclinic: surviving images of a queued tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Workgroups are dealt round-robin to the 8 XCDs in linear block order.  Blocks of one
@@ -449,9 +547,25 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
     //          [26] cand_hi, [27] cand_lo, [28] inv_w, [29] -r0/w - eta, [30] 1 - 2 eta
     unsigned long long *out =
         a.counts + int64_t((I + 7 * frame_l) % a.n_rep) * a.n_bins;
+    //   triclinic: [31..39] cell matrix B (rows a, b, c); L and 1/L are unused
     if (tid == 0) {
         PairCtx<true> ctx;
-        ctx.init(a.boxes + int64_t(frame) * 6, a.maxabs_bits, a.r0, a.r1, a.n_bins);
+        if (TRI) {
+            // error bound of the float32 path: the shifted difference
+            // fl(fl(x_j + t) - x_i) against the contract's (double)(x_j - x_i) + t deviates by less
+            // than 7 * 2^-24 * sum|B| per component; the orthorhombic formula with the pseudo
+            // length 4 sum|B| gives 2^-22 (2 M + 4 sum|B|) >= 2^-20 sum|B|
+            const float *B = a.tri + int64_t(frame) * 9;
+            float sum = 0.f;
+            for (int i = 0; i < 9; ++i) {
+                s_geo[31 + i] = B[i];
+                sum += fabsf(B[i]);
+            }
+            const float pseudo[3] = {4.f * sum, 4.f * sum, 4.f * sum};
+            ctx.init(pseudo, a.maxabs_bits, a.r0, a.r1, a.n_bins);
+        } else {
+            ctx.init(a.boxes + int64_t(frame) * 6, a.maxabs_bits, a.r0, a.r1, a.n_bins);
+        }
         const float Lmax = fmaxf(ctx.Lf[0], fmaxf(ctx.Lf[1], ctx.Lf[2]));
         // a tile pair is culled when its box gap exceeds r1 + error bound + slack
         const float cut = sqrtf(ctx.cand_hi) + 1e-5f * Lmax;
@@ -491,6 +605,7 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
         hot.L[k] = cell_uniform(s_geo[k]);
         hot.invL[k] = cell_uniform(s_geo[3 + k]);
     }
+    hot.tri = TRI ? s_geo + 31 : nullptr;
     const double *thr = GH ? a.thresh : sT;
     // per-wave histograms of n_bins + 1 slots: the extra slot absorbs a (proven impossible,
     // DESIGN.md §4.2) index n_bins instead of letting it alias the next histogram's bin 0
@@ -525,10 +640,32 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
             const int J = Jb + tid;
             float g2 = __int_as_float(0x7f800000);
             unsigned code = 0u;
+            unsigned img_mask = 0u;
             if (J < round1) {
                 const float4 lo = BB2[2 * J], hi = BB2[2 * J + 1];
                 const float cJ[3] = {0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)};
                 const float hJ[3] = {0.5f * (hi.x - lo.x), 0.5f * (hi.y - lo.y), 0.5f * (hi.z - lo.z)};
+                if (TRI) {
+                    // every neighbouring image of the j tile is a candidate of its own: the cut is
+                    // below half the smallest cell height (host check), so at most one image of
+                    // a PAIR can come within the cut and nothing is counted twice
+                    const float ex = s_geo[11] + hJ[0], ey = s_geo[12] + hJ[1], ez = s_geo[13] + hJ[2];
+                    const float d0x = cJ[0] - s_geo[8], d0y = cJ[1] - s_geo[9], d0z = cJ[2] - s_geo[10];
+#pragma unroll 1
+                    for (int img = 0; img < 27; ++img) {
+                        const float ia = float(img % 3 - 1), ib = float((img / 3) % 3 - 1),
+                                    ic = float(img / 9 - 1);
+                        const float tx = ia * s_geo[31] + ib * s_geo[34] + ic * s_geo[37];
+                        const float ty = ib * s_geo[35] + ic * s_geo[38];
+                        const float tz = ic * s_geo[39];
+                        const float gx = fmaxf(0.f, fabsf(d0x + tx) - ex), gy = fmaxf(0.f, fabsf(d0y + ty) - ey),
+                                    gz = fmaxf(0.f, fabsf(d0z + tz) - ez);
+                        if (__fmaf_rn(gz, gz, __fmaf_rn(gy, gy, gx * gx)) <= s_geo[7])
+                            img_mask |= 1u << img;
+                    }
+                    g2 = img_mask ? 0.f : __int_as_float(0x7f800000);
+                    code = unsigned(J);
+                } else {
                 g2 = 0.f;
                 int general = 0;
 #pragma unroll
@@ -551,6 +688,7 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
                     general |= !(reach < halfL) && !(cut < halfL && reach < Lk - cut - 1e-4f * Lk);
                 }
                 code |= unsigned(J) | (unsigned(general) << 28);
+                }
             }
             const bool keep = g2 <= s_geo[7];
             const unsigned long long mask = __ballot(keep);
@@ -559,8 +697,12 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
                 if (lane == 0)
                     base = atomicAdd(&s_qn, (unsigned)__popcll(mask));
                 base = __builtin_amdgcn_readfirstlane(base);
-                if (keep)
-                    sQ[base + __popcll(mask & ((1ull << lane) - 1ull))] = code;
+                if (keep) {
+                    const unsigned slot = base + __popcll(mask & ((1ull << lane) - 1ull));
+                    sQ[slot] = code;
+                    if (TRI)
+                        sQimg[slot] = img_mask;
+                }
             }
         }
         __syncthreads();
@@ -574,11 +716,25 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
                 break;
             const unsigned code = sQ[e];
             const int Jt = int(code & 0x3fffffu);
-            const int gen = int(code >> 28) & 1;
-            const float sx = float(int((code >> 22) & 3u) - 1) * s_geo[0];
-            const float sy = float(int((code >> 24) & 3u) - 1) * s_geo[1];
-            const float sz = float(int((code >> 26) & 3u) - 1) * s_geo[2];
-            float4 pj = PW2[int64_t(Jt) * 64 + lane];
+            const float4 pj_raw = PW2[int64_t(Jt) * 64 + lane];
+            // orthorhombic: one pass with the tile pair's image; triclinic: one pass per
+            // surviving image of the tile
+            for (unsigned imgs = TRI ? sQimg[e] : 1u; imgs; imgs &= imgs - 1u) {
+            int gen = 0;
+            float sx, sy, sz;
+            if (TRI) {
+                const int img = __builtin_ctz(imgs);
+                const float ia = float(img % 3 - 1), ib = float((img / 3) % 3 - 1), ic = float(img / 9 - 1);
+                sx = -(ia * s_geo[31] + ib * s_geo[34] + ic * s_geo[37]);
+                sy = -(ib * s_geo[35] + ic * s_geo[38]);
+                sz = -(ic * s_geo[39]);
+            } else {
+                gen = int(code >> 28) & 1;
+                sx = float(int((code >> 22) & 3u) - 1) * s_geo[0];
+                sy = float(int((code >> 24) & 3u) - 1) * s_geo[1];
+                sz = float(int((code >> 26) & 3u) - 1) * s_geo[2];
+            }
+            float4 pj = pj_raw;
             if (!gen) {
                 pj.x -= sx;
                 pj.y -= sy;
@@ -716,6 +872,7 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
                 if (GH) cell_flush(hot, a, thr, hg, wv, PO1f, PO2);
                 else cell_flush(hot, a, thr, hl, wv, PO1f, PO2);
             }
+            }   // images
         }
         __syncthreads();   // the queue is reset by the next round
     }

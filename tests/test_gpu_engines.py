@@ -583,3 +583,35 @@ def test_sq_column_form_equals_lattice_and_general_kernels(monkeypatch):
     slices = [slice(0, sizes[0]), slice(sizes[0], N)]
     ref = sum(of.ssf_frame_ref(q, pos[f].astype(np.float64), slices, pairs, "partial") for f in range(F))
     assert np.allclose(out["columns"], ref, rtol=1e-6, atol=1e-9 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("cell", [(42.0, 40.5, 45.25, 75.0, 80.0, 110.0), (36.0, 36.0, 36.0, 60.0, 60.0, 90.0),
+                                  (50.0, 38.0, 41.0, 90.0, 90.0, 120.0), (33.0, 46.0, 39.0, 101.5, 90.0, 67.25)])
+def test_rdf_triclinic_culled_kernel(cell, monkeypatch):
+    """Triclinic cells with the cut below half the smallest cell height: the cell-sorted kernel
+    with 27 tile images (float32 filter + 27-image contract for undecided pairs) against the C
+    oracle and against the brute-force 27-image kernel."""
+    rng = np.random.default_rng(46)
+    dims = np.array(cell, dtype=np.float32)
+    B = orf.triclinic_vectors(dims).astype(np.float64)
+    n = 5200
+    pos = (rng.random((n, 3)) @ B + rng.normal(0, 30.0, (n, 3))).astype(np.float32)
+    other = (rng.random((2300, 3)) @ B).astype(np.float32)
+    for rng_range, nb, exclusion in [((0.0, 9.0), 120, (1, 1)), ((1.5, 8.0), 33, None), ((0.0, 6.0), 201, (4, 4))]:
+        want = c_radial_histogram(pos, pos, nb, rng_range, dims, exclusion=exclusion)
+        monkeypatch.delenv("MDX_RDF_TRI_BRUTE", raising=False)
+        eng = _core.RdfEngine(_edges(nb, rng_range), exclusion, timing=True)
+        eng.accumulate(pos, None, dims)
+        got = eng.counts()
+        st = eng.stats()
+        eng.close()
+        assert np.array_equal(got, want), (cell, rng_range)
+        assert 0 < st["pairs_computed"] < 0.6 * st["pairs_evaluated"]      # the culled path ran
+        monkeypatch.setenv("MDX_RDF_TRI_BRUTE", "1")
+        assert np.array_equal(_gpu_hist(pos, None, nb, rng_range, dims, exclusion, "auto"), want)
+    monkeypatch.delenv("MDX_RDF_TRI_BRUTE", raising=False)
+    want = c_radial_histogram(pos, other, 64, (0.0, 7.0), dims)
+    assert np.array_equal(_gpu_hist(pos, other, 64, (0.0, 7.0), dims, None, "auto"), want)
+    # a range beyond half the smallest height falls back to the brute-force kernel
+    want = c_radial_histogram(pos[:1500], pos[:1500], 50, (0.0, 22.0), dims, exclusion=(1, 1))
+    assert np.array_equal(_gpu_hist(pos[:1500], None, 50, (0.0, 22.0), dims, (1, 1), "auto"), want)
