@@ -277,7 +277,15 @@ int mdx_isf_accumulate_traj(mdx_isf_t h, mdx_traj_t traj, const int64_t *frames,
  * box lengths; zero_dims as for mdx_msd_push. */
 int mdx_msd_push_traj(mdx_msd_t h, int group, mdx_traj_t traj, const int64_t *frames,
                       int64_t n_frames, const int32_t *index, int64_t n_index, int unwrap,
-                      const double *dims, int zero_dims);
+                      const double *dims, int zero_dims, const double *shift);
+/* System centre of mass of every listed frame, out float64[n_frames][3] (host), over the
+ * listed particles with the given masses (transport.py:993-1014: all atoms for center_atom,
+ * else the groups' particles); unwrap as above; wrap != 0 brings coordinates outside [0, L]
+ * back first (center_wrap).  Its output is the `shift` of mdx_msd_push_traj (NULL: none):
+ * shift[t] is subtracted from every position of frame t. */
+int mdx_msd_system_com_traj(mdx_msd_t h, mdx_traj_t traj, const int64_t *frames, int64_t n_frames,
+                            const int32_t *index, int64_t n_index, const double *masses, int unwrap,
+                            const double *dims, int wrap, double *out);
 
 #ifdef __cplusplus
 }

@@ -397,15 +397,30 @@ class MsdEngine(_Engine):
     def push_device(self, group, d_pos, n_total, first, count, zero_dims=0):
         check(lib().mdx_msd_push_device(self.handle, group, d_pos, n_total, first, count, zero_dims))
 
-    def push_traj(self, group, traj_file, frames, index=None, *, unwrap_dims=None, zero_dims=0):
+    def system_com_traj(self, traj_file, frames, index, masses, *, unwrap_dims=None, wrap_dims=None):
+        """float64[len(frames), 3] system centre of mass per frame (``Onsager(center=True)``)."""
+        f = np.ascontiguousarray(frames, dtype=np.int64)
+        i = None if index is None else np.ascontiguousarray(index, dtype=np.int32)
+        m = np.ascontiguousarray(masses, dtype=np.float64)
+        dims = unwrap_dims if unwrap_dims is not None else wrap_dims
+        d = None if dims is None else np.ascontiguousarray(dims, dtype=np.float64)[:3]
+        out = np.empty((len(f), 3), dtype=np.float64)
+        check(lib().mdx_msd_system_com_traj(self.handle, traj_file.handle, _ptr(f), len(f), _ptr(i),
+                                            len(m), _ptr(m), 0 if unwrap_dims is None else 1, _ptr(d),
+                                            0 if wrap_dims is None else 1, _ptr(out)))
+        return out
+
+    def push_traj(self, group, traj_file, frames, index=None, *, unwrap_dims=None, zero_dims=0,
+                  shift=None):
         """A group's positions straight from a native trajectory file; ``unwrap_dims``: box
         lengths for the device-side global unwrap (None: positions are used as stored)."""
         f = np.ascontiguousarray(frames, dtype=np.int64)
         i = None if index is None else np.ascontiguousarray(index, dtype=np.int32)
         d = None if unwrap_dims is None else np.ascontiguousarray(unwrap_dims, dtype=np.float64)[:3]
+        sh = None if shift is None else np.ascontiguousarray(shift, dtype=np.float64)
         check(lib().mdx_msd_push_traj(self.handle, group, traj_file.handle, _ptr(f), len(f), _ptr(i),
                                       0 if i is None else len(i), 0 if d is None else 1, _ptr(d),
-                                      zero_dims))
+                                      zero_dims, _ptr(sh)))
 
     def result(self, want_msd=True):
         msd = np.zeros((self.n_groups, self.n_blocks, self.t_block)) if want_msd else None

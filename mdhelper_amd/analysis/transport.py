@@ -349,11 +349,24 @@ class Onsager(SerialAnalysisBase):
                 # frames stream file -> pinned memory -> HBM; unwrapping and the float64
                 # widening happen on the device (mdx_msd_push_traj)
                 numbers = self._frame_numbers()[:self._n_frames]
+                native = self._trajectory.native
+                unwrap_dims = self._dimensions if self._unwrap else None
+                shift = None
+                if self._center:
+                    # system centre of mass per frame (reference :993-1014), every rank the same
+                    wrap_dims = self._dimensions if self._center_wrap else None
+                    if self._center_atom:
+                        shift = eng.system_com_traj(native, numbers, None, self.universe.atoms.masses,
+                                                    unwrap_dims=unwrap_dims, wrap_dims=wrap_dims)
+                    else:
+                        shift = eng.system_com_traj(
+                            native, numbers, np.concatenate([g.indices for g in self._groups]),
+                            np.concatenate([g.masses for g in self._groups]),
+                            unwrap_dims=unwrap_dims, wrap_dims=wrap_dims)
                 for g, (grp, (lo, hi)) in enumerate(zip(self._groups, self._own)):
                     if hi > lo:
-                        eng.push_traj(g, self._trajectory.native, numbers, grp.indices[lo:hi],
-                                      unwrap_dims=self._dimensions if self._unwrap else None,
-                                      zero_dims=zero_mask)
+                        eng.push_traj(g, native, numbers, grp.indices[lo:hi],
+                                      unwrap_dims=unwrap_dims, zero_dims=zero_mask, shift=shift)
             for g, own in enumerate(self._own_slices):
                 if own.stop > own.start and not self._from_file:
                     eng.push(g, self._positions, own.start, own.stop - own.start, zero_mask)
@@ -403,10 +416,12 @@ class Onsager(SerialAnalysisBase):
     def run(self, start=None, stop=None, step=None, frames=None, n_jobs: int = 1, verbose=None,
             **kwargs):
         traj = self._trajectory
-        atoms_only = all(g == "atoms" for g in self._groupings) and not self._center
-        # trajectory files: nothing is staged on the host, unwrapping included
+        atoms_only = all(g == "atoms" for g in self._groupings)
+        # trajectory files: nothing is staged on the host, unwrapping and the removal of the
+        # system centre of mass included
         self._from_file = bool(atoms_only and self._fft and getattr(traj, "native", None) is not None)
-        fast = hasattr(traj, "frame_block") and atoms_only and (self._from_file or not self._unwrap)
+        fast = hasattr(traj, "frame_block") and atoms_only and (
+            self._from_file or not (self._unwrap or self._center))
         if not fast:
             return super().run(start=start, stop=stop, step=step, frames=frames, n_jobs=n_jobs,
                                verbose=verbose, **kwargs)

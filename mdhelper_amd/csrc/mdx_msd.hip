@@ -286,6 +286,7 @@ struct mdx_msd {
     // accumulators: power [G][B][nc] + D [G][B*T_b] contiguous (one all-reduce), traj [G][B*T_b][3]
     DeviceBuffer d_acc, d_traj, d_series, d_spec, d_stage, d_inv_in, d_inv_out;
     DeviceBuffer d_f32, d_index, d_prev, d_image;   // trajectory-file path: frames, unwrap state
+    DeviceBuffer d_masses, d_com_x, d_shift;        // system centre of mass per frame
     bool own_fft = false;                           // n_fft = 2^18..2^20: mdx_msd_fft.hpp, not rocFFT
     msdfft::Shape shape;
     DeviceBuffer d_tw, d_pfull;                     // twiddle tables [2][512], full-spectrum sums [B][N]
@@ -369,7 +370,7 @@ static int msd_push_device(mdx_msd *h, int group, const double *d_pos, int64_t n
 __global__ __launch_bounds__(256) void msd_unwrap_widen_kernel(
     const float *__restrict__ in, int64_t n_coord, int64_t n_frames, int first_block, int unwrap,
     double lx, double ly, double lz, float *__restrict__ prev, int *__restrict__ image,
-    double *__restrict__ out)
+    double *__restrict__ out, const double *__restrict__ shift /* [n_frames][3] or nullptr */)
 {
     const int64_t e = blockIdx.x * int64_t(256) + threadIdx.x;
     if (e >= n_coord)
@@ -389,16 +390,103 @@ __global__ __launch_bounds__(256) void msd_unwrap_widen_kernel(
             x_old = x;
             v = __dadd_rn(v, __dmul_rn((double)img, L));
         }
+        if (shift)   // system centre of mass of this frame (transport.py:993-1014)
+            v = __dsub_rn(v, shift[3 * f + k]);
         out[f * n_coord + e] = v;
     }
     prev[e] = x_old;
     image[e] = img;
 }
 
+// out[f][k] = sum_a m_a x[f][a][k] / sum_a m_a; wrap != 0: coordinates outside [0, L] are first
+// brought back with x -= floor(x / L) L (algorithm/topology.py `wrap`).  One block per frame.
+__global__ __launch_bounds__(256) void msd_frame_com_kernel(const double *__restrict__ x, int64_t n,
+                                                           const double *__restrict__ masses,
+                                                           double inv_total, int wrap, double lx,
+                                                           double ly, double lz, double *__restrict__ out)
+{
+    __shared__ double red[3][256];
+    const int64_t f = blockIdx.x;
+    const int tid = threadIdx.x;
+    const double L[3] = {lx, ly, lz};
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int64_t a = tid; a < n; a += 256) {
+        const double m = masses[a];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            double v = x[(f * n + a) * 3 + k];
+            if (wrap && (v < 0.0 || v > L[k]))
+                v -= floor(v / L[k]) * L[k];
+            acc[k] = fma(m, v, acc[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        red[k][tid] = acc[k];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                red[k][tid] += red[k][tid + off];
+        __syncthreads();
+    }
+    if (tid < 3)
+        out[3 * f + tid] = red[tid][0] * inv_total;
+}
+
+// System centre of mass of every listed frame (transport.py:993-1014), positions unwrapped first
+// when requested — the state walk needs every listed particle, so the frames are staged whole.
+static int msd_system_com_traj(mdx_msd *h, Trajectory *t, const int64_t *frames, int64_t n_frames,
+                               const int32_t *index, int64_t n_sel, const double *masses, int unwrap,
+                               const double *dims, int wrap, double *out)
+{
+    std::vector<int32_t> iota;
+    if (!index) {
+        iota.resize(size_t(n_sel));
+        for (int64_t i = 0; i < n_sel; ++i)
+            iota[size_t(i)] = (int32_t)i;
+        index = iota.data();
+    }
+    double total = 0.0;
+    for (int64_t i = 0; i < n_sel; ++i)
+        total += masses[i];
+    MDX_REQUIRE(total > 0.0, "the selection has no mass");
+    MDX_HIP(hipStreamSynchronize(h->stream));
+    MDX_TRY(h->d_index.ensure(size_t(4) * n_sel));
+    MDX_HIP(hipMemcpy(h->d_index.ptr, index, size_t(4) * n_sel, hipMemcpyHostToDevice));
+    MDX_TRY(h->d_masses.ensure(size_t(8) * n_sel));
+    MDX_HIP(hipMemcpy(h->d_masses.ptr, masses, size_t(8) * n_sel, hipMemcpyHostToDevice));
+    MDX_TRY(h->d_prev.ensure(size_t(n_sel) * 12));
+    MDX_TRY(h->d_image.ensure(size_t(n_sel) * 12));
+    const int64_t block = std::max<int64_t>(1, std::min<int64_t>(n_frames, (int64_t(64) << 20) / (12 * n_sel)));
+    MDX_TRY(h->d_f32.ensure(size_t(block) * n_sel * 12));
+    MDX_TRY(h->d_com_x.ensure(size_t(block) * n_sel * 24));
+    MDX_TRY(h->d_shift.ensure(size_t(24) * n_frames));
+    for (int64_t f0 = 0; f0 < n_frames; f0 += block) {
+        const int64_t nf = std::min(block, n_frames - f0);
+        TrajSelection sel{h->d_index.as<int>(), n_sel, h->d_f32.as<float>()};
+        MDX_TRY(t->stage_async(h->dev, h->stream, frames + f0, nf, &sel, 1));
+        hipLaunchKernelGGL(msd_unwrap_widen_kernel, dim3((unsigned)ceil_div(3 * n_sel, 256)), dim3(256),
+                           0, h->stream, h->d_f32.as<float>(), 3 * n_sel, nf, f0 == 0 ? 1 : 0, unwrap,
+                           dims ? dims[0] : 0.0, dims ? dims[1] : 0.0, dims ? dims[2] : 0.0,
+                           h->d_prev.as<float>(), h->d_image.as<int>(), h->d_com_x.as<double>(),
+                           (const double *)nullptr);
+        hipLaunchKernelGGL(msd_frame_com_kernel, dim3((unsigned)nf), dim3(256), 0, h->stream,
+                           h->d_com_x.as<double>(), n_sel, h->d_masses.as<double>(), 1.0 / total, wrap,
+                           dims ? dims[0] : 1.0, dims ? dims[1] : 1.0, dims ? dims[2] : 1.0,
+                           h->d_shift.as<double>() + 3 * f0);
+        MDX_HIP(hipGetLastError());
+    }
+    MDX_HIP(hipMemcpyAsync(out, h->d_shift.ptr, size_t(24) * n_frames, hipMemcpyDeviceToHost, h->stream));
+    MDX_HIP(hipStreamSynchronize(h->stream));
+    return MDX_OK;
+}
+
 // The first n_blocks * t_block listed frames of a trajectory file -> one group of the engine.
 static int msd_push_traj(mdx_msd *h, int group, Trajectory *t, const int64_t *frames,
                          const int32_t *index, int64_t n_sel, int unwrap, const double *dims,
-                         int zero_dims)
+                         int zero_dims, const double *shift)
 {
     const int64_t T = int64_t(h->n_blocks) * h->t_block;
     // particle chunks: the float64 block of a chunk within ~30 % of the free HBM
@@ -423,6 +511,10 @@ static int msd_push_traj(mdx_msd *h, int group, Trajectory *t, const int64_t *fr
     MDX_TRY(h->d_image.ensure(size_t(chunk) * 12));
     const int64_t block = std::max<int64_t>(1, std::min<int64_t>(T, (int64_t(64) << 20) / (12 * chunk)));
     MDX_TRY(h->d_f32.ensure(size_t(block) * chunk * 12));
+    if (shift) {
+        MDX_TRY(h->d_shift.ensure(size_t(24) * T));
+        MDX_HIP(hipMemcpy(h->d_shift.ptr, shift, size_t(24) * T, hipMemcpyHostToDevice));
+    }
     for (int64_t a0 = 0; a0 < n_sel; a0 += chunk) {
         const int64_t c = std::min(chunk, n_sel - a0);
         for (int64_t f0 = 0; f0 < T; f0 += block) {
@@ -433,7 +525,8 @@ static int msd_push_traj(mdx_msd *h, int group, Trajectory *t, const int64_t *fr
                                dim3(256), 0, h->stream, h->d_f32.as<float>(), 3 * c, nf,
                                f0 == 0 ? 1 : 0, unwrap, dims ? dims[0] : 0.0, dims ? dims[1] : 0.0,
                                dims ? dims[2] : 0.0, h->d_prev.as<float>(), h->d_image.as<int>(),
-                               h->d_stage.as<double>() + f0 * c * 3);
+                               h->d_stage.as<double>() + f0 * c * 3,
+                               shift ? h->d_shift.as<double>() + 3 * f0 : (const double *)nullptr);
             MDX_HIP(hipGetLastError());
         }
         MDX_TRY(msd_push_device(h, group, h->d_stage.as<double>(), c, 0, c, zero_dims));
@@ -536,7 +629,8 @@ int mdx_msd_destroy(mdx_msd_t h)
     h->fft.destroy();
     for (DeviceBuffer *b : {&h->d_acc, &h->d_traj, &h->d_series, &h->d_spec, &h->d_stage,
                             &h->d_inv_in, &h->d_inv_out, &h->d_f32, &h->d_index, &h->d_prev,
-                            &h->d_image, &h->d_tw, &h->d_pfull})
+                            &h->d_image, &h->d_tw, &h->d_pfull, &h->d_masses, &h->d_com_x,
+                            &h->d_shift})
         b->release();
     if (h->stream)
         (void)hipStreamDestroy(h->stream);
@@ -599,9 +693,30 @@ int mdx_msd_push(mdx_msd_t h, int group, const double *pos, int64_t n_total, int
     return MDX_OK;
 }
 
+int mdx_msd_system_com_traj(mdx_msd_t h, mdx_traj_t traj, const int64_t *frames, int64_t n_frames,
+                            const int32_t *index, int64_t n_index, const double *masses, int unwrap,
+                            const double *dims, int wrap, double *out)
+{
+    MDX_REQUIRE(h && traj && frames && masses && out, "NULL argument");
+    MDX_REQUIRE(n_frames >= 0, "negative frame count");
+    MDX_REQUIRE((!unwrap && !wrap) || (dims && dims[0] > 0 && dims[1] > 0 && dims[2] > 0),
+                "unwrapping / wrapping needs positive box dimensions");
+    MDX_TRY(set_device(h->dev));
+    Trajectory *t = mdx_traj_internal(traj);
+    const int64_t n = index ? n_index : (n_index > 0 ? n_index : t->n_atoms);
+    MDX_REQUIRE(n > 0 && (index || n <= t->n_atoms), "bad selection");
+    for (int64_t i = 0; index && i < n; ++i)
+        if (index[i] < 0 || index[i] >= t->n_atoms)
+            return fail(MDX_ERR_INVALID_VALUE, "particle index %d out of range [0, %lld)", index[i],
+                        (long long)t->n_atoms);
+    if (n_frames == 0)
+        return MDX_OK;
+    return msd_system_com_traj(h, t, frames, n_frames, index, n, masses, unwrap, dims, wrap, out);
+}
+
 int mdx_msd_push_traj(mdx_msd_t h, int group, mdx_traj_t traj, const int64_t *frames,
                       int64_t n_frames, const int32_t *index, int64_t n_index, int unwrap,
-                      const double *dims, int zero_dims)
+                      const double *dims, int zero_dims, const double *shift)
 {
     MDX_REQUIRE(h && traj && frames, "NULL argument");
     MDX_REQUIRE(group >= 0 && group < h->n_groups, "group %d out of range", group);
@@ -621,7 +736,7 @@ int mdx_msd_push_traj(mdx_msd_t h, int group, mdx_traj_t traj, const int64_t *fr
         if (index[i] < 0 || index[i] >= t->n_atoms)
             return fail(MDX_ERR_INVALID_VALUE, "particle index %d out of range [0, %lld)", index[i],
                         (long long)t->n_atoms);
-    return msd_push_traj(h, group, t, frames, index, n, unwrap, dims, zero_dims);
+    return msd_push_traj(h, group, t, frames, index, n, unwrap, dims, zero_dims, shift);
 }
 
 int mdx_msd_result(mdx_msd_t h, double *msd_self_sum, double *sum_traj)

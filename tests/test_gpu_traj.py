@@ -155,3 +155,39 @@ def test_onsager_from_file_with_device_unwrap(tmp_path, kind):
         b = Onsager(um.atoms, temperature=300, verbose=False).run(stop=300)
     assert np.allclose(a.results.msd_self, b.results.msd_self, rtol=1e-9,
                        atol=1e-9 * np.abs(b.results.msd_self).max())
+
+
+@pytest.mark.parametrize("mode", ["groups", "groups_wrap", "atoms", "atoms_wrap_unwrap"])
+def test_onsager_center_from_file_on_device(tmp_path, mode):
+    """Onsager(center=True) on a trajectory file: the per-frame system centre of mass is formed on
+    the device and subtracted there (reference transport.py:993-1014); equals the per-frame host
+    analysis of the same frames."""
+    import warnings
+    from mdhelper_amd.analysis import Onsager
+    rng = np.random.default_rng(71)
+    T, N, L = 240, 60, np.array([9.0, 10.5, 8.25])
+    drift = np.cumsum(rng.normal(0.05, 0.02, (T, 1, 3)), axis=0)       # a moving centre of mass
+    walk = rng.uniform(0, L, (1, N, 3)) + np.cumsum(rng.normal(0, 0.3, (T, N, 3)), axis=0) + drift
+    unwrap = mode == "atoms_wrap_unwrap"
+    stored = (np.mod(walk, L) if unwrap else walk).astype(np.float32)
+    path = tmp_path / "c.nc"
+    write_amber_netcdf(path, stored, L, times=np.arange(T) * 0.5)
+    dims = np.array([*L, 90, 90, 90], dtype=np.float32)
+    masses = rng.uniform(1.0, 30.0, N)
+    charges = np.where(np.arange(N) % 2 == 0, 1.0, -1.0)
+    uf = mdhelper_amd.FileUniverse(path, dt=0.5, charges=charges, masses=masses)
+    um = mdhelper_amd.ArrayUniverse(stored, dims, dt=0.5, charges=charges, masses=masses)
+    cat, an = np.arange(0, N - 10, 2), np.arange(1, N - 10, 2)          # 10 atoms in no group
+    kw = dict(temperature=300, n_blocks=2, center=True, verbose=False, unwrap=unwrap,
+              center_atom=mode.startswith("atoms"), center_wrap="wrap" in mode)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = Onsager([uf.select(cat), uf.select(an)], **kw).run()
+        b = Onsager([um.select(cat), um.select(an)], **kw).run()
+        plain = Onsager([um.select(cat), um.select(an)], **{**kw, "center": False}).run()
+    assert a._from_file and not b._from_file
+    for name in ("msd_self", "msd_cross"):
+        x, y = getattr(a.results, name), getattr(b.results, name)
+        assert np.allclose(x, y, rtol=1e-8, atol=1e-8 * np.abs(y).max()), name
+    # the subtraction matters for this drifting system
+    assert not np.allclose(plain.results.msd_cross, b.results.msd_cross, rtol=1e-3)
