@@ -322,11 +322,16 @@ def bench_sq(args, world):
         "frames_per_sec": args.steps * F * world.world / dt,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "sq_rho_columns_kernel (grid wavevectors: separable phase tables in LDS, "
-                               "columns of common (m_x, m_y))",
-                     "note": "fp64 VALU / LDS bound: 4.5 FMA-class operations + 1.25 16-B LDS reads per "
-                             "evaluation; non-lattice wavevector sets take sq_rho_kernel (~40 fp64 instr each)",
-                     "valu": {"evaluations_per_sec_kernel": evals / max(kernel_s, 1e-9)}},
+                     "kernel": "sq_rho_quads_kernel (grid wavevectors: separable phase tables in LDS, "
+                               "4 columns x 8 m_z accumulators per thread)",
+                     "note": "fp64 VALU bound: 4 FMAs per term + 0.5 complex products, 0.5 16-B LDS reads per "
+                             "term, ~100 fp64 instructions per particle, axis and tile for the tables; "
+                             "non-lattice wavevector sets take sq_rho_kernel (~40 fp64 instr each)",
+                     "valu": {"evaluations_per_sec_kernel": evals / max(kernel_s, 1e-9),
+                              # 4.5 v_fma_f64-class wave-instructions per 64 terms, 4.76 cycles each at the
+                              # nominal 2.4 GHz on 1024 SIMDs (profiles/r01_g_valu_issue_microbench.txt)
+                              "fp64_issue_bound_frac_est": evals / max(kernel_s, 1e-9) * 4.5 / 64 * 4.76
+                                                           / (1024 * 2.4e9)}},
         "checksum": float(ssf.sum()),
     }
     if world.rank == 0 and world.world == 1 and not args.no_cpu_baseline:

@@ -288,6 +288,7 @@ struct mdx_msd {
     DeviceBuffer d_f32, d_index, d_prev, d_image;   // trajectory-file path: frames, unwrap state
     DeviceBuffer d_masses, d_com_x, d_shift;        // system centre of mass per frame
     bool own_fft = false;                           // n_fft = 2^18..2^20: mdx_msd_fft.hpp, not rocFFT
+    int64_t fft_batch_atoms = 0;                    // own transform: particles per batch (0: no batching)
     msdfft::Shape shape;
     DeviceBuffer d_tw, d_pfull;                     // twiddle tables [2][512], full-spectrum sums [B][N]
     StreamTimer timer;
@@ -320,7 +321,8 @@ static int msd_push_device(mdx_msd *h, int group, const double *d_pos, int64_t n
     const int64_t n_chunks = ceil_div(count, chunk);
     chunk = ceil_div(count, n_chunks);
     if (h->own_fft) {
-        const int64_t p_pad_max = ceil_div(ceil_div(chunk * 3, 2), msdfft::PG) * msdfft::PG;
+        const int64_t most = h->fft_batch_atoms > 0 ? std::min(h->fft_batch_atoms, chunk) : chunk;
+        const int64_t p_pad_max = ceil_div(ceil_div(most * 3, 2), msdfft::PG) * msdfft::PG;
         MDX_TRY(h->d_spec.ensure(size_t(B) * h->n_fft * p_pad_max * 16));
     } else {
         MDX_TRY(h->d_series.ensure(size_t(chunk) * 3 * B * h->n_fft * 8));
@@ -333,13 +335,21 @@ static int msd_push_device(mdx_msd *h, int group, const double *d_pos, int64_t n
         hipLaunchKernelGGL(msd_sums_kernel, dim3((unsigned)(B * h->t_block)), dim3(192), 0, h->stream,
                            d_pos, n_total, first + a0, c, zero_dims, h->traj(group), h->dsq(group));
         if (h->own_fft) {
-            const int p_pad = (int)(ceil_div(ceil_div(n_elem, 2), msdfft::PG) * msdfft::PG);
             // tables: half table of W_R1, half table of W_R2, W_N^m for m < R2
             const double2 *tw_r1 = h->d_tw.as<double2>(), *tw_r2 = tw_r1 + h->shape.r1 / 2,
                           *twN = tw_r2 + h->shape.r2 / 2;
-            msdfft::launch(h->shape, h->stream, d_pos, n_total, first + a0, n_elem, h->t_block, B,
-                           zero_dims, p_pad, tw_r1, tw_r2, twN, h->d_spec.as<double2>(),
-                           h->d_pfull.as<double>(), h->nc, h->power(group));
+            // Batches of `sub` particles whose half-transformed block Y (written by pass A, read
+            // once by pass B) fits the 256 MB memory-side cache: pass B then reads it from there,
+            // and the same addresses are reused by the next batch.
+            const int64_t sub = h->fft_batch_atoms > 0 ? std::min<int64_t>(h->fft_batch_atoms, c) : c;
+            for (int64_t s0 = 0; s0 < c; s0 += sub) {
+                const int64_t ne = std::min(sub, c - s0) * 3;
+                const int p_pad = (int)(ceil_div(ceil_div(ne, 2), msdfft::PG) * msdfft::PG);
+                msdfft::launch(h->shape, h->stream, d_pos, n_total, first + a0 + s0, ne, h->t_block, B,
+                               zero_dims, p_pad, tw_r1, tw_r2, twN, h->d_spec.as<double2>(),
+                               h->d_pfull.as<double>(), s0 > 0 ? 1 : 0);
+            }
+            msdfft::launch_fold(h->shape, h->stream, h->d_pfull.as<double>(), B, h->nc, h->power(group));
             // positions read twice (sums, pass A), Y written and read once
             h->bytes_moved += c * 3 * B * (2 * h->t_block * 8 + 2 * h->n_fft * 8);
             continue;
@@ -608,6 +618,14 @@ int mdx_msd_create(mdx_msd_t *out, int dev, int64_t n_frames_block, int n_blocks
                 break;
             }
             if ((rc = h->d_pfull.ensure(size_t(8) * n_blocks * h->n_fft)) != MDX_OK) break;
+            // batch size in MiB of Y (MDX_MSD_BATCH_MB, 0 = whole chunks), whole groups of 16
+            // particles = 3 pair groups
+            const char *env = getenv("MDX_MSD_BATCH_MB");
+            const int64_t mb = env ? atoll(env) : 0;
+            if (mb > 0) {
+                const int64_t atoms = (mb << 20) / (int64_t(3) * n_blocks * h->n_fft * 8);
+                h->fft_batch_atoms = std::max<int64_t>(16, atoms / 16 * 16);
+            }
         }
     } while (0);
     if (rc != MDX_OK) {

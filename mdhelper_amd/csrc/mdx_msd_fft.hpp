@@ -162,12 +162,12 @@ template <int M> __device__ __forceinline__ void fft_wave(double2 *z, const doub
         stockham_stage<M, M / 64, 64, false>(z, tw, lane, n_live);   // radix 16
 }
 
-// Pass A.  grid (pair groups, COLS_SPLIT column ranges, blocks of the trajectory), 512 threads.
+// Pass A.  grid (pair groups, column ranges, blocks of the trajectory), 512 threads; gridDim.y
+// (a power of two <= R2 / 2) splits the R2 columns so that small batches still fill the chip.
 // pos: float64 [B * t_block][n_total][3]; the chunk's coordinates are e in [0, n_elem) behind
 // particle `first`; coordinate e belongs to pair e / 2 (real part: even e).
 // A block walks its columns in order: while one column is transformed the next column's rows
 // are already in flight (registers).  t_block <= N / 2: at most R1 / 2 live rows.
-constexpr int COLS_SPLIT = 4;
 
 template <int R1, int R2>
 __global__ __launch_bounds__(THREADS, R1 == 512 ? 4 : 2) void msd_fft_cols_kernel(
@@ -182,7 +182,8 @@ __global__ __launch_bounds__(THREADS, R1 == 512 ? 4 : 2) void msd_fft_cols_kerne
     __shared__ double2 s_h[R1 / 2];   // exp(-2 pi i m / R1), m < R1 / 2
     __shared__ double2 s_n[R2];       // exp(-2 pi i m / N),  m < R2
     const int pg = blockIdx.x, b = blockIdx.z;
-    const int n2_begin = blockIdx.y * (R2 / COLS_SPLIT);
+    const int n2_count = R2 / int(gridDim.y);
+    const int n2_begin = blockIdx.y * n2_count;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < R1 / 2; i += THREADS)
         s_h[i] = tw_r1[i];
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(THREADS, R1 == 512 ? 4 : 2) void msd_fft_cols_kerne
     }
     MDX_COLS_LOAD(n2_begin)
     __syncthreads();
-    for (int n2 = n2_begin; n2 < n2_begin + R2 / COLS_SPLIT; ++n2) {
+    for (int n2 = n2_begin; n2 < n2_begin + n2_count; ++n2) {
 #pragma unroll
         for (int i = 0; i < LOADS; ++i)
             dst[2 * (row0 + 32 * i)] = x[i];
@@ -235,11 +236,11 @@ __global__ __launch_bounds__(THREADS, R1 == 512 ? 4 : 2) void msd_fft_cols_kerne
 }
 
 // Pass B.  grid (k1 < R1, blocks of the trajectory), 512 threads; thread = k2 (and k2 + 512).
-// Pfull[b][k1][k2] = sum over all pairs of |Z_{k1 + R1 k2}|^2  (overwritten).
+// Pfull[b][k1][k2] (+)= sum over the pairs of this launch of |Z_{k1 + R1 k2}|^2.
 template <int R1, int R2>
 __global__ __launch_bounds__(THREADS, R2 == 512 ? 4 : 2) void msd_fft_rows_power_kernel(
     const double2 *__restrict__ Y, int p_pad, const double2 *__restrict__ tw_r2,
-    double *__restrict__ Pfull)
+    double *__restrict__ Pfull, int accumulate)
 {
     constexpr int ZS = R2 + 1;
     constexpr int LOADS = R2 * PG / THREADS;    // 8 or 16 complex values per thread and group
@@ -296,8 +297,10 @@ __global__ __launch_bounds__(THREADS, R2 == 512 ? 4 : 2) void msd_fft_rows_power
 #undef MDX_ROWS_LOAD
 #undef MDX_ROWS_PUT
 #pragma unroll
-    for (int i = 0; i < OUTS; ++i)
-        Pfull[(int64_t(b) * R1 + k1) * R2 + tid + THREADS * i] = acc[i];
+    for (int i = 0; i < OUTS; ++i) {
+        double *o = Pfull + (int64_t(b) * R1 + k1) * R2 + tid + THREADS * i;
+        *o = accumulate ? *o + acc[i] : acc[i];
+    }
 }
 
 // P[b][k] += (Pfull[b][k] + Pfull[b][N - k]) / 2 for the half spectrum k <= N/2, with Pfull
@@ -337,18 +340,23 @@ inline Shape shape_for(int64_t n_fft)
 }
 
 // tw_r1 / tw_r2: half tables exp(-2 pi i m / R), m < R / 2; twN: exp(-2 pi i m / N), m < R2
+// One batch of coordinates -> Pfull; accumulate != 0 adds to what earlier batches left there.
 inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64_t n_total,
                    int64_t first, int64_t n_elem, int64_t t_block, int n_blocks, int zero_dims,
                    int p_pad, const double2 *tw_r1, const double2 *tw_r2, const double2 *twN,
-                   double2 *Y, double *Pfull, int64_t nc, double *P)
+                   double2 *Y, double *Pfull, int accumulate)
 {
-    const dim3 ga((unsigned)(p_pad / PG), COLS_SPLIT, (unsigned)n_blocks);
+    // >= ~1024 blocks of pass A where the batch allows it
+    int split = 4;
+    while (split < sh.r2 / 2 && int64_t(p_pad / PG) * split * n_blocks < 1024)
+        split *= 2;
+    const dim3 ga((unsigned)(p_pad / PG), (unsigned)split, (unsigned)n_blocks);
     const dim3 gb((unsigned)sh.r1, (unsigned)n_blocks);
 #define MDX_MSDFFT_LAUNCH(A, B)                                                                    \
     hipLaunchKernelGGL((msd_fft_cols_kernel<A, B>), ga, dim3(THREADS), 0, stream, pos, n_total, first, \
                        n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y);                          \
     hipLaunchKernelGGL((msd_fft_rows_power_kernel<A, B>), gb, dim3(THREADS), 0, stream, Y, p_pad,     \
-                       tw_r2, Pfull)
+                       tw_r2, Pfull, accumulate)
     if (sh.r1 == 512 && sh.r2 == 512) {
         MDX_MSDFFT_LAUNCH(512, 512);
     } else if (sh.r1 == 1024 && sh.r2 == 512) {
@@ -357,6 +365,11 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
         MDX_MSDFFT_LAUNCH(1024, 1024);
     }
 #undef MDX_MSDFFT_LAUNCH
+}
+
+inline void launch_fold(const Shape &sh, hipStream_t stream, const double *Pfull, int n_blocks,
+                        int64_t nc, double *P)
+{
     hipLaunchKernelGGL(msd_power_fold_kernel, dim3((unsigned)((nc + 255) / 256), (unsigned)n_blocks),
                        dim3(256), 0, stream, Pfull, sh.r1, sh.r2, nc, P);
 }

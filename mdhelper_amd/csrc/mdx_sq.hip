@@ -33,18 +33,19 @@ using namespace mdx_sq_dev;
 
 namespace {
 
-__global__ __launch_bounds__(256) void sq_pair_kernel(const double2 *__restrict__ rho, int n_frames,
-                                                      int n_groups, int n_split, int n_q,
-                                                      const int *__restrict__ pairs, int n_pairs,
-                                                      double *__restrict__ acc)
+constexpr int PAIR_Q = 64, PAIR_FS = 16;   // wavevectors x interleaved frame subsets per block
+
+__global__ __launch_bounds__(PAIR_Q * PAIR_FS) void sq_pair_kernel(
+    const double2 *__restrict__ rho, int n_frames, int n_groups, int n_split, int n_q,
+    const int *__restrict__ pairs, int n_pairs, double *__restrict__ acc)
 {
-    const int qi = blockIdx.x * 256 + threadIdx.x;
+    __shared__ double part[PAIR_FS][PAIR_Q];
+    const int lane = threadIdx.x % PAIR_Q, fs = threadIdx.x / PAIR_Q;
+    const int qi = blockIdx.x * PAIR_Q + lane;
     const int p = blockIdx.y;
-    if (qi >= n_q)
-        return;
     const int j = pairs[2 * p], k = pairs[2 * p + 1];
     double sum = 0.0;
-    for (int f = 0; f < n_frames; ++f) {
+    for (int f = fs; f < n_frames && qi < n_q; f += PAIR_FS) {
         const double2 *R = rho + int64_t(f) * n_groups * n_split * n_q;
         auto group_rho = [&](int g) {
             double2 r = make_double2(0.0, 0.0);
@@ -71,7 +72,14 @@ __global__ __launch_bounds__(256) void sq_pair_kernel(const double2 *__restrict_
             sum += 2.0 * (a.x * b.x + a.y * b.y);
         }
     }
-    acc[int64_t(p) * n_q + qi] += sum;
+    part[fs][lane] = sum;
+    __syncthreads();
+    if (fs == 0 && qi < n_q) {
+        double total = 0.0;   // fixed order: the result does not depend on scheduling
+        for (int s = 0; s < PAIR_FS; ++s)
+            total += part[s][lane];
+        acc[int64_t(p) * n_q + qi] += total;
+    }
 }
 
 // float64 positions -> F[q] for the function-level drop-in (one pseudo-frame, one group)
@@ -126,6 +134,11 @@ struct mdx_sq {
     SqLattice lat{};
     size_t lat_lds = 0;
     // column form of the lattice path (mdx_sq_device.hpp): items, block size, its own tile
+    bool quads = false;          // register-blocked columns (sq_rho_quads_kernel)
+    int n_qitems = 0, items_p2 = 0, n_sub = 1;
+    SqLattice quad_lat{};
+    size_t quad_lds = 0;
+    DeviceBuffer d_qitems;
     bool columns = false;
     int n_items = 0, col_threads = 0;
     SqLattice col_lat{};
@@ -139,14 +152,19 @@ static int sq_accumulate_device(mdx_sq *h, const float *d_pos, int64_t n, int64_
         return MDX_OK;
     MDX_REQUIRE(n >= h->n_total, "positions hold %lld particles but the groups span %lld",
                 (long long)n, (long long)h->n_total);
-    const int qblocks = h->columns ? (int)ceil_div(h->n_items, h->col_threads)
-                                   : (int)ceil_div(h->n_q, SQ_QPB);
+    const int qblocks = h->quads     ? (int)ceil_div(int64_t(h->items_p2) * h->n_sub, SQ_QUAD_THREADS)
+                        : h->columns ? (int)ceil_div(h->n_items, h->col_threads)
+                                     : (int)ceil_div(h->n_q, SQ_QPB);
     // split the particles when frames x q-blocks x groups alone would not fill 256 CUs
     int64_t max_group = 0;
     for (int g = 0; g < h->n_groups; ++g)
         max_group = std::max(max_group, h->offsets[g + 1] - h->offsets[g]);
+    // ... counted in waves: 256 CUs x 4 SIMDs x ~8 resident waves (MDX_SQ_WAVES overrides)
+    const int block_waves = (h->quads ? SQ_QUAD_THREADS : h->columns ? h->col_threads : SQ_THREADS) / 64;
+    static const int64_t want_waves = getenv("MDX_SQ_WAVES") ? atoll(getenv("MDX_SQ_WAVES")) : 4096;
     int n_split = 1;
-    while (int64_t(qblocks) * h->n_groups * n_split * std::min<int64_t>(n_frames, 4096) < 1024 &&
+    while (int64_t(qblocks) * block_waves * h->n_groups * n_split * std::min<int64_t>(n_frames, 4096) <
+               want_waves &&
            n_split < 64 && max_group / (n_split * 2) >= 2 * SQ_TILE)
         n_split *= 2;
     const int64_t rho_per_frame = int64_t(h->n_groups) * n_split * h->n_q * 16;
@@ -157,7 +175,13 @@ static int sq_accumulate_device(mdx_sq *h, const float *d_pos, int64_t n, int64_
     hipEvent_t ev = h->timer.begin();
     for (int64_t f0 = 0; f0 < n_frames; f0 += slab) {
         const int64_t nf = std::min(slab, n_frames - f0);
-        if (h->columns)
+        if (h->quads)
+            hipLaunchKernelGGL(sq_rho_quads_kernel, dim3(qblocks, h->n_groups * n_split, (unsigned)nf),
+                               dim3(SQ_QUAD_THREADS), h->quad_lds, h->stream, d_pos + f0 * n * 3, n,
+                               h->d_qitems.as<SqQuadItem>(), h->n_qitems, h->items_p2, h->n_sub,
+                               (int)h->n_q, h->quad_lat, h->d_offsets.as<int64_t>(), h->n_groups,
+                               n_split, h->d_rho.as<double2>());
+        else if (h->columns)
             hipLaunchKernelGGL(sq_rho_columns_kernel, dim3(qblocks, h->n_groups * n_split, (unsigned)nf),
                                dim3(h->col_threads), h->col_lds, h->stream, d_pos + f0 * n * 3, n,
                                h->d_items.as<SqColumnItem>(), h->n_items, (int)h->n_q, h->col_lat,
@@ -174,8 +198,8 @@ static int sq_accumulate_device(mdx_sq *h, const float *d_pos, int64_t n, int64_
                                dim3(SQ_THREADS), 0, h->stream, d_pos + f0 * n * 3, n,
                                h->d_q.as<double>(), (int)h->n_q, h->d_offsets.as<int64_t>(),
                                h->n_groups, n_split, h->d_rho.as<double2>());
-        hipLaunchKernelGGL(sq_pair_kernel, dim3((unsigned)ceil_div(h->n_q, 256), h->n_pairs),
-                           dim3(256), 0, h->stream, h->d_rho.as<double2>(), (int)nf, h->n_groups,
+        hipLaunchKernelGGL(sq_pair_kernel, dim3((unsigned)ceil_div(h->n_q, PAIR_Q), h->n_pairs),
+                           dim3(PAIR_Q * PAIR_FS), 0, h->stream, h->d_rho.as<double2>(), (int)nf, h->n_groups,
                            n_split, (int)h->n_q, h->d_pairs.as<int>(), h->n_pairs,
                            h->d_acc.as<double>());
     }
@@ -241,8 +265,40 @@ int mdx_sq_create(mdx_sq_t *out, int dev, const double *wavevectors, int64_t n_q
                 rc = fail(MDX_ERR_HIP, "lattice table setup failed");
                 break;
             }
+            std::vector<SqQuadItem> qitems;
+            if (!getenv("MDX_SQ_NO_COLUMNS") && !getenv("MDX_SQ_NO_QUADS") &&
+                sq_build_quads(trip, n_q, h->lat, qitems)) {
+                h->n_qitems = (int)qitems.size();
+                h->items_p2 = 1;
+                while (h->items_p2 < h->n_qitems)
+                    h->items_p2 *= 2;
+                h->n_sub = std::max(1, SQ_QUAD_THREADS / h->items_p2);
+                if (h->n_sub == 1)
+                    h->items_p2 = h->n_qitems;   // whole blocks of distinct items
+                // two blocks per CU, two table sets per block: ~36 KB per set; the tile is a
+                // multiple of the copies per item
+                const int total_r = h->lat.R[0] + h->lat.R[1] + h->lat.R[2];
+                const int unit = std::max(16, h->n_sub);
+                const int tile = (int)(std::min<size_t>(512, size_t(36) * 1024 / (size_t(16) * total_r) -
+                                                                 SQ_QUAD_PAD) / unit * unit);
+                if (tile >= 16) {
+                    h->quad_lat = h->lat;
+                    h->quad_lat.tile = tile;
+                    h->quad_lds = std::max<size_t>(size_t(32) * (tile + SQ_QUAD_PAD) * total_r + 256, size_t(32) * 1024);
+                    if ((rc = h->d_qitems.ensure(sizeof(SqQuadItem) * qitems.size())) != MDX_OK) break;
+                    if (hipMemcpy(h->d_qitems.ptr, qitems.data(), sizeof(SqQuadItem) * qitems.size(),
+                                  hipMemcpyHostToDevice) != hipSuccess ||
+                        hipFuncSetAttribute(reinterpret_cast<const void *>(sq_rho_quads_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)h->quad_lds) != hipSuccess) {
+                        rc = fail(MDX_ERR_HIP, "quad table setup failed");
+                        break;
+                    }
+                    h->quads = true;
+                }
+            }
             std::vector<SqColumnItem> items;
-            if (!getenv("MDX_SQ_NO_COLUMNS") && sq_build_columns(trip, n_q, h->lat, items)) {
+            if (!h->quads && !getenv("MDX_SQ_NO_COLUMNS") && sq_build_columns(trip, n_q, h->lat, items)) {
                 h->n_items = (int)items.size();
                 const int waves = (int)std::min<int64_t>(4, ceil_div(h->n_items, 64));
                 h->col_threads = 64 * waves;
@@ -283,7 +339,7 @@ int mdx_sq_destroy(mdx_sq_t h)
     h->timer.destroy();
     h->pipe.destroy();
     for (DeviceBuffer *b : {&h->d_q, &h->d_offsets, &h->d_pairs, &h->d_acc, &h->d_rho, &h->d_stage[0],
-                            &h->d_stage[1], &h->d_index, &h->d_mtrip, &h->d_items})
+                            &h->d_stage[1], &h->d_index, &h->d_mtrip, &h->d_items, &h->d_qitems})
         b->release();
     if (h->stream)
         (void)hipStreamDestroy(h->stream);

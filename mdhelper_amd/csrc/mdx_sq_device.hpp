@@ -246,8 +246,8 @@ __global__ __launch_bounds__(256) void sq_rho_columns_kernel(
 #pragma unroll
             for (int j = 0; j < SQ_ZPT; ++j) {
                 const double2 ez = r2[it.z[j]];
-                ar[j] += fma(tr, ez.x, -ti * ez.y);
-                ai[j] += fma(tr, ez.y, ti * ez.x);
+                ar[j] = fma(tr, ez.x, fma(-ti, ez.y, ar[j]));
+                ai[j] = fma(tr, ez.y, fma(ti, ez.x, ai[j]));
             }
         }
     }
@@ -258,6 +258,248 @@ __global__ __launch_bounds__(256) void sq_rho_columns_kernel(
             if (j < it.nz)
                 out[it.q[j]] = make_double2(ar[j], ai[j]);
     }
+}
+
+// Register-blocked form of the column kernel: one thread owns SQ_QCOLS columns (m_x, m_y) that
+// share a list of SQ_ZPT m_z values — a 4 x 8 block of accumulators fed by 8 + 8 table reads per
+// particle instead of 2 + 8 per column (the column kernel is bound by its LDS reads: 1.25 16-byte
+// reads per term against four fp64 FMAs).  Threads beyond the item count take further copies of
+// the items for interleaved particles (sub = thread / items_p2) and are summed at the end.
+// Dynamic LDS: max(two table sets, 32 KB).
+constexpr int SQ_QCOLS = 4;
+constexpr int SQ_QUAD_THREADS = 256;
+
+struct SqQuadItem {
+    short i0[SQ_QCOLS], i1[SQ_QCOLS];   // table offsets of the columns
+    short z[SQ_ZPT];                    // table offsets m_z - mmin_z
+    int q[SQ_QCOLS][SQ_ZPT];            // wavevector index of each entry, -1: none
+};
+
+// Tables of a tile: tab[axis][m][particle] (particle fastest, row stride `lat.tile + SQ_QUAD_PAD`
+// entries), two sets so that the next tile is filled while the current one is consumed: one
+// barrier per tile.  A thread's particles of a tile are consecutive, which turns the particle
+// index into the immediate offset of the ds_read instructions.
+constexpr int SQ_QUAD_PAD = 1;
+
+__device__ __forceinline__ void sq_quad_fill(double2 *set, const SqLattice &lat, int stride,
+                                             const float *P, int64_t base, int cnt, int tid)
+{
+    for (int t = tid; t < cnt * 3; t += SQ_QUAD_THREADS) {
+        const int a = t / 3, k = t - 3 * a;
+        const double theta = lat.base[k] * (double)P[(base + a) * 3 + k];
+        double2 *col = set + size_t(k == 0 ? 0 : k == 1 ? lat.R[0] : lat.R[0] + lat.R[1]) * stride + a;
+        double s1, c1;
+        sincos_f64(theta, s1, c1);
+        const int mmin = lat.mmin[k], mmax = mmin + lat.R[k] - 1;
+        double er = 1.0, ei = 0.0;                 // E(0) upwards
+        for (int m = 0; m <= mmax; ++m) {
+            if (m >= mmin)
+                col[size_t(m - mmin) * stride] = make_double2(er, ei);
+            const double nr = fma(er, c1, -ei * s1), ni = fma(er, s1, ei * c1);
+            er = nr;
+            ei = ni;
+        }
+        er = c1;
+        ei = -s1;                                  // E(-1) downwards
+        for (int m = -1; m >= mmin; --m) {
+            if (m <= mmax)
+                col[size_t(m - mmin) * stride] = make_double2(er, ei);
+            const double nr = fma(er, c1, ei * s1), ni = fma(ei, c1, -er * s1);
+            er = nr;
+            ei = ni;
+        }
+    }
+}
+
+__global__ __launch_bounds__(SQ_QUAD_THREADS, 2) void sq_rho_quads_kernel(
+    const float *__restrict__ pos, int64_t n_atoms, const SqQuadItem *__restrict__ items,
+    int n_items, int items_p2, int n_sub, int n_q, SqLattice lat,
+    const int64_t *__restrict__ group_offsets, int n_groups, int n_split, double2 *__restrict__ rho)
+{
+    extern __shared__ double2 lat_tab[];
+    const int tid = threadIdx.x, T = SQ_QUAD_THREADS;
+    const int slot = blockIdx.x * T + tid;
+    const int item = n_sub > 1 ? (slot & (items_p2 - 1)) : slot;
+    const int sub = n_sub > 1 ? slot / items_p2 : 0;
+    const bool live = item < n_items;
+    const int g = blockIdx.y / n_split, sp = blockIdx.y % n_split;
+    const int frame = blockIdx.z;
+    const int A = lat.tile, stride = A + SQ_QUAD_PAD;
+    const int total_r = lat.R[0] + lat.R[1] + lat.R[2];
+    const int set_len = total_r * stride;          // entries per table set
+    const int chunk = A / n_sub;                   // particles per thread and tile (A % n_sub == 0)
+    const SqQuadItem *it = items + min(item, n_items - 1);
+    // byte offsets of this thread's 16 read streams, at its first particle of a tile
+    int o0[SQ_QCOLS], o1[SQ_QCOLS], oz[SQ_ZPT];
+#pragma unroll
+    for (int c = 0; c < SQ_QCOLS; ++c) {
+        o0[c] = (it->i0[c] * stride + sub * chunk) * 16;
+        o1[c] = ((lat.R[0] + it->i1[c]) * stride + sub * chunk) * 16;
+    }
+#pragma unroll
+    for (int j = 0; j < SQ_ZPT; ++j)
+        oz[j] = ((lat.R[0] + lat.R[1] + it->z[j]) * stride + sub * chunk) * 16;
+    double ar[SQ_QCOLS][SQ_ZPT], ai[SQ_QCOLS][SQ_ZPT];
+#pragma unroll
+    for (int c = 0; c < SQ_QCOLS; ++c)
+#pragma unroll
+        for (int j = 0; j < SQ_ZPT; ++j)
+            ar[c][j] = ai[c][j] = 0.0;
+    const int64_t g_lo = group_offsets[g], g_hi = group_offsets[g + 1];
+    const int64_t per = (g_hi - g_lo + n_split - 1) / n_split;
+    const int64_t lo = g_lo + sp * per, hi = min(g_hi, lo + per);
+    const float *P = pos + int64_t(frame) * n_atoms * 3;
+
+    if (lo < hi)
+        sq_quad_fill(lat_tab, lat, stride, P, lo, (int)min<int64_t>(A, hi - lo), tid);
+    __syncthreads();
+    int cur = 0;
+    for (int64_t base = lo; base < hi; base += A, cur ^= 1) {
+        const int cnt = (int)min<int64_t>(A, hi - base);
+        if (base + A < hi)
+            sq_quad_fill(lat_tab + size_t(cur ^ 1) * set_len, lat, stride, P, base + A,
+                         (int)min<int64_t>(A, hi - base - A), tid);
+        const int mine = max(0, min(chunk, cnt - sub * chunk));
+        // byte address of a read = stream offset (per thread) + ib (set and particle)
+        auto at = [&](int stream_bytes, int ib) {
+            return *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(lat_tab) +
+                                                      (stream_bytes + ib));
+        };
+        // Software pipeline: the reads of the next particle's (e_x, e_y) and of the next e_z are
+        // issued before the FMAs that hide their latency (the scheduler, short of registers,
+        // otherwise waits for every read right after issuing it).  The read past a thread's
+        // last particle stays inside the allocation and is discarded.
+        const int ib0 = cur * set_len * 16;
+        double2 ex[SQ_QCOLS], ey[SQ_QCOLS];
+#pragma unroll
+        for (int c = 0; c < SQ_QCOLS; ++c) {
+            ex[c] = at(o0[c], ib0);
+            ey[c] = at(o1[c], ib0);
+        }
+#pragma unroll 1
+        for (int i = 0; i < mine; ++i) {
+            const int ib = ib0 + i * 16;
+            double tr[SQ_QCOLS], ti[SQ_QCOLS];
+#pragma unroll
+            for (int c = 0; c < SQ_QCOLS; ++c) {
+                tr[c] = fma(ex[c].x, ey[c].x, -ex[c].y * ey[c].y);
+                ti[c] = fma(ex[c].x, ey[c].y, ex[c].y * ey[c].x);
+            }
+            double2 ez = at(oz[0], ib);
+#pragma unroll
+            for (int c = 0; c < SQ_QCOLS; ++c) {
+                ex[c] = at(o0[c], ib + 16);
+                ey[c] = at(o1[c], ib + 16);
+            }
+#pragma unroll
+            for (int j = 0; j < SQ_ZPT; ++j) {
+                double2 ezn = ez;
+                if (j + 1 < SQ_ZPT)
+                    ezn = at(oz[j + 1], ib);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < SQ_QCOLS; ++c) {
+                    ar[c][j] = fma(tr[c], ez.x, fma(-ti[c], ez.y, ar[c][j]));
+                    ai[c][j] = fma(tr[c], ez.y, fma(ti[c], ez.x, ai[c][j]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                ez = ezn;
+            }
+        }
+        __syncthreads();
+    }
+    // the copies of an item are summed in a fixed order through LDS (the table space, one column
+    // of the block at a time: 16 doubles per thread)
+    double2 *out = rho + ((int64_t(frame) * n_groups + g) * n_split + sp) * n_q;
+    double *red = reinterpret_cast<double *>(lat_tab);
+#pragma unroll
+    for (int c = 0; c < SQ_QCOLS; ++c) {
+        if (n_sub > 1) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < SQ_ZPT; ++j) {
+                red[(2 * j) * T + tid] = ar[c][j];
+                red[(2 * j + 1) * T + tid] = ai[c][j];
+            }
+            __syncthreads();
+        }
+        if (live && sub == 0) {
+#pragma unroll
+            for (int j = 0; j < SQ_ZPT; ++j) {
+                const int q = it->q[c][j];
+                if (q < 0)
+                    continue;
+                double re = ar[c][j], im = ai[c][j];
+                for (int s2 = 1; s2 < n_sub; ++s2) {
+                    re += red[(2 * j) * T + s2 * items_p2 + item];
+                    im += red[(2 * j + 1) * T + s2 * items_p2 + item];
+                }
+                out[q] = make_double2(re, im);
+            }
+        }
+    }
+}
+
+// Host: quad items of a detected lattice set.  Columns are cut into chunks of SQ_ZPT consecutive
+// m_z; chunks with the same m_z list are grouped four at a time (the last group of a list is
+// padded with a repeated column that writes nothing).  Returns false when less than 60 % of the
+// accumulators would be used (scattered sets: the column kernel serves those).
+inline bool sq_build_quads(const std::vector<short> &trip, int64_t n_q, const SqLattice &lat,
+                           std::vector<SqQuadItem> &items)
+{
+    struct Entry { int mx, my, mz; int q; };
+    std::vector<Entry> e((size_t)n_q);
+    for (int64_t i = 0; i < n_q; ++i)
+        e[(size_t)i] = {trip[4 * i], trip[4 * i + 1], trip[4 * i + 2], (int)i};
+    std::sort(e.begin(), e.end(), [](const Entry &a, const Entry &b) {
+        if (a.mx != b.mx) return a.mx < b.mx;
+        if (a.my != b.my) return a.my < b.my;
+        if (a.mz != b.mz) return a.mz < b.mz;
+        return a.q < b.q;
+    });
+    struct Chunk { std::vector<short> z; short i0, i1; std::vector<int> q; };
+    std::vector<Chunk> chunks;
+    size_t i = 0;
+    while (i < e.size()) {
+        size_t j = i;
+        while (j < e.size() && e[j].mx == e[i].mx && e[j].my == e[i].my)
+            ++j;
+        for (size_t c = i; c < j; c += SQ_ZPT) {
+            Chunk ch;
+            ch.i0 = (short)(e[i].mx - lat.mmin[0]);
+            ch.i1 = (short)(e[i].my - lat.mmin[1]);
+            for (size_t k = c; k < std::min(j, c + SQ_ZPT); ++k) {
+                ch.z.push_back((short)(e[k].mz - lat.mmin[2]));
+                ch.q.push_back(e[k].q);
+            }
+            chunks.push_back(std::move(ch));
+        }
+        i = j;
+    }
+    std::stable_sort(chunks.begin(), chunks.end(),
+                     [](const Chunk &a, const Chunk &b) { return a.z < b.z; });
+    items.clear();
+    for (size_t c = 0; c < chunks.size();) {
+        size_t d = c;
+        while (d < chunks.size() && chunks[d].z == chunks[c].z)
+            ++d;
+        for (size_t k = c; k < d; k += SQ_QCOLS) {
+            SqQuadItem it{};
+            for (int col = 0; col < SQ_QCOLS; ++col) {
+                const bool have = k + col < d;
+                const Chunk &ch = chunks[have ? k + col : k];
+                it.i0[col] = ch.i0;
+                it.i1[col] = ch.i1;
+                for (int z = 0; z < SQ_ZPT; ++z)
+                    it.q[col][z] = (have && z < (int)ch.q.size()) ? ch.q[(size_t)z] : -1;
+            }
+            for (int z = 0; z < SQ_ZPT; ++z)
+                it.z[z] = z < (int)chunks[c].z.size() ? chunks[c].z[(size_t)z] : chunks[c].z[0];
+            items.push_back(it);
+        }
+        c = d;
+    }
+    return !items.empty() && double(n_q) >= 0.6 * double(items.size()) * SQ_QCOLS * SQ_ZPT;
 }
 
 // Host: the column items of a detected lattice set (trip: short[n_q][4]).  Items are ordered

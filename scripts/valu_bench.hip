@@ -10,6 +10,16 @@ __global__ void kern(float *out, int iters)
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7};
     f2 pb = {b, b}, pc = {c, c};
+    double d0 = a0, d1 = 1., d2 = 2., d3 = 3., d4 = 4., d5 = 5., d6 = 6., d7 = 7., db = 1.0001, dc = 0.5;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 q0 = {0, 0, 0, 0}, q1 = q0, q2 = q0, q3 = q0;
+    __shared__ float lds[16384];
+    if (MODE >= 6) {
+        for (int i = threadIdx.x; i < 16384; i += blockDim.x)
+            lds[i] = i;
+        __syncthreads();
+    }
+    const unsigned lds_addr = MODE == 7 ? (threadIdx.x & 63) * 16 : 0;
     for (int i = 0; i < iters; ++i) {
         if (MODE == 0) {   // 8 independent v_fma_f32 x 16
             REP16(asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
@@ -29,8 +39,18 @@ __global__ void kern(float *out, int iters)
             REP16(asm volatile("v_cmp_gt_f32 vcc, %0, %1\n v_cmp_gt_f32 vcc, %1, %2\n v_cmp_gt_f32 vcc, %2, %3\n v_cmp_gt_f32 vcc, %3, %0\n"
                                "v_cmp_gt_f32 vcc, %0, %1\n v_cmp_gt_f32 vcc, %1, %2\n v_cmp_gt_f32 vcc, %2, %3\n v_cmp_gt_f32 vcc, %3, %0\n"
                                :: "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "vcc");)
+        } else if (MODE == 5) {   // 8 independent v_fma_f64
+            REP16(asm volatile("v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %1, %1, %8, %9\n v_fma_f64 %2, %2, %8, %9\n v_fma_f64 %3, %3, %8, %9\n"
+                               "v_fma_f64 %4, %4, %8, %9\n v_fma_f64 %5, %5, %8, %9\n v_fma_f64 %6, %6, %8, %9\n v_fma_f64 %7, %7, %8, %9\n"
+                               : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(db), "v"(dc));)
+        } else if (MODE == 6 || MODE == 7) {   // 8 ds_read_b128: one address for the wave / 16 B per lane
+            REP16(asm volatile("ds_read_b128 %0, %4\n ds_read_b128 %1, %4 offset:1024\n ds_read_b128 %2, %4 offset:2048\n ds_read_b128 %3, %4 offset:3072\n"
+                               "ds_read_b128 %0, %4 offset:4096\n ds_read_b128 %1, %4 offset:5120\n ds_read_b128 %2, %4 offset:6144\n ds_read_b128 %3, %4 offset:7168\n"
+                               "s_waitcnt lgkmcnt(0)\n"
+                               : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(lds_addr) : "memory");)
         }
     }
+    a0 += (float)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7) + q0.x + q1.y + q2.z + q3.w;
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
 }
 template <int MODE> void run(const char *name, int n_instr_per_iter)
@@ -60,5 +80,8 @@ int main()
     run<2>("v_sqrt_f32", 8);
     run<3>("v_pk_add_f32", 4);
     run<4>("v_cmp_gt_f32", 8);
+    run<5>("v_fma_f64", 8);
+    run<6>("ds_read_b128 bc", 8);
+    run<7>("ds_read_b128 ln", 8);
     return 0;
 }

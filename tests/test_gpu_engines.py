@@ -554,22 +554,36 @@ def test_isf_lattice_tables_equal_general_sincos_path(mode, monkeypatch):
 
 
 def test_sq_column_form_equals_lattice_and_general_kernels(monkeypatch):
-    """Grid wavevector sets through the three S(q) kernels: column form (default), per-q lattice
-    tables (MDX_SQ_NO_COLUMNS) and general fp64 sincos (MDX_SQ_NO_LATTICE)."""
+    """Grid wavevector sets through the four S(q) kernels: register-blocked columns (default),
+    column form (MDX_SQ_NO_QUADS), per-q lattice tables (MDX_SQ_NO_COLUMNS) and general fp64
+    sincos (MDX_SQ_NO_LATTICE)."""
     rng = np.random.default_rng(81)
     F, sizes, L = 5, (1700, 1301), np.array([31.0, 29.5, 33.25])
     N = sum(sizes)
     pos = (rng.random((F, N, 3)) * L).astype(np.float32)
-    grid = np.stack(np.meshgrid(*[2 * np.pi * np.arange(-3, 4) / x for x in L], indexing="ij"), -1).reshape(-1, 3)
+
+    def grid_of(lo, hi):
+        return np.stack(np.meshgrid(*[2 * np.pi * np.arange(lo, hi) / x for x in L], indexing="ij"),
+                        -1).reshape(-1, 3)
+
+    grid = grid_of(-3, 4)
+    big = grid_of(-6, 7)
     sets = {"full 7^3 grid": grid,
+            "positive octant 8^3 (one item copy per 16 threads)": grid_of(0, 8),
+            "13^3 grid (two m_z chunks, 86 items)": big,
+            "21 x 21 x 9 grid (more than 256 items: several blocks)":
+                np.stack(np.meshgrid(2 * np.pi * np.arange(-10, 11) / L[0], 2 * np.pi * np.arange(-10, 11) / L[1],
+                                     2 * np.pi * np.arange(0, 9) / L[2], indexing="ij"), -1).reshape(-1, 3),
             "sphere |q| < 0.5": grid[np.linalg.norm(grid, axis=1) < 0.5],
+            "sphere of the 13^3 grid": big[np.linalg.norm(big, axis=1) < 1.1],
             "ragged columns": grid[rng.random(len(grid)) < 0.6]}
     pairs = of.ssf_pairs(2, "partial")
+    envs = ("MDX_SQ_NO_QUADS", "MDX_SQ_NO_COLUMNS", "MDX_SQ_NO_LATTICE")
     for name, q in sets.items():
         out = {}
-        for kind, env in (("columns", {}), ("lattice", {"MDX_SQ_NO_COLUMNS": "1"}),
-                          ("general", {"MDX_SQ_NO_LATTICE": "1"})):
-            for k in ("MDX_SQ_NO_COLUMNS", "MDX_SQ_NO_LATTICE"):
+        for kind, env in (("quads", {}), ("columns", {"MDX_SQ_NO_QUADS": "1"}),
+                          ("lattice", {"MDX_SQ_NO_COLUMNS": "1"}), ("general", {"MDX_SQ_NO_LATTICE": "1"})):
+            for k in envs:
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
@@ -578,11 +592,23 @@ def test_sq_column_form_equals_lattice_and_general_kernels(monkeypatch):
             out[kind] = eng.result()
             eng.close()
         scale = np.abs(out["general"]).max()
-        assert np.allclose(out["columns"], out["general"], rtol=1e-9, atol=1e-9 * scale), name
-        assert np.allclose(out["lattice"], out["general"], rtol=1e-9, atol=1e-9 * scale), name
+        for kind in ("quads", "columns", "lattice"):
+            assert np.allclose(out[kind], out["general"], rtol=1e-9, atol=1e-9 * scale), (name, kind)
+    for k in envs:
+        monkeypatch.delenv(k, raising=False)
     slices = [slice(0, sizes[0]), slice(sizes[0], N)]
     ref = sum(of.ssf_frame_ref(q, pos[f].astype(np.float64), slices, pairs, "partial") for f in range(F))
-    assert np.allclose(out["columns"], ref, rtol=1e-6, atol=1e-9 * np.abs(ref).max())
+    assert np.allclose(out["quads"], ref, rtol=1e-6, atol=1e-9 * np.abs(ref).max())
+    # groups smaller than one table tile, and a single particle
+    for tiny in ((3, 1), (50, 17)):
+        n = sum(tiny)
+        eng = _core.SqEngine(grid, tiny, pairs)
+        eng.accumulate(pos[:, :n])
+        got = eng.result()
+        eng.close()
+        sl = [slice(0, tiny[0]), slice(tiny[0], n)]
+        ref = sum(of.ssf_frame_ref(grid, pos[f, :n].astype(np.float64), sl, pairs, "partial") for f in range(F))
+        assert np.allclose(got, ref, rtol=1e-6, atol=1e-9 * np.abs(ref).max()), tiny
 
 
 @pytest.mark.parametrize("cell", [(42.0, 40.5, 45.25, 75.0, 80.0, 110.0), (36.0, 36.0, 36.0, 60.0, 60.0, 90.0),
