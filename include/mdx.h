@@ -219,6 +219,10 @@ int mdx_msd_push_device(mdx_msd_t h, int group, const double *d_pos, int64_t n_t
 /* msd_self[g][b][t] = sum_particles MSD_particle / N_g  (transport.py:1036-1039, before /2D)
  * sum_traj[g][b][t][3] = sum_particles r(t)            (input of :1034 and :1044-1052) */
 int mdx_msd_result(mdx_msd_t h, double *msd_self_sum, double *sum_traj);
+/* acf_sum[g][b][m] = sum_particles sum_d sum_k x(k) x(k+m), m < n_frames_block, not normalised:
+ * the vector ACF numerator of correlation_fft(..., average=True, vector=True) as called by
+ * EndToEndVector._conclude (src/mdhelper/analysis/polymer.py:765-781) = acf_sum / (N (T - m)). */
+int mdx_msd_result_acf(mdx_msd_t h, double *acf_sum);
 int mdx_msd_allreduce(mdx_msd_t h, mdx_comm_t comm);
 int mdx_msd_stats(mdx_msd_t h, int64_t *launches, double *kernel_ms, int64_t *bytes_moved);
 int mdx_msd_enable_timing(mdx_msd_t h, int on);

@@ -428,6 +428,13 @@ class MsdEngine(_Engine):
         check(lib().mdx_msd_result(self.handle, _ptr(msd), _ptr(traj)))
         return msd, traj
 
+    def result_acf(self):
+        """float64[n_groups, n_blocks, t_block]: sum over the pushed entities and dimensions of
+        ``sum_k x(k) x(k+m)`` (the un-normalised vector ACF; ``mdx_msd_result_acf``)."""
+        acf = np.zeros((self.n_groups, self.n_blocks, self.t_block))
+        check(lib().mdx_msd_result_acf(self.handle, _ptr(acf)))
+        return acf
+
     def reset(self):
         check(lib().mdx_msd_reset(self.handle))
 

@@ -757,9 +757,22 @@ int mdx_msd_push_traj(mdx_msd_t h, int group, mdx_traj_t traj, const int64_t *fr
     return msd_push_traj(h, group, t, frames, index, n, unwrap, dims, zero_dims, shift);
 }
 
+static int msd_result(mdx_msd_t h, double *msd_self_sum, double *acf_sum, double *sum_traj);
+
 int mdx_msd_result(mdx_msd_t h, double *msd_self_sum, double *sum_traj)
 {
     MDX_REQUIRE(h, "NULL handle");
+    return msd_result(h, msd_self_sum, nullptr, sum_traj);
+}
+
+int mdx_msd_result_acf(mdx_msd_t h, double *acf_sum)
+{
+    MDX_REQUIRE(h && acf_sum, "NULL argument");
+    return msd_result(h, nullptr, acf_sum, nullptr);
+}
+
+static int msd_result(mdx_msd_t h, double *msd_self_sum, double *acf_sum, double *sum_traj)
+{
     MDX_TRY(set_device(h->dev));
     const int64_t GB = int64_t(h->n_groups) * h->n_blocks;
     const int64_t Tb = h->t_block;
@@ -767,7 +780,7 @@ int mdx_msd_result(mdx_msd_t h, double *msd_self_sum, double *sum_traj)
         MDX_HIP(hipStreamSynchronize(h->stream));
         MDX_HIP(hipMemcpy(sum_traj, h->d_traj.ptr, size_t(8) * h->traj_len(), hipMemcpyDeviceToHost));
     }
-    if (!msd_self_sum) {
+    if (!msd_self_sum && !acf_sum) {
         h->timer.collect();
         return MDX_OK;
     }
@@ -787,7 +800,10 @@ int mdx_msd_result(mdx_msd_t h, double *msd_self_sum, double *sum_traj)
     h->timer.collect();
     // MSD_m = S_m - 2 A_m   (correlation.py:621-648, summed over the particles)
     const double inv_n = 1.0 / double(h->n_fft);
-    for (int64_t gb = 0; gb < GB; ++gb) {
+    if (acf_sum)   // sum over particles and dimensions of sum_k x(k) x(k+m), not normalised
+        for (int64_t i = 0; i < GB * Tb; ++i)
+            acf_sum[i] = acf[size_t(i)] * inv_n;
+    for (int64_t gb = 0; msd_self_sum && gb < GB; ++gb) {
         const double *d = D.data() + gb * Tb;
         const double *a = acf.data() + gb * Tb;
         double *o = msd_self_sum + gb * Tb;

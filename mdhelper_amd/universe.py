@@ -177,6 +177,12 @@ class _Level:
         return len(self._unique)
 
     @property
+    def n_residues(self):
+        return len(self._unique)
+
+    n_segments = n_residues
+
+    @property
     def masses(self):
         return np.bincount(self._inverse, weights=self._group.masses, minlength=len(self._unique))
 

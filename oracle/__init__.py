@@ -15,6 +15,10 @@ Pinning status:
   (fixtures ``tests/golden/correlation_*.npz`` made by
   ``scripts/make_golden.py``) and against the closed-form answers of
   ``tests/test_algorithm_correlation.py:438-561``.
+* ``oracle.polymer``      — ``EndToEndVector`` frame loop + ``unwrap_edge`` for linear chains
+  restated; its ACF goes through ``oracle.correlation`` (pinned); the reference holds no test
+  or fixture for the class itself, so the class-level restatement is **parity unpinned** and
+  is checked against closed forms (rigid rotors, rotational diffusion).
 * ``oracle.fourier``      — pinned against the reference's
   ``src/mdhelper/algorithm/accelerated.py`` loop bodies run as plain Python
   (fixtures ``tests/golden/fourier_*.npz``).

@@ -353,3 +353,88 @@ def test_rdf_device_centres_of_mass_equal_the_per_frame_path(tmp_path):
                 assert ref.counts.sum() > 0
             assert np.array_equal(fast.results.counts, ref.counts), kw
             assert np.allclose(fast.results.rdf, ref.rdf, rtol=1e-12), kw
+
+
+@pytest.mark.parametrize("case", ["atoms", "residues, two groups, blocks", "unwrap from a file"])
+def test_end_to_end_vector_acf_on_device(case, tmp_path):
+    """``EndToEndVector`` (reference analysis/polymer.py:510-803): the ACF of the unit end-to-end
+    vectors through the correlation engine (power spectra summed over chains and components on the
+    device, one inverse transform per group and block) against the frame-by-frame restatement."""
+    from mdhelper_amd.analysis import polymer
+    from oracle import polymer as op
+    rng = np.random.default_rng(12)
+
+    def chains(T, M, n, L):
+        conf = np.cumsum(rng.normal(scale=0.55, size=(1, M, n, 3)), axis=2)
+        wiggle = np.cumsum(rng.normal(scale=0.06, size=(T, M, n, 3)), axis=0)
+        drift = np.cumsum(rng.normal(scale=0.3, size=(T, M, 1, 3)), axis=0)
+        return (rng.uniform(0, L, (1, M, 1, 3)) + conf + wiggle + drift).reshape(T, M * n, 3)
+
+    if case == "atoms":
+        pos = chains(500, 40, 10, 20.0).astype(np.float32)
+        u = mdhelper_amd.ArrayUniverse(pos, [40, 40, 40, 90, 90, 90], dt=2.0)
+        a = polymer.EndToEndVector(u.atoms, n_chains=40, n_monomers=10, verbose=False).run()
+        ref, _ = op.end_to_end_run_ref(pos, [np.arange(400)], [40], [10], ["atoms"])
+    elif case == "residues, two groups, blocks":
+        pos = chains(301, 12, 18, 20.0).astype(np.float32)           # 12 chains of 6 monomers of 3 atoms
+        masses = rng.uniform(1, 16, pos.shape[1])
+        u = mdhelper_amd.ArrayUniverse(pos, [40, 40, 40, 90, 90, 90], dt=2.0, masses=masses)
+        g1, g2 = u.atoms[:5 * 18], u.atoms[5 * 18:]
+        with pytest.warns(UserWarning, match="not divisible"):
+            a = polymer.EndToEndVector([g1, g2], ["residues", "atoms"], n_chains=(5, 7), n_monomers=(6, 18),
+                                       n_blocks=3, verbose=False).run()
+        ref, _ = op.end_to_end_run_ref(pos, [g1.indices, g2.indices], [5, 7], [6, 18], ["residues", "atoms"],
+                                       masses=masses, n_blocks=3)
+        assert a.results.acf.shape == (2, 3, 100)
+    else:
+        from trajfiles import write_amber_netcdf
+        L = np.array([11.0, 12.0, 10.5])
+        pos = chains(400, 30, 8, 11.0)
+        wrapped = np.mod(pos, L).astype(np.float32)
+        path = tmp_path / "chains.nc"
+        write_amber_netcdf(path, wrapped, L, times=np.arange(400) * 2.0)
+        u = mdhelper_amd.FileUniverse(path, dt=2.0)
+        a = polymer.EndToEndVector(u.atoms, n_chains=30, n_monomers=8, unwrap=True, n_blocks=2,
+                                   verbose=False).run()
+        ref, e2e = op.end_to_end_run_ref(wrapped, [np.arange(240)], [30], [8], ["atoms"], dimensions=L,
+                                         unwrap=True, n_blocks=2)
+        true = pos.reshape(400, 30, 8, 3)
+        assert np.allclose(e2e, true[:, :, -1] - true[:, :, 0], atol=1e-4)
+    assert np.allclose(a.results.acf, ref, rtol=1e-9, atol=1e-11)
+    assert np.allclose(a.results.acf[..., 0], 1.0, atol=1e-12)
+    direct = polymer.EndToEndVector(*([u.atoms] if case != "residues, two groups, blocks" else [[g1, g2],
+                                    ["residues", "atoms"]]),
+                                    **({"n_chains": 40, "n_monomers": 10} if case == "atoms" else
+                                       {"n_chains": (5, 7), "n_monomers": (6, 18), "n_blocks": 3}
+                                       if case.startswith("residues") else
+                                       {"n_chains": 30, "n_monomers": 8, "unwrap": True, "n_blocks": 2}),
+                                    fft=False, verbose=False)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        direct.run()
+    assert np.allclose(direct.results.acf, a.results.acf, rtol=1e-9, atol=1e-11)
+
+
+def test_end_to_end_relaxation_time_of_rotational_diffusion():
+    """Dumbbells whose orientation diffuses on the sphere: C_ee decays exponentially with
+    tau = 1 / (2 D_r); the fitted relaxation time recovers it."""
+    from mdhelper_amd.analysis import polymer
+    rng = np.random.default_rng(4)
+    T, M, sigma = 4000, 600, 0.05
+    u_vec = rng.normal(size=(M, 3))
+    u_vec /= np.linalg.norm(u_vec, axis=1, keepdims=True)
+    pos = np.empty((T, 2 * M, 3), dtype=np.float32)
+    for t in range(T):
+        pos[t, 0::2] = 10.0
+        pos[t, 1::2] = 10.0 + u_vec
+        u_vec = u_vec + sigma * rng.normal(size=(M, 3))
+        u_vec /= np.linalg.norm(u_vec, axis=1, keepdims=True)
+    uni = mdhelper_amd.ArrayUniverse(pos, [20, 20, 20, 90, 90, 90], dt=1.0)
+    e = polymer.EndToEndVector(uni.atoms, n_chains=M, n_monomers=2, verbose=False).run()
+    e.calculate_relaxation_time()
+    # per step <u.u'> = 1 - sigma^2 (two transverse components): tau = 1 / sigma^2
+    assert e.results.relaxation_times.shape == (1, 1)
+    assert np.isclose(e.results.relaxation_times[0, 0], 1 / sigma ** 2, rtol=0.1)
+    m = np.arange(1, 200)
+    assert np.allclose(e.results.acf[0, 0, 1:200], np.exp(-m * sigma ** 2), atol=0.02)

@@ -109,6 +109,7 @@ class OracleMsdEngine:
         self.tb, self.b, self.g = t_block, n_blocks, n_groups
         self._msd = np.zeros((n_groups, n_blocks, t_block))
         self._traj = np.zeros((n_groups, n_blocks, t_block, 3))
+        self._acf = np.zeros((n_groups, n_blocks, t_block))
 
     def push(self, group, positions, first, count, zero_dims=0):
         from oracle import correlation as oc
@@ -118,9 +119,14 @@ class OracleMsdEngine:
                 p[..., k] = 0
         self._msd[group] += oc.msd_fft_ref(p, axis=1, average=False).sum(axis=-1)
         self._traj[group] += p.sum(axis=2)
+        acf = oc.correlation_fft_ref(p, axis=1, vector=True).sum(axis=-1)       # [B, T_b], per lag mean
+        self._acf[group] += acf * (self.tb - np.arange(self.tb))
 
     def result(self, want_msd=True):
         return self._msd.copy(), self._traj.copy()
+
+    def result_acf(self):
+        return self._acf.copy()
 
     def close(self):
         pass
@@ -147,6 +153,7 @@ def _analyses(comm):
     import mdhelper_amd
     from mdhelper_amd.analysis import (IntermediateScatteringFunction, Onsager,
                                        RadialDistributionFunction, StructureFactor)
+    from mdhelper_amd.analysis.polymer import EndToEndVector
     frames, L, walk = _build_inputs()
     u = mdhelper_amd.ArrayUniverse(frames, [L, L, L, 90, 90, 90])
     rdf = RadialDistributionFunction(u.atoms, n_bins=40, range=(0.0, 6.0), exclusion=(1, 1), comm=comm).run()
@@ -159,7 +166,10 @@ def _analyses(comm):
                                          n_lags=4, incoherent=True, comm=comm).run()
     uw = mdhelper_amd.ArrayUniverse(walk, [14.0, 14.0, 14.0, 90, 90, 90])
     ons = Onsager((uw.atoms[:15], uw.atoms[15:]), temperature=1.0, reduced=True, n_blocks=2, comm=comm).run()
-    return {"counts": rdf.results.counts, "rdf": rdf.results.rdf, "counts_slow": slow.results.counts,
+    # 25 particles = 5 chains of 5 (group 1) ... the first 20 as 4 chains of 5, the rest as 1 chain
+    e2e = EndToEndVector((uw.atoms[:20], uw.atoms[20:]), n_chains=(4, 1), n_monomers=(5, 5), n_blocks=2,
+                         comm=comm).run()
+    return {"acf": e2e.results.acf, "counts": rdf.results.counts, "rdf": rdf.results.rdf, "counts_slow": slow.results.counts,
             "counts_com": com.results.counts, "cisf": isf.results.cisf, "iisf": isf.results.iisf,
             "ssf": sf.results.ssf, "msd_self": ons.results.msd_self, "msd_cross": ons.results.msd_cross}
 
@@ -200,4 +210,5 @@ def test_world_size_2_matches_single_rank(tmp_path):
         assert np.allclose(got["iisf"], single["iisf"], rtol=1e-9, atol=1e-12)
         assert np.allclose(got["msd_self"], single["msd_self"], rtol=1e-9, atol=1e-12)
         assert np.allclose(got["msd_cross"], single["msd_cross"], rtol=1e-9, atol=1e-10)
+        assert np.allclose(got["acf"], single["acf"], rtol=1e-9, atol=1e-12)       # chains shard
     assert single["counts"].sum() > 0 and single["counts_com"].sum() > 0
