@@ -115,6 +115,10 @@ int mdx_rdf_accumulate(mdx_rdf_t h, const float *pos1, int64_t n1, const float *
  * call are then PARTICLES, molecule g owning rows [offsets[g], offsets[g+1]); the histogram is
  * taken over the float32 centres sum_a m_a x_a / M_g.  offsets: int64[n_groups+1], masses:
  * float64[offsets[n_groups]], both on the host; n_groups <= 0 removes the grouping. */
+/* 2-D mode, RadialDistributionFunction(drop_axis=...) (structure.py:761-770): coordinate `axis`
+ * (0, 1, 2; -1 switches the mode off) of both sets is set to zero after the centre-of-mass stage
+ * and the cell length along it becomes max(lx, ly, lz), on the device, for every entry point. */
+int mdx_rdf_set_drop_axis(mdx_rdf_t h, int axis);
 int mdx_rdf_set_grouping(mdx_rdf_t h, int which, int64_t n_groups, const int64_t *offsets,
                          const double *masses);
 /* Same, all pointers in HBM (from mdx_malloc); asynchronous on the handle's stream. */

@@ -191,6 +191,11 @@ class RdfEngine(_Engine):
     def accumulate_device(self, d_pos1, n1, d_pos2, n2, d_boxes, n_frames):
         check(lib().mdx_rdf_accumulate_device(self.handle, d_pos1, n1, d_pos2, n2, d_boxes, n_frames))
 
+    def set_drop_axis(self, axis):
+        """2-D mode: coordinate ``axis`` (0, 1, 2; ``None`` = off) is zeroed on the device and the
+        cell length along it set to the largest one (``mdx_rdf_set_drop_axis``)."""
+        check(lib().mdx_rdf_set_drop_axis(self.handle, -1 if axis is None else int(axis)))
+
     def set_grouping(self, which, offsets, masses):
         """Rows of set ``which`` (1 or 2) become particles of molecules ``[offsets[g], offsets[g+1])``
         whose centres of mass are binned; ``offsets=None`` removes the grouping."""

@@ -58,6 +58,7 @@ _SIGNATURES = {
     "mdx_rdf_reset": (c_int, [_vp]),
     "mdx_rdf_accumulate": (c_int, [_vp, _vp, c_int64, _vp, c_int64, _vp, c_int64]),
     "mdx_rdf_accumulate_device": (c_int, [_vp, _vp, c_int64, _vp, c_int64, _vp, c_int64]),
+    "mdx_rdf_set_drop_axis": (c_int, [_vp, c_int]),
     "mdx_rdf_set_grouping": (c_int, [_vp, c_int, c_int64, _vp, _vp]),
     "mdx_rdf_counts": (c_int, [_vp, _vp]),
     "mdx_rdf_synchronize": (c_int, [_vp]),

@@ -308,7 +308,7 @@ class RadialDistributionFunction(DynamicAnalysisBase):
 
     def run(self, start=None, stop=None, step=None, frames=None, verbose=None, **kwargs):
         traj = self._trajectory
-        fast = _is_array_trajectory(traj) and self._drop_axis is None
+        fast = _is_array_trajectory(traj)
         if not fast:
             return super().run(start=start, stop=stop, step=step, frames=frames, verbose=verbose,
                                **kwargs)
@@ -326,6 +326,8 @@ class RadialDistributionFunction(DynamicAnalysisBase):
             self._engine.set_grouping(1, off1, m1)
         if off2 is not None and not self._same:
             self._engine.set_grouping(2, off2, m2)
+        # 2-D mode: the coordinate is zeroed and the cell stretched on the device (:761-766)
+        self._engine.set_drop_axis(self._drop_axis)
         all1 = len(i1) == traj.n_atoms and np.array_equal(i1, np.arange(len(i1)))
         native = getattr(traj, "native", None)
         if native is not None:
@@ -334,7 +336,12 @@ class RadialDistributionFunction(DynamicAnalysisBase):
         for b0 in np.arange(0, len(mine), block):
             sel = mine[b0:b0 + block]
             boxes = traj.box_block(sel)
-            self._area_or_volume += float(box_volumes(boxes).sum())
+            if self._drop_axis is None:
+                self._area_or_volume += float(box_volumes(boxes).sum())
+            else:
+                self._area_or_volume += float(
+                    np.delete(np.asarray(boxes, dtype=np.float32)[:, :3], self._drop_axis, axis=1)
+                    .prod(axis=1, dtype=np.float32).astype(float).sum())
             if native is not None:
                 self._engine.accumulate_traj(native, sel, boxes, None if all1 else i1,
                                              None if self._same else i2, same=self._same)

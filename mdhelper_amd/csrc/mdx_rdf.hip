@@ -390,6 +390,9 @@ struct mdx_rdf {
         int64_t n_atoms = 0, n_groups = 0;
         DeviceBuffer d_offsets, d_masses, d_total, d_com;
     } grouping[2];
+    // drop_axis (2-D mode, structure.py:761-770): coordinate zeroed, box length -> max(lx, ly, lz)
+    int drop_axis = -1;
+    DeviceBuffer d_drop[2], d_drop_box;
     // host-buffer entry point: double-buffered staging, copy stream, hand-over events
     DeviceBuffer d_stage1[2], d_stage2[2], d_boxes[2], d_index[2];
     StagePipeline pipe;
@@ -784,11 +787,37 @@ static int accumulate_device_points(mdx_rdf *h, const float *d_pos1, int64_t n1,
                                     const float *h_boxes, int64_t n_frames);
 
 // Entry of every accumulate variant: sets with a grouping are reduced to centres of mass first.
+// drop_axis: dst = src with coordinate `axis` set to zero (may run in place)
+__global__ __launch_bounds__(256) void rdf_drop_axis_kernel(const float *src, float *dst,
+                                                            int64_t n_rows, int axis)
+{
+    const int64_t i = blockIdx.x * int64_t(256) + threadIdx.x;
+    if (i >= n_rows * 3)
+        return;
+    dst[i] = (int)(i % 3) == axis ? 0.f : src[i];
+}
+
+// ... and the frame's cell: lengths[axis] = max(lengths) (structure.py:766)
+__global__ __launch_bounds__(256) void rdf_drop_box_kernel(const float *__restrict__ src,
+                                                           float *__restrict__ dst, int64_t n_frames,
+                                                           int axis)
+{
+    const int64_t f = blockIdx.x * int64_t(256) + threadIdx.x;
+    if (f >= n_frames)
+        return;
+    float b[6];
+    for (int k = 0; k < 6; ++k)
+        b[k] = src[6 * f + k];
+    b[axis] = fmaxf(b[0], fmaxf(b[1], b[2]));
+    for (int k = 0; k < 6; ++k)
+        dst[6 * f + k] = b[k];
+}
+
 static int accumulate_device(mdx_rdf *h, const float *d_pos1, int64_t n1, const float *d_pos2,
                              int64_t n2, const float *d_boxes, const float *h_boxes,
                              int64_t n_frames)
 {
-    if (!h->grouping[0].n_groups && !h->grouping[1].n_groups)
+    if (!h->grouping[0].n_groups && !h->grouping[1].n_groups && h->drop_axis < 0)
         return accumulate_device_points(h, d_pos1, n1, d_pos2, n2, d_boxes, h_boxes, n_frames);
     if (n_frames == 0)
         return MDX_OK;
@@ -796,6 +825,9 @@ static int accumulate_device(mdx_rdf *h, const float *d_pos1, int64_t n1, const 
     const float *src[2] = {d_pos1, same ? d_pos1 : d_pos2};
     int64_t n[2] = {n1, same ? n1 : n2};
     const float *pts[2] = {src[0], src[1]};
+    bool owned[2] = {false, false};
+    MDX_REQUIRE(!same || !h->grouping[1].n_groups || h->grouping[0].n_groups,
+                "a self histogram takes the grouping of set 1");
     for (int g = 0; g < (same ? 1 : 2); ++g) {
         mdx_rdf::Grouping &G = h->grouping[g];
         if (!G.n_groups)
@@ -809,13 +841,40 @@ static int accumulate_device(mdx_rdf *h, const float *d_pos1, int64_t n1, const 
                            G.d_com.as<float>());
         pts[g] = G.d_com.as<float>();
         n[g] = G.n_groups;
+        owned[g] = true;
+    }
+    std::vector<float> boxes_host;
+    if (h->drop_axis >= 0) {
+        // after the centres of mass, as the reference orders it (structure.py:753-766)
+        for (int g = 0; g < (same ? 1 : 2); ++g) {
+            float *dst = const_cast<float *>(pts[g]);
+            if (!owned[g]) {
+                MDX_TRY(h->d_drop[g].ensure(size_t(12) * n[g] * n_frames));
+                dst = h->d_drop[g].as<float>();
+            }
+            const int64_t rows = n[g] * n_frames;
+            hipLaunchKernelGGL(rdf_drop_axis_kernel, dim3((unsigned)ceil_div(rows * 3, 256)), dim3(256), 0,
+                               h->stream, pts[g], dst, rows, h->drop_axis);
+            pts[g] = dst;
+        }
+        if (d_boxes) {
+            MDX_TRY(h->d_drop_box.ensure(size_t(24) * n_frames));
+            hipLaunchKernelGGL(rdf_drop_box_kernel, dim3((unsigned)ceil_div(n_frames, 256)), dim3(256), 0,
+                               h->stream, d_boxes, h->d_drop_box.as<float>(), n_frames, h->drop_axis);
+            d_boxes = h->d_drop_box.as<float>();
+            if (h_boxes) {
+                boxes_host.assign(h_boxes, h_boxes + 6 * n_frames);
+                for (int64_t f = 0; f < n_frames; ++f) {
+                    float *b = boxes_host.data() + 6 * f;
+                    b[h->drop_axis] = std::max(b[0], std::max(b[1], b[2]));
+                }
+                h_boxes = boxes_host.data();
+            }
+        }
     }
     MDX_HIP(hipGetLastError());
-    if (same) {
-        MDX_REQUIRE(!h->grouping[1].n_groups || h->grouping[0].n_groups,
-                    "a self histogram takes the grouping of set 1");
+    if (same)
         return accumulate_device_points(h, pts[0], n[0], nullptr, n[0], d_boxes, h_boxes, n_frames);
-    }
     return accumulate_device_points(h, pts[0], n[0], pts[1], n[1], d_boxes, h_boxes, n_frames);
 }
 
@@ -960,7 +1019,7 @@ int mdx_rdf_destroy(mdx_rdf_t h)
                             &h->grouping[1].d_offsets, &h->grouping[1].d_masses,
                             &h->grouping[1].d_total, &h->grouping[1].d_com, &h->d_misc, &h->d_pw1,
                             &h->d_po1, &h->d_bb1, &h->d_pw2, &h->d_po2, &h->d_bb2, &h->d_bb16_1,
-                            &h->d_bb16_2})
+                            &h->d_bb16_2, &h->d_drop[0], &h->d_drop[1], &h->d_drop_box})
         b->release();
     if (h->stream)
         (void)hipStreamDestroy(h->stream);
@@ -981,6 +1040,14 @@ int mdx_rdf_reset(mdx_rdf_t h)
     h->pairs_evaluated = 0;
     h->pairs_bruteforce = 0;
     h->reduced_global = false;
+    return MDX_OK;
+}
+
+int mdx_rdf_set_drop_axis(mdx_rdf_t h, int axis)
+{
+    MDX_REQUIRE(h, "NULL handle");
+    MDX_REQUIRE(axis >= -1 && axis <= 2, "axis must be 0, 1, 2 or -1 (none)");
+    h->drop_axis = axis;
     return MDX_OK;
 }
 

@@ -438,3 +438,47 @@ def test_end_to_end_relaxation_time_of_rotational_diffusion():
     assert np.isclose(e.results.relaxation_times[0, 0], 1 / sigma ** 2, rtol=0.1)
     m = np.arange(1, 200)
     assert np.allclose(e.results.acf[0, 0, 1:200], np.exp(-m * sigma ** 2), atol=0.02)
+
+
+@pytest.mark.parametrize("axis", ["x", 1, "z"])
+def test_rdf_drop_axis_on_device_all_entry_points(axis, tmp_path):
+    """2-D mode (structure.py:761-770) on the device: coordinate zeroed after the centre-of-mass
+    stage, cell length along it = the largest one; batched in-memory path, file path and the
+    frame-by-frame restatement agree bit for bit, counts and normalisation."""
+    from trajfiles import write_amber_netcdf
+    rng = np.random.default_rng(31)
+    Lf = np.array([21.0, 26.5, 23.25], dtype=np.float32)
+    F, N = 6, 1200
+    frames = (rng.random((F, N, 3)) * Lf).astype(np.float32)
+    dims = np.array([*Lf, 90, 90, 90], dtype=np.float32)
+    k = ord(axis) - 120 if isinstance(axis, str) else axis
+    masses = rng.uniform(1, 20, N)
+    u = mdhelper_amd.ArrayUniverse(frames, dims, resids=np.arange(N) // 3, masses=masses)
+    flat = frames.copy()
+    flat[..., k] = 0
+    box = dims.copy()
+    box[k] = Lf.max()
+    # atoms, self histogram
+    r = RadialDistributionFunction(u.atoms, n_bins=40, range=(0.0, 9.0), drop_axis=axis, exclusion=(1, 1)).run()
+    want = sum(orf.radial_histogram_ref(flat[f], flat[f], 40, (0.0, 9.0), box, exclusion=(1, 1)) for f in range(F))
+    assert np.array_equal(r.results.counts, want)
+    area = float(np.delete(Lf, k).prod())
+    shell = np.pi * np.diff(r.results.edges ** 2)
+    assert np.allclose(r.results.rdf, want / (F * shell * N * (N - 1) * F / (F * area)), rtol=1e-6)
+    # residue centres of mass of one set against atoms of another: centres first, then the drop
+    a, b = u.atoms[:600], u.atoms[600:]
+    r2 = RadialDistributionFunction(a, b, n_bins=40, range=(0.5, 9.0), drop_axis=axis,
+                                    groupings=("residues", "atoms")).run()
+    m = masses[:600].reshape(200, 3)
+    com = ((frames[:, :600].reshape(F, 200, 3, 3).astype(np.float64) * m[None, :, :, None]).sum(axis=2)
+           / m.sum(axis=1)[None, :, None]).astype(np.float32)
+    com[..., k] = 0
+    want2 = sum(orf.radial_histogram_ref(com[f], flat[f, 600:], 40, (0.5, 9.0), box) for f in range(F))
+    assert np.array_equal(r2.results.counts, want2)
+    # trajectory file
+    path = tmp_path / "flat.nc"
+    write_amber_netcdf(path, frames, Lf, times=np.arange(F) * 1.0)
+    uf = mdhelper_amd.FileUniverse(path, dt=1.0, resids=np.arange(N) // 3, masses=masses)
+    r3 = RadialDistributionFunction(uf.atoms, n_bins=40, range=(0.0, 9.0), drop_axis=axis, exclusion=(1, 1)).run()
+    assert np.array_equal(r3.results.counts, want)
+    assert np.allclose(r3.results.rdf, r.results.rdf, rtol=1e-12)

@@ -24,6 +24,10 @@ class OracleRdfEngine:
         self.n_bins = len(edges) - 1
         self._counts = np.zeros(self.n_bins, dtype=np.int64)
         self._grouping = {}
+        self._drop = None
+
+    def set_drop_axis(self, axis):
+        self._drop = axis
 
     def set_grouping(self, which, offsets, masses):
         self._grouping[which] = None if offsets is None else (np.asarray(offsets), np.asarray(masses))
@@ -46,9 +50,14 @@ class OracleRdfEngine:
         b = a if pos2 is None else [self._points(2, np.asarray(pos2)[f]) for f in range(pos1.shape[0])]
         pos1, pos2 = a, (None if pos2 is None else b)
         for f in range(len(pos1)):
-            p2 = pos1[f] if pos2 is None else np.asarray(pos2)[f]
-            c_radial_histogram(pos1[f], p2, self.n_bins, (self.edges[0], self.edges[-1]),
-                               None if boxes is None else np.asarray(boxes)[f],
+            p1 = np.array(pos1[f], dtype=np.float32)
+            p2 = p1 if pos2 is None else np.array(pos2[f], dtype=np.float32)
+            box = None if boxes is None else np.array(np.asarray(boxes)[f], dtype=np.float32)
+            if self._drop is not None:        # structure.py:761-766
+                p1[:, self._drop] = 0
+                p2[:, self._drop] = 0
+                box[self._drop] = box[:3].max()
+            c_radial_histogram(p1, p2, self.n_bins, (self.edges[0], self.edges[-1]), box,
                                exclusion=self.exclusion, counts=self._counts, n_threads=1)
 
     def counts(self):
