@@ -168,6 +168,13 @@ int mdx_sq_create(mdx_sq_t *out, int dev, const double *wavevectors, int64_t n_q
                   int n_pairs);
 int mdx_sq_destroy(mdx_sq_t h);
 int mdx_sq_reset(mdx_sq_t h);
+/* groupings="residues" / "segments" (structure.py:1484-1486 with center_of_mass): the rows handed to
+ * every accumulate entry point are then particles sorted molecule by molecule — molecule g = rows
+ * [offsets[g], offsets[g+1]), masses float64[offsets[n_molecules]] — and the Fourier sums run over
+ * the float32 centres of mass formed on the device; group_offsets of mdx_sq_create index the
+ * molecules.  Groups with groupings="atoms" enter as molecules of one particle and mass 1.
+ * n_molecules <= 0 removes the grouping. */
+int mdx_sq_set_grouping(mdx_sq_t h, int64_t n_molecules, const int64_t *offsets, const double *masses);
 int mdx_sq_accumulate(mdx_sq_t h, const float *pos, int64_t n, int64_t n_frames);
 int mdx_sq_accumulate_device(mdx_sq_t h, const float *d_pos, int64_t n, int64_t n_frames);
 /* float64[n_pairs][n_q] un-normalised sums over frames (structure.py:1494-1508). */
@@ -192,6 +199,8 @@ int mdx_isf_create(mdx_isf_t *out, int dev, const double *wavevectors, int64_t n
 int mdx_isf_destroy(mdx_isf_t h);
 int mdx_isf_reset(mdx_isf_t h);
 int mdx_isf_accumulate(mdx_isf_t h, const float *pos, int64_t n, int64_t n_frames);
+/* As mdx_sq_set_grouping; only before the first frame of a series. */
+int mdx_isf_set_grouping(mdx_isf_t h, int64_t n_molecules, const int64_t *offsets, const double *masses);
 /* cisf: float64[n_lags][n_pairs][n_q]; iisf (may be NULL): float64[n_lags][n_slots][n_q] with
  * n_slots = 1 for mode=None (pairs = (-1,-1)) and n_groups otherwise; un-normalised sums. */
 int mdx_isf_result(mdx_isf_t h, double *cisf, double *iisf);

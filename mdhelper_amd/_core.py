@@ -278,6 +278,21 @@ class SqEngine(_Engine):
         if timing:
             check(lib().mdx_sq_enable_timing(h, 1))
 
+    _set_grouping = "mdx_sq_set_grouping"
+
+    def set_grouping(self, offsets, masses):
+        """Incoming rows become particles of molecules ``[offsets[g], offsets[g+1])`` whose float32
+        centres of mass enter the Fourier sums; ``offsets=None`` removes the grouping."""
+        fn = getattr(lib(), self._set_grouping)
+        if offsets is None:
+            check(fn(self.handle, 0, None, None))
+            return
+        o = np.ascontiguousarray(offsets, dtype=np.int64)
+        m = np.ascontiguousarray(masses, dtype=np.float64)
+        if len(m) != o[-1]:
+            raise ValueError("masses must hold one entry per particle of the grouping.")
+        check(fn(self.handle, len(o) - 1, _ptr(o), _ptr(m)))
+
     def accumulate(self, pos):
         p = np.ascontiguousarray(pos, dtype=np.float32)
         if p.ndim == 2:
@@ -333,6 +348,21 @@ class IsfEngine(_Engine):
         self.dev = dev
         if timing:
             check(lib().mdx_isf_enable_timing(h, 1))
+
+    _set_grouping = "mdx_isf_set_grouping"
+
+    def set_grouping(self, offsets, masses):
+        """Incoming rows become particles of molecules ``[offsets[g], offsets[g+1])`` whose float32
+        centres of mass enter the Fourier sums; ``offsets=None`` removes the grouping."""
+        fn = getattr(lib(), self._set_grouping)
+        if offsets is None:
+            check(fn(self.handle, 0, None, None))
+            return
+        o = np.ascontiguousarray(offsets, dtype=np.int64)
+        m = np.ascontiguousarray(masses, dtype=np.float64)
+        if len(m) != o[-1]:
+            raise ValueError("masses must hold one entry per particle of the grouping.")
+        check(fn(self.handle, len(o) - 1, _ptr(o), _ptr(m)))
 
     def accumulate(self, pos):
         """pos: float32[F, N, 3], frames in analysis order."""

@@ -537,7 +537,7 @@ class StructureFactor(NumbaAnalysisBase):
     # iteration per frame.  Shared with IntermediateScatteringFunction.
     def run(self, start=None, stop=None, step=None, frames=None, verbose=None, **kwargs):
         traj = self._trajectory
-        if not (_is_array_trajectory(traj) and all(g == "atoms" for g in self._groupings)):
+        if not _is_array_trajectory(traj):
             return super().run(start=start, stop=stop, step=step, frames=frames, verbose=verbose,
                                **kwargs)
         self._setup_frames(traj, start=start, stop=stop, step=step, frames=frames)
@@ -547,7 +547,22 @@ class StructureFactor(NumbaAnalysisBase):
         self.times[:] = numbers * traj.dt
         lo, hi = getattr(self, "_frames_mine", (0, len(numbers)))
         mine = numbers[lo:hi]
-        index = np.concatenate([np.asarray(g.indices) for g in self._groups])
+        if all(g == "atoms" for g in self._groupings):
+            index = np.concatenate([np.asarray(g.indices) for g in self._groups])
+        elif self._engine is not None:
+            # residue / segment centres of mass are formed on the device: rows sorted molecule
+            # by molecule; plain-atom groups enter as molecules of one particle and unit mass
+            rows, sizes, masses = [], [], []
+            for g, gr in zip(self._groups, self._groupings):
+                idx, off, m = RadialDistributionFunction._selection(g, gr)
+                rows.append(idx)
+                sizes.append(np.ones(len(idx), dtype=np.int64) if off is None else np.diff(off))
+                masses.append(np.ones(len(idx)) if m is None else m)
+            index = np.concatenate(rows)
+            self._engine.set_grouping(np.concatenate(([0], np.cumsum(np.concatenate(sizes)))),
+                                      np.concatenate(masses))
+        else:
+            index = np.zeros(0, dtype=int)
         identity = len(index) == traj.n_atoms and np.array_equal(index, np.arange(len(index)))
         native = getattr(traj, "native", None)
         block = 4096 if native is not None else self._batch.capacity

@@ -19,6 +19,7 @@
 // looped inside, so sums are formed in a fixed order (run-to-run reproducible).
 #include "mdx_common.hpp"
 #include "mdx_internal.hpp"
+#include "mdx_molecules.hpp"
 
 using namespace mdx;
 
@@ -231,7 +232,8 @@ struct mdx_isf {
     std::vector<int64_t> offsets;
     std::vector<int64_t> ranges;      // particle range of every incoherent slot
     DeviceBuffer d_q, d_offsets, d_pairs, d_ranges, d_rho_ring, d_pos_ring, d_cisf, d_iisf, d_part,
-        d_pos_stage, d_index, d_mtrip;
+        d_pos_stage, d_index, d_mtrip, d_row_stage;
+    MoleculeStage mol;      // optional centre-of-mass stage (groupings other than "atoms")
     bool lattice = false;   // grid wavevectors: separable phase tables (mdx_sq_device.hpp)
     SqLattice lat{};
     size_t lat_lds = 0;
@@ -244,8 +246,16 @@ struct mdx_isf {
 template <typename Source>
 static int isf_accumulate(mdx_isf *h, int64_t n, int64_t n_frames, Source source)
 {
-    MDX_REQUIRE(n >= h->n_total && n_frames >= 0, "bad size");
     MDX_TRY(set_device(h->dev));
+    // with a grouping set the incoming rows are particles sorted molecule by molecule; the rings
+    // and kernels below see the float32 centres of mass
+    const int64_t n_rows = n;
+    if (h->mol.active()) {
+        MDX_REQUIRE(n == h->mol.n_atoms, "%lld particles given, the grouping was defined for %lld",
+                    (long long)n, (long long)h->mol.n_atoms);
+        n = h->mol.n_groups;
+    }
+    MDX_REQUIRE(n >= h->n_total && n_frames >= 0, "bad size");
     if (h->incoherent)
         MDX_TRY(h->d_pos_ring.ensure(size_t(12) * n * h->ring_slots));
     const int qblocks = (int)ceil_div(h->n_q, SQ_QPB);
@@ -263,7 +273,13 @@ static int isf_accumulate(mdx_isf *h, int64_t n, int64_t n_frames, Source source
             MDX_TRY(h->d_pos_stage.ensure(size_t(12) * n * nf));
             d_new = h->d_pos_stage.as<float>();
         }
-        MDX_TRY(source(d_new, done, nf));
+        if (h->mol.active()) {
+            MDX_TRY(h->d_row_stage.ensure(size_t(12) * n_rows * nf));
+            MDX_TRY(source(h->d_row_stage.as<float>(), done, nf));
+            MDX_TRY(h->mol.run(h->stream, h->d_row_stage.as<float>(), nf, d_new, nullptr));
+        } else {
+            MDX_TRY(source(d_new, done, nf));
+        }
         hipEvent_t ev = h->timer.begin();
         if (h->lattice)
             hipLaunchKernelGGL(sq_rho_lattice_kernel, dim3(qblocks, h->n_groups, (unsigned)nf),
@@ -320,6 +336,17 @@ static int isf_accumulate(mdx_isf *h, int64_t n, int64_t n_frames, Source source
 }
 
 extern "C" {
+
+int mdx_isf_set_grouping(mdx_isf_t h, int64_t n_molecules, const int64_t *offsets, const double *masses)
+{
+    MDX_REQUIRE(h, "NULL handle");
+    MDX_TRY(set_device(h->dev));
+    MDX_HIP(hipStreamSynchronize(h->stream));
+    MDX_REQUIRE(h->frames_seen == 0, "the grouping cannot change in the middle of a series");
+    MDX_REQUIRE(n_molecules <= 0 || n_molecules >= h->n_total,
+                "%lld molecules given, the groups span %lld", (long long)n_molecules, (long long)h->n_total);
+    return h->mol.set(n_molecules, offsets, masses);
+}
 
 int mdx_isf_accumulate(mdx_isf_t h, const float *pos, int64_t n, int64_t n_frames)
 {
@@ -457,8 +484,9 @@ int mdx_isf_destroy(mdx_isf_t h)
     h->timer.destroy();
     for (DeviceBuffer *b : {&h->d_q, &h->d_offsets, &h->d_pairs, &h->d_ranges, &h->d_rho_ring,
                             &h->d_pos_ring, &h->d_cisf, &h->d_iisf, &h->d_part, &h->d_pos_stage,
-                            &h->d_index, &h->d_mtrip})
+                            &h->d_index, &h->d_mtrip, &h->d_row_stage})
         b->release();
+    h->mol.release();
     if (h->stream)
         (void)hipStreamDestroy(h->stream);
     delete h;

@@ -29,6 +29,7 @@
 
 #include "mdx_common.hpp"
 #include "mdx_internal.hpp"
+#include "mdx_molecules.hpp"
 #include "mdx_rdf_device.hpp"
 #include "mdx_rdf_cell.hpp"
 #include "mdx_traj.hpp"
@@ -336,30 +337,6 @@ __global__ __launch_bounds__(256) void rdf_tri_tile_kernel(TriArgs a)
     }
 }
 
-// Centres of mass on the device: out[frame][g][k] = (float)(sum_a m_a x_a / M_g)
-// over the particles a in [offsets[g], offsets[g+1]) of the incoming order, accumulated in
-// double in that order with separate multiply and add — the operations of the reference's host
-// path (algorithm/molecule.py:300-306 through numpy: weights m * x, sequential sums, one
-// division), so the float32 centres are the ones the reference bins.
-__global__ __launch_bounds__(256) void rdf_com_kernel(const float *__restrict__ pos, int64_t n_atoms,
-                                                      const int64_t *__restrict__ offsets,
-                                                      const double *__restrict__ masses,
-                                                      const double *__restrict__ total_mass,
-                                                      int64_t n_groups, float *__restrict__ out)
-{
-    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;   // (group, k)
-    const int64_t frame = blockIdx.y;
-    if (i >= n_groups * 3)
-        return;
-    const int64_t g = i / 3;
-    const int k = int(i - 3 * g);
-    const float *p = pos + frame * n_atoms * 3 + k;
-    double acc = 0.0;
-    for (int64_t a = offsets[g]; a < offsets[g + 1]; ++a)
-        acc = __dadd_rn(acc, __dmul_rn(masses[a], (double)p[3 * a]));
-    out[(frame * n_groups + g) * 3 + k] = (float)(acc / total_mass[g]);
-}
-
 __global__ void rdf_reduce_kernel(const unsigned long long *__restrict__ rep, int n_rep, int n_bins,
                                   unsigned long long *__restrict__ total)
 {
@@ -386,10 +363,7 @@ struct mdx_rdf {
     int n_rep = 32;
     DeviceBuffer d_thresh, d_counts, d_total, d_pack1, d_pack2, d_misc, d_tri;
     // optional centre-of-mass stage per set: incoming rows are particles grouped into molecules
-    struct Grouping {
-        int64_t n_atoms = 0, n_groups = 0;
-        DeviceBuffer d_offsets, d_masses, d_total, d_com;
-    } grouping[2];
+    MoleculeStage grouping[2];
     // drop_axis (2-D mode, structure.py:761-770): coordinate zeroed, box length -> max(lx, ly, lz)
     int drop_axis = -1;
     DeviceBuffer d_drop[2], d_drop_box;
@@ -829,17 +803,12 @@ static int accumulate_device(mdx_rdf *h, const float *d_pos1, int64_t n1, const 
     MDX_REQUIRE(!same || !h->grouping[1].n_groups || h->grouping[0].n_groups,
                 "a self histogram takes the grouping of set 1");
     for (int g = 0; g < (same ? 1 : 2); ++g) {
-        mdx_rdf::Grouping &G = h->grouping[g];
-        if (!G.n_groups)
+        MoleculeStage &G = h->grouping[g];
+        if (!G.active())
             continue;
         MDX_REQUIRE(n[g] == G.n_atoms, "set %d holds %lld particles, its grouping was defined for %lld",
                     g + 1, (long long)n[g], (long long)G.n_atoms);
-        MDX_TRY(G.d_com.ensure(size_t(12) * G.n_groups * n_frames));
-        hipLaunchKernelGGL(rdf_com_kernel, dim3((unsigned)ceil_div(G.n_groups * 3, 256), (unsigned)n_frames),
-                           dim3(256), 0, h->stream, src[g], G.n_atoms, G.d_offsets.as<int64_t>(),
-                           G.d_masses.as<double>(), G.d_total.as<double>(), G.n_groups,
-                           G.d_com.as<float>());
-        pts[g] = G.d_com.as<float>();
+        MDX_TRY(G.run(h->stream, src[g], n_frames, nullptr, &pts[g]));
         n[g] = G.n_groups;
         owned[g] = true;
     }
@@ -1014,13 +983,12 @@ int mdx_rdf_destroy(mdx_rdf_t h)
     h->pipe.destroy();
     for (DeviceBuffer *b : {&h->d_thresh, &h->d_counts, &h->d_total, &h->d_pack1, &h->d_pack2,
                             &h->d_stage1[0], &h->d_stage2[0], &h->d_boxes[0], &h->d_stage1[1],
-                            &h->d_stage2[1], &h->d_boxes[1], &h->d_index[0], &h->d_index[1], &h->d_tri, &h->grouping[0].d_offsets,
-                            &h->grouping[0].d_masses, &h->grouping[0].d_total, &h->grouping[0].d_com,
-                            &h->grouping[1].d_offsets, &h->grouping[1].d_masses,
-                            &h->grouping[1].d_total, &h->grouping[1].d_com, &h->d_misc, &h->d_pw1,
+                            &h->d_stage2[1], &h->d_boxes[1], &h->d_index[0], &h->d_index[1], &h->d_tri, &h->d_misc, &h->d_pw1,
                             &h->d_po1, &h->d_bb1, &h->d_pw2, &h->d_po2, &h->d_bb2, &h->d_bb16_1,
                             &h->d_bb16_2, &h->d_drop[0], &h->d_drop[1], &h->d_drop_box})
         b->release();
+    h->grouping[0].release();
+    h->grouping[1].release();
     if (h->stream)
         (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1058,32 +1026,7 @@ int mdx_rdf_set_grouping(mdx_rdf_t h, int which, int64_t n_groups, const int64_t
     MDX_REQUIRE(which == 1 || which == 2, "which must be 1 or 2");
     MDX_TRY(set_device(h->dev));
     MDX_HIP(hipStreamSynchronize(h->stream));
-    mdx_rdf::Grouping &G = h->grouping[which - 1];
-    if (n_groups <= 0) {   // back to plain particles
-        G.n_groups = G.n_atoms = 0;
-        return MDX_OK;
-    }
-    MDX_REQUIRE(offsets && masses, "NULL argument");
-    MDX_REQUIRE(offsets[0] == 0, "offsets must start at 0");
-    const int64_t n_atoms = offsets[n_groups];
-    std::vector<double> total((size_t)n_groups);
-    for (int64_t g = 0; g < n_groups; ++g) {
-        MDX_REQUIRE(offsets[g + 1] > offsets[g], "group %lld is empty", (long long)g);
-        double m = 0.0;
-        for (int64_t a = offsets[g]; a < offsets[g + 1]; ++a)
-            m += masses[a];   // sequential, as numpy.bincount sums the weights
-        MDX_REQUIRE(m > 0.0, "group %lld has no mass", (long long)g);
-        total[(size_t)g] = m;
-    }
-    MDX_TRY(G.d_offsets.ensure(size_t(8) * (n_groups + 1)));
-    MDX_TRY(G.d_masses.ensure(size_t(8) * n_atoms));
-    MDX_TRY(G.d_total.ensure(size_t(8) * n_groups));
-    MDX_HIP(hipMemcpy(G.d_offsets.ptr, offsets, size_t(8) * (n_groups + 1), hipMemcpyHostToDevice));
-    MDX_HIP(hipMemcpy(G.d_masses.ptr, masses, size_t(8) * n_atoms, hipMemcpyHostToDevice));
-    MDX_HIP(hipMemcpy(G.d_total.ptr, total.data(), size_t(8) * n_groups, hipMemcpyHostToDevice));
-    G.n_groups = n_groups;
-    G.n_atoms = n_atoms;
-    return MDX_OK;
+    return h->grouping[which - 1].set(n_groups, offsets, masses);
 }
 
 int mdx_rdf_accumulate_device(mdx_rdf_t h, const float *d_pos1, int64_t n1, const float *d_pos2,

@@ -23,6 +23,7 @@
 // results are run-to-run reproducible.
 #include "mdx_common.hpp"
 #include "mdx_internal.hpp"
+#include "mdx_molecules.hpp"
 
 using namespace mdx;
 
@@ -129,6 +130,7 @@ struct mdx_sq {
     std::vector<int64_t> offsets;
     DeviceBuffer d_q, d_offsets, d_pairs, d_acc, d_rho, d_stage[2], d_index, d_mtrip;
     StagePipeline pipe;   // host-buffer / trajectory-file entry points
+    MoleculeStage mol;    // optional centre-of-mass stage (groupings other than "atoms")
     StreamTimer timer;
     bool lattice = false;        // wavevectors are integer multiples of one base per axis
     SqLattice lat{};
@@ -146,7 +148,22 @@ struct mdx_sq {
     DeviceBuffer d_items;
 };
 
+static int sq_accumulate_points(mdx_sq *h, const float *d_pos, int64_t n, int64_t n_frames);
+
+// rows -> points: with a grouping set the incoming rows are particles sorted molecule by
+// molecule and the Fourier sums run over the float32 centres of mass
 static int sq_accumulate_device(mdx_sq *h, const float *d_pos, int64_t n, int64_t n_frames)
+{
+    if (!h->mol.active() || n_frames == 0)
+        return sq_accumulate_points(h, d_pos, n, n_frames);
+    MDX_REQUIRE(n == h->mol.n_atoms, "%lld particles given, the grouping was defined for %lld",
+                (long long)n, (long long)h->mol.n_atoms);
+    const float *centres = nullptr;
+    MDX_TRY(h->mol.run(h->stream, d_pos, n_frames, nullptr, &centres));
+    return sq_accumulate_points(h, centres, h->mol.n_groups, n_frames);
+}
+
+static int sq_accumulate_points(mdx_sq *h, const float *d_pos, int64_t n, int64_t n_frames)
 {
     if (n_frames == 0)
         return MDX_OK;
@@ -341,6 +358,7 @@ int mdx_sq_destroy(mdx_sq_t h)
     for (DeviceBuffer *b : {&h->d_q, &h->d_offsets, &h->d_pairs, &h->d_acc, &h->d_rho, &h->d_stage[0],
                             &h->d_stage[1], &h->d_index, &h->d_mtrip, &h->d_items, &h->d_qitems})
         b->release();
+    h->mol.release();
     if (h->stream)
         (void)hipStreamDestroy(h->stream);
     delete h;
@@ -355,6 +373,16 @@ int mdx_sq_reset(mdx_sq_t h)
     MDX_HIP(hipStreamSynchronize(h->stream));
     h->timer.reset();
     return MDX_OK;
+}
+
+int mdx_sq_set_grouping(mdx_sq_t h, int64_t n_molecules, const int64_t *offsets, const double *masses)
+{
+    MDX_REQUIRE(h, "NULL handle");
+    MDX_TRY(set_device(h->dev));
+    MDX_HIP(hipStreamSynchronize(h->stream));
+    MDX_REQUIRE(n_molecules <= 0 || n_molecules >= h->n_total,
+                "%lld molecules given, the groups span %lld", (long long)n_molecules, (long long)h->n_total);
+    return h->mol.set(n_molecules, offsets, masses);
 }
 
 int mdx_sq_accumulate_device(mdx_sq_t h, const float *d_pos, int64_t n, int64_t n_frames)
@@ -397,7 +425,7 @@ int mdx_sq_accumulate_traj(mdx_sq_t h, mdx_traj_t traj, const int64_t *frames, i
     MDX_TRY(set_device(h->dev));
     Trajectory *t = mdx_traj_internal(traj);
     const int64_t n = index ? n_index : (n_index > 0 ? n_index : t->n_atoms);
-    MDX_REQUIRE(n >= h->n_total, "the selection holds %lld particles, the groups need %lld",
+    MDX_REQUIRE(h->mol.active() || n >= h->n_total, "the selection holds %lld particles, the groups need %lld",
                 (long long)n, (long long)h->n_total);
     MDX_REQUIRE(index || n <= t->n_atoms, "selection larger than the trajectory");
     if (n_frames == 0)

@@ -482,3 +482,67 @@ def test_rdf_drop_axis_on_device_all_entry_points(axis, tmp_path):
     r3 = RadialDistributionFunction(uf.atoms, n_bins=40, range=(0.0, 9.0), drop_axis=axis, exclusion=(1, 1)).run()
     assert np.array_equal(r3.results.counts, want)
     assert np.allclose(r3.results.rdf, r.results.rdf, rtol=1e-12)
+
+
+class _PerFrameTrajectory:
+    """Hides ``frame_block`` so that an analysis takes the generic frame-by-frame protocol."""
+
+    def __init__(self, traj):
+        self._traj = traj
+
+    def __getattr__(self, name):
+        if name in ("frame_block", "box_block", "native"):
+            raise AttributeError(name)
+        return getattr(self._traj, name)
+
+    def __getitem__(self, item):
+        return self._traj[item]
+
+    def __len__(self):
+        return len(self._traj)
+
+
+@pytest.mark.parametrize("kind", ["memory", "netcdf"])
+def test_structure_factor_and_isf_centres_of_mass_on_device(kind, tmp_path):
+    """groupings="residues" / mixed for S(q) and the ISF: centres of mass formed on the
+    device (mdx_sq_set_grouping, mdx_isf_set_grouping) equal the per-frame host path."""
+    from mdhelper_amd.analysis import IntermediateScatteringFunction
+    from trajfiles import write_amber_netcdf
+    rng = np.random.default_rng(8)
+    F, N, L = 9, 720, 18.0
+    frames = (rng.random((F, N, 3)) * L).astype(np.float32)
+    masses = rng.uniform(1, 30, N)
+    resids = np.arange(N) // 3
+    segids = np.arange(N) // 60
+    kw = dict(masses=masses, resids=resids, segids=segids)
+    if kind == "memory":
+        u = mdhelper_amd.ArrayUniverse(frames, [L, L, L, 90, 90, 90], dt=0.5, **kw)
+    else:
+        path = tmp_path / "m.nc"
+        write_amber_netcdf(path, frames, [L, L, L], times=np.arange(F) * 0.5)
+        u = mdhelper_amd.FileUniverse(path, dt=0.5, **kw)
+    slow_u = mdhelper_amd.ArrayUniverse(frames, [L, L, L, 90, 90, 90], dt=0.5, **kw)
+    # shuffled membership: the molecules of a group are not contiguous in the file
+    pick = rng.permutation(N // 3)[:150]
+    sel_a = np.sort(np.concatenate([3 * pick, 3 * pick + 1, 3 * pick + 2]))
+    rest = np.setdiff1d(np.arange(N), sel_a)
+    for groupings in ("residues", ("residues", "atoms"), ("atoms", "residues")):
+        def groups(univ):
+            if groupings == ("atoms", "residues"):
+                return univ.atoms[:360], univ.atoms[360:]
+            return univ.atoms[sel_a], univ.atoms[rest]
+        fast = StructureFactor(groups(u), groupings, mode="partial", n_points=4, verbose=False).run()
+        slow = StructureFactor(groups(slow_u), groupings, mode="partial", n_points=4, verbose=False)
+        slow._trajectory = _PerFrameTrajectory(slow_u.trajectory)
+        slow.run()
+        assert fast.results.ssf.shape == slow.results.ssf.shape
+        assert np.allclose(fast.results.ssf, slow.results.ssf, rtol=1e-10, atol=1e-12), groupings
+        assert np.abs(fast.results.ssf).max() > 0.1
+        fi = IntermediateScatteringFunction(groups(u), groupings, mode="partial", n_points=3, n_lags=4,
+                                            incoherent=True, verbose=False).run()
+        si = IntermediateScatteringFunction(groups(slow_u), groupings, mode="partial", n_points=3, n_lags=4,
+                                            incoherent=True, verbose=False)
+        si._trajectory = _PerFrameTrajectory(slow_u.trajectory)
+        si.run()
+        assert np.allclose(fi.results.cisf, si.results.cisf, rtol=1e-10, atol=1e-12), groupings
+        assert np.allclose(fi.results.iisf, si.results.iisf, rtol=1e-10, atol=1e-12), groupings

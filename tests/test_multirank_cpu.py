@@ -67,13 +67,31 @@ class OracleRdfEngine:
         pass
 
 
+def _centres(grouping, frames):
+    """float32 centres of mass of rows sorted molecule by molecule (algorithm/molecule.py)."""
+    if grouping is None:
+        return np.asarray(frames, dtype=np.float32)
+    offsets, m = grouping
+    inverse = np.repeat(np.arange(len(offsets) - 1), np.diff(offsets))
+    msum = np.bincount(inverse, weights=m)
+    out = []
+    for p in np.asarray(frames, dtype=np.float64):
+        out.append(np.stack([np.bincount(inverse, weights=m * p[:, k]) for k in range(3)], axis=1) / msum[:, None])
+    return np.asarray(out).astype(np.float32)
+
+
 class OracleSqEngine:
     def __init__(self, wavevectors, group_sizes, pairs, **kw):
         self.q, self.sizes, self.pairs = np.asarray(wavevectors), list(group_sizes), pairs
         self._acc = np.zeros((len(pairs), len(self.q)))
+        self._grouping = None
+
+    def set_grouping(self, offsets, masses):
+        self._grouping = None if offsets is None else (np.asarray(offsets), np.asarray(masses))
 
     def accumulate(self, pos):
         from oracle import fourier as of
+        pos = _centres(self._grouping, pos)
         slices, idx = [], 0
         for n in self.sizes:
             slices.append(slice(idx, idx + n))
@@ -96,9 +114,13 @@ class OracleIsfEngine:
         self.q, self.sizes, self.pairs = np.asarray(wavevectors), list(group_sizes), pairs
         self.n_lags, self.incoherent = n_lags, incoherent
         self._frames = []
+        self._grouping = None
+
+    def set_grouping(self, offsets, masses):
+        self._grouping = None if offsets is None else (np.asarray(offsets), np.asarray(masses))
 
     def accumulate(self, pos):
-        self._frames.extend(np.asarray(pos, dtype=np.float32))
+        self._frames.extend(_centres(self._grouping, pos))
 
     def result(self):
         from oracle import fourier as of
@@ -173,12 +195,19 @@ def _analyses(comm):
     sf = StructureFactor((u.atoms[:120], u.atoms[120:]), mode="partial", n_points=3, comm=comm).run()
     isf = IntermediateScatteringFunction((u.atoms[:120], u.atoms[120:]), mode="partial", n_points=3,
                                          n_lags=4, incoherent=True, comm=comm).run()
+    ur = mdhelper_amd.ArrayUniverse(frames, [L, L, L, 90, 90, 90], resids=np.arange(300) // 3,
+                                    masses=np.linspace(1.0, 9.0, 300))
+    sfr = StructureFactor((ur.atoms[:120], ur.atoms[120:]), ("residues", "atoms"), mode="partial", n_points=3,
+                          comm=comm).run()
+    isfr = IntermediateScatteringFunction((ur.atoms[:120], ur.atoms[120:]), "residues", mode="partial",
+                                          n_points=3, n_lags=3, incoherent=True, comm=comm).run()
     uw = mdhelper_amd.ArrayUniverse(walk, [14.0, 14.0, 14.0, 90, 90, 90])
     ons = Onsager((uw.atoms[:15], uw.atoms[15:]), temperature=1.0, reduced=True, n_blocks=2, comm=comm).run()
     # 25 particles = 5 chains of 5 (group 1) ... the first 20 as 4 chains of 5, the rest as 1 chain
     e2e = EndToEndVector((uw.atoms[:20], uw.atoms[20:]), n_chains=(4, 1), n_monomers=(5, 5), n_blocks=2,
                          comm=comm).run()
-    return {"acf": e2e.results.acf, "counts": rdf.results.counts, "rdf": rdf.results.rdf, "counts_slow": slow.results.counts,
+    return {"ssf_res": sfr.results.ssf, "cisf_res": isfr.results.cisf, "iisf_res": isfr.results.iisf,
+            "acf": e2e.results.acf, "counts": rdf.results.counts, "rdf": rdf.results.rdf, "counts_slow": slow.results.counts,
             "counts_com": com.results.counts, "cisf": isf.results.cisf, "iisf": isf.results.iisf,
             "ssf": sf.results.ssf, "msd_self": ons.results.msd_self, "msd_cross": ons.results.msd_cross}
 
@@ -220,4 +249,6 @@ def test_world_size_2_matches_single_rank(tmp_path):
         assert np.allclose(got["msd_self"], single["msd_self"], rtol=1e-9, atol=1e-12)
         assert np.allclose(got["msd_cross"], single["msd_cross"], rtol=1e-9, atol=1e-10)
         assert np.allclose(got["acf"], single["acf"], rtol=1e-9, atol=1e-12)       # chains shard
+        for name in ("ssf_res", "cisf_res", "iisf_res"):                            # device-COM wiring
+            assert np.allclose(got[name], single[name], rtol=1e-9, atol=1e-12), name
     assert single["counts"].sum() > 0 and single["counts_com"].sum() > 0
