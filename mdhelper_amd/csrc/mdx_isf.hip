@@ -222,6 +222,25 @@ __global__ void isf_reduce_kernel(const double *__restrict__ part, int n_split, 
 
 }  // namespace
 
+// ring[frame][g][q] = sum over the particle parts of parts[frame][g][part][q], fixed order
+__global__ __launch_bounds__(256) void isf_rho_merge_kernel(const double2 *__restrict__ parts, int n_parts,
+                                                            int n_q, int64_t n_out,
+                                                            double2 *__restrict__ ring)
+{
+    const int64_t i = blockIdx.x * int64_t(256) + threadIdx.x;   // (frame, g, q)
+    if (i >= n_out)
+        return;
+    const int64_t fg = i / n_q;
+    const int q = int(i - fg * n_q);
+    double2 r = make_double2(0.0, 0.0);
+    for (int s = 0; s < n_parts; ++s) {
+        const double2 v = parts[(fg * n_parts + s) * n_q + q];
+        r.x += v.x;
+        r.y += v.y;
+    }
+    ring[i] = r;
+}
+
 struct mdx_isf {
     int dev = 0;
     hipStream_t stream = nullptr;
@@ -232,11 +251,15 @@ struct mdx_isf {
     std::vector<int64_t> offsets;
     std::vector<int64_t> ranges;      // particle range of every incoherent slot
     DeviceBuffer d_q, d_offsets, d_pairs, d_ranges, d_rho_ring, d_pos_ring, d_cisf, d_iisf, d_part,
-        d_pos_stage, d_index, d_mtrip, d_row_stage;
+        d_pos_stage, d_index, d_mtrip, d_row_stage, d_rho_parts;
     MoleculeStage mol;      // optional centre-of-mass stage (groupings other than "atoms")
     bool lattice = false;   // grid wavevectors: separable phase tables (mdx_sq_device.hpp)
     SqLattice lat{};
     size_t lat_lds = 0;
+    // incoherent part through the register-blocked column form (isf_incoherent_quads_kernel)
+    bool quads = false;
+    SqQuadShape quad{};
+    DeviceBuffer d_qitems;
     StreamTimer timer;
 };
 
@@ -281,17 +304,45 @@ static int isf_accumulate(mdx_isf *h, int64_t n, int64_t n_frames, Source source
             MDX_TRY(source(d_new, done, nf));
         }
         hipEvent_t ev = h->timer.begin();
-        if (h->lattice)
-            hipLaunchKernelGGL(sq_rho_lattice_kernel, dim3(qblocks, h->n_groups, (unsigned)nf),
-                               dim3(SQ_THREADS), h->lat_lds, h->stream, d_new, n,
-                               h->d_mtrip.as<short4>(), (int)h->n_q, h->lat,
-                               h->d_offsets.as<int64_t>(), h->n_groups, 1,
-                               h->d_rho_ring.as<double2>() + int64_t(slot0) * h->n_groups * h->n_q);
-        else
-            hipLaunchKernelGGL(sq_rho_kernel, dim3(qblocks, h->n_groups, (unsigned)nf),
-                               dim3(SQ_THREADS), 0, h->stream, d_new, n, h->d_q.as<double>(),
-                               (int)h->n_q, h->d_offsets.as<int64_t>(), h->n_groups, 1,
-                               h->d_rho_ring.as<double2>() + int64_t(slot0) * h->n_groups * h->n_q);
+        {
+            // rho_g(q) of the new frames -> ring.  A chunk holds at most n_lags frames, so the
+            // particles of a group are split (and the parts summed in a fixed order) until the
+            // grid fills the chip.
+            int64_t max_group = 0;
+            for (int g = 0; g < h->n_groups; ++g)
+                max_group = std::max(max_group, h->offsets[g + 1] - h->offsets[g]);
+            const int rblocks = h->quads ? h->quad.blocks() : qblocks;
+            int rs = 1;
+            while (int64_t(rblocks) * 4 * h->n_groups * rs * nf < 4096 && rs < 64 &&
+                   max_group / (rs * 2) >= 1024)
+                rs *= 2;
+            double2 *ring = h->d_rho_ring.as<double2>() + int64_t(slot0) * h->n_groups * h->n_q;
+            double2 *dst = ring;
+            if (rs > 1) {
+                MDX_TRY(h->d_rho_parts.ensure(size_t(16) * nf * h->n_groups * rs * h->n_q));
+                dst = h->d_rho_parts.as<double2>();
+            }
+            if (h->quads)
+                hipLaunchKernelGGL(sq_rho_quads_kernel, dim3(rblocks, h->n_groups * rs, (unsigned)nf),
+                                   dim3(SQ_QUAD_THREADS), h->quad.lds, h->stream, d_new, n,
+                                   h->d_qitems.as<SqQuadItem>(), h->quad.n_items, h->quad.items_p2,
+                                   h->quad.n_sub, (int)h->n_q, h->quad.lat, h->d_offsets.as<int64_t>(),
+                                   h->n_groups, rs, dst);
+            else if (h->lattice)
+                hipLaunchKernelGGL(sq_rho_lattice_kernel, dim3(qblocks, h->n_groups * rs, (unsigned)nf),
+                                   dim3(SQ_THREADS), h->lat_lds, h->stream, d_new, n,
+                                   h->d_mtrip.as<short4>(), (int)h->n_q, h->lat,
+                                   h->d_offsets.as<int64_t>(), h->n_groups, rs, dst);
+            else
+                hipLaunchKernelGGL(sq_rho_kernel, dim3(qblocks, h->n_groups * rs, (unsigned)nf),
+                                   dim3(SQ_THREADS), 0, h->stream, d_new, n, h->d_q.as<double>(),
+                                   (int)h->n_q, h->d_offsets.as<int64_t>(), h->n_groups, rs, dst);
+            if (rs > 1) {
+                const int64_t n_out = nf * h->n_groups * h->n_q;
+                hipLaunchKernelGGL(isf_rho_merge_kernel, dim3((unsigned)ceil_div(n_out, 256)), dim3(256), 0,
+                                   h->stream, dst, rs, (int)h->n_q, n_out, ring);
+            }
+        }
         hipLaunchKernelGGL(isf_coherent_kernel,
                            dim3((unsigned)ceil_div(h->n_q, 256), h->n_pairs, h->n_lags), dim3(256), 0,
                            h->stream, h->d_rho_ring.as<double2>(), h->ring_slots, h->n_groups,
@@ -307,7 +358,20 @@ static int isf_accumulate(mdx_isf *h, int64_t n, int64_t n_frames, Source source
                 n_split *= 2;
             const int64_t n_out = int64_t(h->n_lags) * h->n_slots * h->n_q;
             MDX_TRY(h->d_part.ensure(size_t(8) * n_out * n_split));
-            if (h->lattice)
+            if (h->quads) {
+                const int iblocks = h->quad.blocks();
+                n_split = 1;   // 4 waves per block here
+                while (int64_t(iblocks) * 4 * h->n_slots * n_split * h->n_lags < 4096 && n_split < 64 &&
+                       max_range / (n_split * 2) >= 4 * h->quad.lat.tile)
+                    n_split *= 2;
+                MDX_TRY(h->d_part.ensure(size_t(8) * n_out * n_split));
+                hipLaunchKernelGGL(isf_incoherent_quads_kernel,
+                                   dim3(iblocks, h->n_slots * n_split, h->n_lags), dim3(SQ_QUAD_THREADS),
+                                   h->quad.lds, h->stream, h->d_pos_ring.as<float>(), h->ring_slots, n,
+                                   h->d_qitems.as<SqQuadItem>(), h->quad.n_items, h->quad.items_p2,
+                                   h->quad.n_sub, (int)h->n_q, h->quad.lat, h->d_ranges.as<int64_t>(),
+                                   h->n_slots, n_split, h->n_lags, f0, (int)nf, h->d_part.as<double>());
+            } else if (h->lattice)
                 hipLaunchKernelGGL(isf_incoherent_lattice_kernel,
                                    dim3(qblocks, h->n_slots * n_split, h->n_lags), dim3(SQ_THREADS),
                                    h->lat_lds, h->stream, h->d_pos_ring.as<float>(), h->ring_slots, n,
@@ -464,6 +528,22 @@ int mdx_isf_create(mdx_isf_t *out, int dev, const double *wavevectors, int64_t n
                 rc = fail(MDX_ERR_HIP, "lattice table setup failed");
                 break;
             }
+            std::vector<SqQuadItem> qitems;
+            if (!getenv("MDX_ISF_NO_QUADS") && sq_quad_plan(trip, n_q, h->lat, qitems, h->quad)) {
+                if ((rc = h->d_qitems.ensure(sizeof(SqQuadItem) * qitems.size())) != MDX_OK) break;
+                if (hipMemcpy(h->d_qitems.ptr, qitems.data(), sizeof(SqQuadItem) * qitems.size(),
+                              hipMemcpyHostToDevice) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void *>(isf_incoherent_quads_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)h->quad.lds) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void *>(sq_rho_quads_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)h->quad.lds) != hipSuccess) {
+                    rc = fail(MDX_ERR_HIP, "quad table setup failed");
+                    break;
+                }
+                h->quads = true;
+            }
         }
     } while (0);
     if (rc != MDX_OK) {
@@ -484,7 +564,7 @@ int mdx_isf_destroy(mdx_isf_t h)
     h->timer.destroy();
     for (DeviceBuffer *b : {&h->d_q, &h->d_offsets, &h->d_pairs, &h->d_ranges, &h->d_rho_ring,
                             &h->d_pos_ring, &h->d_cisf, &h->d_iisf, &h->d_part, &h->d_pos_stage,
-                            &h->d_index, &h->d_mtrip, &h->d_row_stage})
+                            &h->d_index, &h->d_mtrip, &h->d_row_stage, &h->d_qitems, &h->d_rho_parts})
         b->release();
     h->mol.release();
     if (h->stream)

@@ -283,36 +283,24 @@ int mdx_sq_create(mdx_sq_t *out, int dev, const double *wavevectors, int64_t n_q
                 break;
             }
             std::vector<SqQuadItem> qitems;
+            SqQuadShape shape;
             if (!getenv("MDX_SQ_NO_COLUMNS") && !getenv("MDX_SQ_NO_QUADS") &&
-                sq_build_quads(trip, n_q, h->lat, qitems)) {
-                h->n_qitems = (int)qitems.size();
-                h->items_p2 = 1;
-                while (h->items_p2 < h->n_qitems)
-                    h->items_p2 *= 2;
-                h->n_sub = std::max(1, SQ_QUAD_THREADS / h->items_p2);
-                if (h->n_sub == 1)
-                    h->items_p2 = h->n_qitems;   // whole blocks of distinct items
-                // two blocks per CU, two table sets per block: ~36 KB per set; the tile is a
-                // multiple of the copies per item
-                const int total_r = h->lat.R[0] + h->lat.R[1] + h->lat.R[2];
-                const int unit = std::max(16, h->n_sub);
-                const int tile = (int)(std::min<size_t>(512, size_t(36) * 1024 / (size_t(16) * total_r) -
-                                                                 SQ_QUAD_PAD) / unit * unit);
-                if (tile >= 16) {
-                    h->quad_lat = h->lat;
-                    h->quad_lat.tile = tile;
-                    h->quad_lds = std::max<size_t>(size_t(32) * (tile + SQ_QUAD_PAD) * total_r + 256, size_t(32) * 1024);
-                    if ((rc = h->d_qitems.ensure(sizeof(SqQuadItem) * qitems.size())) != MDX_OK) break;
-                    if (hipMemcpy(h->d_qitems.ptr, qitems.data(), sizeof(SqQuadItem) * qitems.size(),
-                                  hipMemcpyHostToDevice) != hipSuccess ||
-                        hipFuncSetAttribute(reinterpret_cast<const void *>(sq_rho_quads_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)h->quad_lds) != hipSuccess) {
-                        rc = fail(MDX_ERR_HIP, "quad table setup failed");
-                        break;
-                    }
-                    h->quads = true;
+                sq_quad_plan(trip, n_q, h->lat, qitems, shape)) {
+                h->n_qitems = shape.n_items;
+                h->items_p2 = shape.items_p2;
+                h->n_sub = shape.n_sub;
+                h->quad_lat = shape.lat;
+                h->quad_lds = shape.lds;
+                if ((rc = h->d_qitems.ensure(sizeof(SqQuadItem) * qitems.size())) != MDX_OK) break;
+                if (hipMemcpy(h->d_qitems.ptr, qitems.data(), sizeof(SqQuadItem) * qitems.size(),
+                              hipMemcpyHostToDevice) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void *>(sq_rho_quads_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)h->quad_lds) != hipSuccess) {
+                    rc = fail(MDX_ERR_HIP, "quad table setup failed");
+                    break;
                 }
+                h->quads = true;
             }
             std::vector<SqColumnItem> items;
             if (!h->quads && !getenv("MDX_SQ_NO_COLUMNS") && sq_build_columns(trip, n_q, h->lat, items)) {

@@ -281,12 +281,18 @@ struct SqQuadItem {
 // index into the immediate offset of the ds_read instructions.
 constexpr int SQ_QUAD_PAD = 1;
 
+// theta = base_k * x (Pprev == nullptr) or base_k * (x - x_prev), the float32 coordinates widened
+// first so that the difference is exact in fp64 (the ISF's displacement phases)
 __device__ __forceinline__ void sq_quad_fill(double2 *set, const SqLattice &lat, int stride,
-                                             const float *P, int64_t base, int cnt, int tid)
+                                             const float *P, const float *Pprev, int64_t base, int cnt,
+                                             int tid)
 {
     for (int t = tid; t < cnt * 3; t += SQ_QUAD_THREADS) {
         const int a = t / 3, k = t - 3 * a;
-        const double theta = lat.base[k] * (double)P[(base + a) * 3 + k];
+        double x = (double)P[(base + a) * 3 + k];
+        if (Pprev)
+            x -= (double)Pprev[(base + a) * 3 + k];
+        const double theta = lat.base[k] * x;
         double2 *col = set + size_t(k == 0 ? 0 : k == 1 ? lat.R[0] : lat.R[0] + lat.R[1]) * stride + a;
         double s1, c1;
         sincos_f64(theta, s1, c1);
@@ -311,55 +317,56 @@ __device__ __forceinline__ void sq_quad_fill(double2 *set, const SqLattice &lat,
     }
 }
 
-__global__ __launch_bounds__(SQ_QUAD_THREADS, 2) void sq_rho_quads_kernel(
-    const float *__restrict__ pos, int64_t n_atoms, const SqQuadItem *__restrict__ items,
-    int n_items, int items_p2, int n_sub, int n_q, SqLattice lat,
-    const int64_t *__restrict__ group_offsets, int n_groups, int n_split, double2 *__restrict__ rho)
-{
-    extern __shared__ double2 lat_tab[];
-    const int tid = threadIdx.x, T = SQ_QUAD_THREADS;
-    const int slot = blockIdx.x * T + tid;
-    const int item = n_sub > 1 ? (slot & (items_p2 - 1)) : slot;
-    const int sub = n_sub > 1 ? slot / items_p2 : 0;
-    const bool live = item < n_items;
-    const int g = blockIdx.y / n_split, sp = blockIdx.y % n_split;
-    const int frame = blockIdx.z;
-    const int A = lat.tile, stride = A + SQ_QUAD_PAD;
-    const int total_r = lat.R[0] + lat.R[1] + lat.R[2];
-    const int set_len = total_r * stride;          // entries per table set
-    const int chunk = A / n_sub;                   // particles per thread and tile (A % n_sub == 0)
-    const SqQuadItem *it = items + min(item, n_items - 1);
-    // byte offsets of this thread's 16 read streams, at its first particle of a tile
+// A thread's view of the quad tables: its item and copy, byte offsets of its 16 read streams
+struct SqQuadThread {
+    int item, sub;
+    bool live;
+    int stride, set_len, chunk;
     int o0[SQ_QCOLS], o1[SQ_QCOLS], oz[SQ_ZPT];
+};
+
+__device__ __forceinline__ SqQuadThread sq_quad_thread(const SqQuadItem *items, int n_items,
+                                                       int items_p2, int n_sub, const SqLattice &lat)
+{
+    SqQuadThread t;
+    const int slot = blockIdx.x * SQ_QUAD_THREADS + threadIdx.x;
+    t.item = n_sub > 1 ? (slot & (items_p2 - 1)) : slot;
+    t.sub = n_sub > 1 ? slot / items_p2 : 0;
+    t.live = t.item < n_items;
+    t.stride = lat.tile + SQ_QUAD_PAD;
+    t.set_len = (lat.R[0] + lat.R[1] + lat.R[2]) * t.stride;   // entries per table set
+    t.chunk = lat.tile / n_sub;                                // particles per thread and tile
+    const SqQuadItem *it = items + min(t.item, n_items - 1);
 #pragma unroll
     for (int c = 0; c < SQ_QCOLS; ++c) {
-        o0[c] = (it->i0[c] * stride + sub * chunk) * 16;
-        o1[c] = ((lat.R[0] + it->i1[c]) * stride + sub * chunk) * 16;
+        t.o0[c] = (it->i0[c] * t.stride + t.sub * t.chunk) * 16;
+        t.o1[c] = ((lat.R[0] + it->i1[c]) * t.stride + t.sub * t.chunk) * 16;
     }
 #pragma unroll
     for (int j = 0; j < SQ_ZPT; ++j)
-        oz[j] = ((lat.R[0] + lat.R[1] + it->z[j]) * stride + sub * chunk) * 16;
-    double ar[SQ_QCOLS][SQ_ZPT], ai[SQ_QCOLS][SQ_ZPT];
-#pragma unroll
-    for (int c = 0; c < SQ_QCOLS; ++c)
-#pragma unroll
-        for (int j = 0; j < SQ_ZPT; ++j)
-            ar[c][j] = ai[c][j] = 0.0;
-    const int64_t g_lo = group_offsets[g], g_hi = group_offsets[g + 1];
-    const int64_t per = (g_hi - g_lo + n_split - 1) / n_split;
-    const int64_t lo = g_lo + sp * per, hi = min(g_hi, lo + per);
-    const float *P = pos + int64_t(frame) * n_atoms * 3;
+        t.oz[j] = ((lat.R[0] + lat.R[1] + it->z[j]) * t.stride + t.sub * t.chunk) * 16;
+    return t;
+}
 
+// Particles [lo, hi) of one frame (or of one pair of frames: Pprev) into the thread's 4 x 8
+// accumulators; REAL_ONLY keeps Re(E_x E_y E_z) only (two FMAs per term).  Ends on a barrier.
+template <bool REAL_ONLY>
+__device__ __forceinline__ void sq_quad_frame(double2 *lat_tab, const SqLattice &lat,
+                                              const SqQuadThread &t, const float *P, const float *Pprev,
+                                              int64_t lo, int64_t hi, double (&ar)[SQ_QCOLS][SQ_ZPT],
+                                              double (&ai)[SQ_QCOLS][SQ_ZPT])
+{
+    const int tid = threadIdx.x, A = lat.tile;
     if (lo < hi)
-        sq_quad_fill(lat_tab, lat, stride, P, lo, (int)min<int64_t>(A, hi - lo), tid);
+        sq_quad_fill(lat_tab, lat, t.stride, P, Pprev, lo, (int)min<int64_t>(A, hi - lo), tid);
     __syncthreads();
     int cur = 0;
     for (int64_t base = lo; base < hi; base += A, cur ^= 1) {
         const int cnt = (int)min<int64_t>(A, hi - base);
         if (base + A < hi)
-            sq_quad_fill(lat_tab + size_t(cur ^ 1) * set_len, lat, stride, P, base + A,
+            sq_quad_fill(lat_tab + size_t(cur ^ 1) * t.set_len, lat, t.stride, P, Pprev, base + A,
                          (int)min<int64_t>(A, hi - base - A), tid);
-        const int mine = max(0, min(chunk, cnt - sub * chunk));
+        const int mine = max(0, min(t.chunk, cnt - t.sub * t.chunk));
         // byte address of a read = stream offset (per thread) + ib (set and particle)
         auto at = [&](int stream_bytes, int ib) {
             return *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(lat_tab) +
@@ -369,12 +376,12 @@ __global__ __launch_bounds__(SQ_QUAD_THREADS, 2) void sq_rho_quads_kernel(
         // issued before the FMAs that hide their latency (the scheduler, short of registers,
         // otherwise waits for every read right after issuing it).  The read past a thread's
         // last particle stays inside the allocation and is discarded.
-        const int ib0 = cur * set_len * 16;
+        const int ib0 = cur * t.set_len * 16;
         double2 ex[SQ_QCOLS], ey[SQ_QCOLS];
 #pragma unroll
         for (int c = 0; c < SQ_QCOLS; ++c) {
-            ex[c] = at(o0[c], ib0);
-            ey[c] = at(o1[c], ib0);
+            ex[c] = at(t.o0[c], ib0);
+            ey[c] = at(t.o1[c], ib0);
         }
 #pragma unroll 1
         for (int i = 0; i < mine; ++i) {
@@ -385,22 +392,23 @@ __global__ __launch_bounds__(SQ_QUAD_THREADS, 2) void sq_rho_quads_kernel(
                 tr[c] = fma(ex[c].x, ey[c].x, -ex[c].y * ey[c].y);
                 ti[c] = fma(ex[c].x, ey[c].y, ex[c].y * ey[c].x);
             }
-            double2 ez = at(oz[0], ib);
+            double2 ez = at(t.oz[0], ib);
 #pragma unroll
             for (int c = 0; c < SQ_QCOLS; ++c) {
-                ex[c] = at(o0[c], ib + 16);
-                ey[c] = at(o1[c], ib + 16);
+                ex[c] = at(t.o0[c], ib + 16);
+                ey[c] = at(t.o1[c], ib + 16);
             }
 #pragma unroll
             for (int j = 0; j < SQ_ZPT; ++j) {
                 double2 ezn = ez;
                 if (j + 1 < SQ_ZPT)
-                    ezn = at(oz[j + 1], ib);
+                    ezn = at(t.oz[j + 1], ib);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int c = 0; c < SQ_QCOLS; ++c) {
                     ar[c][j] = fma(tr[c], ez.x, fma(-ti[c], ez.y, ar[c][j]));
-                    ai[c][j] = fma(tr[c], ez.y, fma(ti[c], ez.x, ai[c][j]));
+                    if (!REAL_ONLY)
+                        ai[c][j] = fma(tr[c], ez.y, fma(ti[c], ez.x, ai[c][j]));
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 ez = ezn;
@@ -408,9 +416,21 @@ __global__ __launch_bounds__(SQ_QUAD_THREADS, 2) void sq_rho_quads_kernel(
         }
         __syncthreads();
     }
-    // the copies of an item are summed in a fixed order through LDS (the table space, one column
-    // of the block at a time: 16 doubles per thread)
-    double2 *out = rho + ((int64_t(frame) * n_groups + g) * n_split + sp) * n_q;
+}
+
+// The copies of an item are summed in a fixed order through LDS (the table space, one column of
+// the block at a time: 16 doubles per thread) and written by copy 0: out_c[q] (complex) or
+// out_r[q] (REAL_ONLY).
+template <bool REAL_ONLY>
+__device__ __forceinline__ void sq_quad_store(double2 *lat_tab, const SqQuadThread &t,
+                                              const SqQuadItem *items, int n_items, int items_p2,
+                                              int n_sub, const double (&ar)[SQ_QCOLS][SQ_ZPT],
+                                              const double (&ai)[SQ_QCOLS][SQ_ZPT], double2 *out_c,
+                                              double *out_r)
+{
+    constexpr int T = SQ_QUAD_THREADS;
+    const int tid = threadIdx.x;
+    const SqQuadItem *it = items + min(t.item, n_items - 1);
     double *red = reinterpret_cast<double *>(lat_tab);
 #pragma unroll
     for (int c = 0; c < SQ_QCOLS; ++c) {
@@ -419,25 +439,86 @@ __global__ __launch_bounds__(SQ_QUAD_THREADS, 2) void sq_rho_quads_kernel(
 #pragma unroll
             for (int j = 0; j < SQ_ZPT; ++j) {
                 red[(2 * j) * T + tid] = ar[c][j];
-                red[(2 * j + 1) * T + tid] = ai[c][j];
+                if (!REAL_ONLY)
+                    red[(2 * j + 1) * T + tid] = ai[c][j];
             }
             __syncthreads();
         }
-        if (live && sub == 0) {
+        if (t.live && t.sub == 0) {
 #pragma unroll
             for (int j = 0; j < SQ_ZPT; ++j) {
                 const int q = it->q[c][j];
                 if (q < 0)
                     continue;
-                double re = ar[c][j], im = ai[c][j];
+                double re = ar[c][j], im = REAL_ONLY ? 0.0 : ai[c][j];
                 for (int s2 = 1; s2 < n_sub; ++s2) {
-                    re += red[(2 * j) * T + s2 * items_p2 + item];
-                    im += red[(2 * j + 1) * T + s2 * items_p2 + item];
+                    re += red[(2 * j) * T + s2 * items_p2 + t.item];
+                    if (!REAL_ONLY)
+                        im += red[(2 * j + 1) * T + s2 * items_p2 + t.item];
                 }
-                out[q] = make_double2(re, im);
+                if (REAL_ONLY)
+                    out_r[q] = re;
+                else
+                    out_c[q] = make_double2(re, im);
             }
         }
     }
+}
+
+__global__ __launch_bounds__(SQ_QUAD_THREADS, 2) void sq_rho_quads_kernel(
+    const float *__restrict__ pos, int64_t n_atoms, const SqQuadItem *__restrict__ items,
+    int n_items, int items_p2, int n_sub, int n_q, SqLattice lat,
+    const int64_t *__restrict__ group_offsets, int n_groups, int n_split, double2 *__restrict__ rho)
+{
+    extern __shared__ double2 lat_tab[];
+    const SqQuadThread t = sq_quad_thread(items, n_items, items_p2, n_sub, lat);
+    const int g = blockIdx.y / n_split, sp = blockIdx.y % n_split;
+    const int frame = blockIdx.z;
+    double ar[SQ_QCOLS][SQ_ZPT], ai[SQ_QCOLS][SQ_ZPT];
+#pragma unroll
+    for (int c = 0; c < SQ_QCOLS; ++c)
+#pragma unroll
+        for (int j = 0; j < SQ_ZPT; ++j)
+            ar[c][j] = ai[c][j] = 0.0;
+    const int64_t g_lo = group_offsets[g], g_hi = group_offsets[g + 1];
+    const int64_t per = (g_hi - g_lo + n_split - 1) / n_split;
+    const int64_t lo = g_lo + sp * per, hi = min(g_hi, lo + per);
+    sq_quad_frame<false>(lat_tab, lat, t, pos + int64_t(frame) * n_atoms * 3, nullptr, lo, hi, ar, ai);
+    sq_quad_store<false>(lat_tab, t, items, n_items, items_p2, n_sub, ar, ai,
+                         rho + ((int64_t(frame) * n_groups + g) * n_split + sp) * n_q, nullptr);
+}
+
+// Incoherent ISF through the same blocking: part[split][lag][slot][q] = sum over the block's new
+// frames f >= lag and the slot's particles of cos q.(r(f) - r(f - lag)) — only the real part of
+// E_x E_y E_z is accumulated, two FMAs per term.  grid (item blocks, slots x splits, lags).
+__global__ __launch_bounds__(SQ_QUAD_THREADS, 2) void isf_incoherent_quads_kernel(
+    const float *__restrict__ pos_ring, int ring_slots, int64_t n_atoms,
+    const SqQuadItem *__restrict__ items, int n_items, int items_p2, int n_sub, int n_q,
+    SqLattice lat, const int64_t *__restrict__ ranges /*[n_slots][2]*/, int n_slots, int n_split,
+    int n_lags, long long f_first, int n_new, double *__restrict__ part)
+{
+    extern __shared__ double2 lat_tab[];
+    const SqQuadThread t = sq_quad_thread(items, n_items, items_p2, n_sub, lat);
+    const int slot = blockIdx.y / n_split, sp = blockIdx.y % n_split;
+    const int lag = blockIdx.z;
+    double ar[SQ_QCOLS][SQ_ZPT], ai[SQ_QCOLS][SQ_ZPT];
+#pragma unroll
+    for (int c = 0; c < SQ_QCOLS; ++c)
+#pragma unroll
+        for (int j = 0; j < SQ_ZPT; ++j)
+            ar[c][j] = ai[c][j] = 0.0;
+    const int64_t g_lo = ranges[2 * slot], g_hi = ranges[2 * slot + 1];
+    const int64_t per = (g_hi - g_lo + n_split - 1) / n_split;
+    const int64_t lo = g_lo + sp * per, hi = min(g_hi, lo + per);
+    for (int i = 0; i < n_new; ++i) {
+        const long long f = f_first + i;
+        if (f < lag)
+            continue;
+        sq_quad_frame<true>(lat_tab, lat, t, pos_ring + int64_t(f % ring_slots) * n_atoms * 3,
+                            pos_ring + int64_t((f - lag) % ring_slots) * n_atoms * 3, lo, hi, ar, ai);
+    }
+    sq_quad_store<true>(lat_tab, t, items, n_items, items_p2, n_sub, ar, ai, nullptr,
+                        part + ((int64_t(sp) * n_lags + lag) * n_slots + slot) * n_q);
 }
 
 // Host: quad items of a detected lattice set.  Columns are cut into chunks of SQ_ZPT consecutive
@@ -500,6 +581,42 @@ inline bool sq_build_quads(const std::vector<short> &trip, int64_t n_q, const Sq
         c = d;
     }
     return !items.empty() && double(n_q) >= 0.6 * double(items.size()) * SQ_QCOLS * SQ_ZPT;
+}
+
+// Host: launch shape of the quad kernels for a lattice set — items, copies per item (threads of a
+// block beyond the item count), table tile (two blocks per CU, two table sets per block: ~36 KB per
+// set, a multiple of the copies) and dynamic LDS.  false: the set does not suit the quad form.
+struct SqQuadShape {
+    int n_items = 0, items_p2 = 0, n_sub = 1;
+    SqLattice lat{};
+    size_t lds = 0;
+    int blocks() const { return (int)((int64_t(items_p2) * n_sub + SQ_QUAD_THREADS - 1) / SQ_QUAD_THREADS); }
+};
+
+inline bool sq_quad_plan(const std::vector<short> &trip, int64_t n_q, const SqLattice &base,
+                         std::vector<SqQuadItem> &items, SqQuadShape &sh)
+{
+    if (!sq_build_quads(trip, n_q, base, items))
+        return false;
+    sh.n_items = (int)items.size();
+    sh.items_p2 = 1;
+    while (sh.items_p2 < sh.n_items)
+        sh.items_p2 *= 2;
+    sh.n_sub = std::max(1, SQ_QUAD_THREADS / sh.items_p2);
+    if (sh.n_sub == 1)
+        sh.items_p2 = sh.n_items;   // whole blocks of distinct items
+    const int total_r = base.R[0] + base.R[1] + base.R[2];
+    const int unit = std::max(16, sh.n_sub);
+    const size_t fit = size_t(36) * 1024 / (size_t(16) * total_r);
+    if (fit <= size_t(SQ_QUAD_PAD))
+        return false;
+    const int tile = (int)(std::min<size_t>(512, fit - SQ_QUAD_PAD) / unit * unit);
+    if (tile < 16)
+        return false;
+    sh.lat = base;
+    sh.lat.tile = tile;
+    sh.lds = std::max<size_t>(size_t(32) * (tile + SQ_QUAD_PAD) * total_r + 256, size_t(32) * 1024);
+    return true;
 }
 
 // Host: the column items of a detected lattice set (trip: short[n_q][4]).  Items are ordered

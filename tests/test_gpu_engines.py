@@ -526,8 +526,9 @@ def test_msd_own_two_pass_transform_equals_rocfft(case, monkeypatch):
 
 @pytest.mark.parametrize("mode", [None, "partial"])
 def test_isf_lattice_tables_equal_general_sincos_path(mode, monkeypatch):
-    """Grid wavevectors: separable phase tables (coherent and incoherent parts) against the
-    general fp64 sincos kernels, and both against the restated driver on a subset."""
+    """Grid wavevectors: separable phase tables (coherent part; incoherent part through the
+    register-blocked column kernel and through the per-wavevector tables, MDX_ISF_NO_QUADS)
+    against the general fp64 sincos kernels, and all against the restated driver on a subset."""
     rng = np.random.default_rng(71)
     F, sizes, L = 14, (2600, 1900), 33.0
     N = sum(sizes)
@@ -535,18 +536,21 @@ def test_isf_lattice_tables_equal_general_sincos_path(mode, monkeypatch):
     q = of.grid_wavevectors([L, L, L], 4)[1:]            # drop q = 0: a q_max-style subset
     pairs = of.ssf_pairs(2, mode)
     out = {}
-    for kind in ("lattice", "general"):
+    for kind in ("lattice", "tables", "general"):
+        monkeypatch.delenv("MDX_SQ_NO_LATTICE", raising=False)
+        monkeypatch.delenv("MDX_ISF_NO_QUADS", raising=False)
         if kind == "general":
             monkeypatch.setenv("MDX_SQ_NO_LATTICE", "1")
-        else:
-            monkeypatch.delenv("MDX_SQ_NO_LATTICE", raising=False)
+        elif kind == "tables":
+            monkeypatch.setenv("MDX_ISF_NO_QUADS", "1")
         eng = _core.IsfEngine(q, sizes if mode else [N], pairs, 6, True)
         eng.accumulate(pos[:5])
         eng.accumulate(pos[5:])
         out[kind] = eng.result()
         eng.close()
-    for a, b in zip(out["lattice"], out["general"]):
-        assert np.allclose(a, b, rtol=1e-9, atol=1e-9 * np.abs(b).max())
+    for kind in ("lattice", "tables"):
+        for a, b in zip(out[kind], out["general"]):
+            assert np.allclose(a, b, rtol=1e-9, atol=1e-9 * np.abs(b).max()), kind
     ref = of.isf_run_ref(pos, sizes, q, 6, mode=mode, incoherent=True, sort=False, unique=False)
     norm = N * np.arange(F, F - 6, -1)[:, None, None]
     assert np.allclose(out["lattice"][0] / norm, ref["cisf"], rtol=1e-6, atol=1e-9 * np.abs(ref["cisf"]).max())
