@@ -295,6 +295,12 @@ int mdx_isf_accumulate_traj(mdx_isf_t h, mdx_traj_t traj, const int64_t *frames,
 int mdx_msd_push_traj(mdx_msd_t h, int group, mdx_traj_t traj, const int64_t *frames,
                       int64_t n_frames, const int32_t *index, int64_t n_index, int unwrap,
                       const double *dims, int zero_dims, const double *shift);
+/* groupings="residues" / "segments" for the trajectory-file path (transport.py:983-992 with
+ * center_of_mass(g, gr, images=...)): the rows of the following mdx_msd_push_traj calls are particles
+ * sorted molecule by molecule — molecule g = rows [offsets[g], offsets[g+1]), masses
+ * float64[offsets[n_molecules]] — and the engine receives the float64 centres of mass of the
+ * unwrapped particles, minus `shift`.  n_molecules <= 0 removes the grouping. */
+int mdx_msd_set_grouping(mdx_msd_t h, int64_t n_molecules, const int64_t *offsets, const double *masses);
 /* System centre of mass of every listed frame, out float64[n_frames][3] (host), over the
  * listed particles with the given masses (transport.py:993-1014: all atoms for center_atom,
  * else the groups' particles); unwrap as above; wrap != 0 brings coordinates outside [0, L]

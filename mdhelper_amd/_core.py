@@ -432,6 +432,19 @@ class MsdEngine(_Engine):
     def push_device(self, group, d_pos, n_total, first, count, zero_dims=0):
         check(lib().mdx_msd_push_device(self.handle, group, d_pos, n_total, first, count, zero_dims))
 
+    def set_grouping(self, offsets, masses):
+        """Rows of the following ``push_traj`` calls are particles of molecules
+        ``[offsets[g], offsets[g+1])``; the engine receives their float64 centres of mass.
+        ``offsets=None`` removes the grouping (``mdx_msd_set_grouping``)."""
+        if offsets is None:
+            check(lib().mdx_msd_set_grouping(self.handle, 0, None, None))
+            return
+        o = np.ascontiguousarray(offsets, dtype=np.int64)
+        m = np.ascontiguousarray(masses, dtype=np.float64)
+        if len(m) != o[-1]:
+            raise ValueError("masses must hold one entry per particle of the grouping.")
+        check(lib().mdx_msd_set_grouping(self.handle, len(o) - 1, _ptr(o), _ptr(m)))
+
     def system_com_traj(self, traj_file, frames, index, masses, *, unwrap_dims=None, wrap_dims=None):
         """float64[len(frames), 3] system centre of mass per frame (``Onsager(center=True)``)."""
         f = np.ascontiguousarray(frames, dtype=np.int64)

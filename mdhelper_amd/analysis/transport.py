@@ -363,10 +363,21 @@ class Onsager(SerialAnalysisBase):
                             native, numbers, np.concatenate([g.indices for g in self._groups]),
                             np.concatenate([g.masses for g in self._groups]),
                             unwrap_dims=unwrap_dims, wrap_dims=wrap_dims)
-                for g, (grp, (lo, hi)) in enumerate(zip(self._groups, self._own)):
-                    if hi > lo:
-                        eng.push_traj(g, native, numbers, grp.indices[lo:hi],
-                                      unwrap_dims=unwrap_dims, zero_dims=zero_mask, shift=shift)
+                from .structure import RadialDistributionFunction
+                for g, (grp, gr, (lo, hi)) in enumerate(zip(self._groups, self._groupings, self._own)):
+                    if hi <= lo:
+                        continue
+                    if gr == "atoms":
+                        eng.set_grouping(None, None)
+                        rows = grp.indices[lo:hi]
+                    else:
+                        # molecules lo .. hi of this rank: rows sorted molecule by molecule, the
+                        # float64 centres of the unwrapped particles are formed on the device
+                        idx, off, m = RadialDistributionFunction._selection(grp, gr)
+                        eng.set_grouping(off[lo:hi + 1] - off[lo], m[off[lo]:off[hi]])
+                        rows = idx[off[lo]:off[hi]]
+                    eng.push_traj(g, native, numbers, rows, unwrap_dims=unwrap_dims,
+                                  zero_dims=zero_mask, shift=shift)
             for g, own in enumerate(self._own_slices):
                 if own.stop > own.start and not self._from_file:
                     eng.push(g, self._positions, own.start, own.stop - own.start, zero_mask)
@@ -417,11 +428,14 @@ class Onsager(SerialAnalysisBase):
             **kwargs):
         traj = self._trajectory
         atoms_only = all(g == "atoms" for g in self._groupings)
-        # trajectory files: nothing is staged on the host, unwrapping and the removal of the
-        # system centre of mass included
-        self._from_file = bool(atoms_only and self._fft and getattr(traj, "native", None) is not None)
-        fast = hasattr(traj, "frame_block") and atoms_only and (
-            self._from_file or not (self._unwrap or self._center))
+        # trajectory files: nothing is staged on the host — unwrapping, residue / segment centres
+        # of mass and the removal of the system centre of mass happen on the device.  (Wrapping
+        # the *centres* for the system centre of mass, center_wrap without center_atom, is the
+        # one combination left to the per-frame path.)
+        on_device = atoms_only or not (self._center and self._center_wrap and not self._center_atom)
+        self._from_file = bool(on_device and self._fft and getattr(traj, "native", None) is not None)
+        fast = hasattr(traj, "frame_block") and (self._from_file or (
+            atoms_only and not (self._unwrap or self._center)))
         if not fast:
             return super().run(start=start, stop=stop, step=step, frames=frames, n_jobs=n_jobs,
                                verbose=verbose, **kwargs)

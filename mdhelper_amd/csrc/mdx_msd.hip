@@ -287,6 +287,9 @@ struct mdx_msd {
     DeviceBuffer d_acc, d_traj, d_series, d_spec, d_stage, d_inv_in, d_inv_out;
     DeviceBuffer d_f32, d_index, d_prev, d_image;   // trajectory-file path: frames, unwrap state
     DeviceBuffer d_masses, d_com_x, d_shift;        // system centre of mass per frame
+    // trajectory-file path with groupings="residues"/"segments": rows sorted molecule by molecule
+    std::vector<int64_t> mol_offsets;               // CSR over the rows of a push_traj call
+    DeviceBuffer d_mol_offsets, d_mol_masses, d_mol_total, d_mol_com;
     bool own_fft = false;                           // n_fft = 2^18..2^20: mdx_msd_fft.hpp, not rocFFT
     int64_t fft_batch_atoms = 0;                    // own transform: particles per batch (0: no batching)
     msdfft::Shape shape;
@@ -493,19 +496,67 @@ static int msd_system_com_traj(mdx_msd *h, Trajectory *t, const int64_t *frames,
     return MDX_OK;
 }
 
+// Centres of mass of molecules [m0, m0 + n_mol) from the unwrapped float64 block x[frame][c][3] of
+// their particles (rows a0 .. a0 + c of the selection): sum_a m_a x_a in row order with separate
+// multiply and add, one division — numpy.bincount(weights=m * x) / bincount(weights=m), the
+// reference's center_of_mass (algorithm/molecule.py:300-306) — then the frame's shift.
+__global__ __launch_bounds__(256) void msd_molecule_com_kernel(
+    const double *__restrict__ x, int64_t c, int64_t a0, const int64_t *__restrict__ offsets,
+    const double *__restrict__ masses, const double *__restrict__ total, int64_t m0, int64_t n_mol,
+    const double *__restrict__ shift, double *__restrict__ out)
+{
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;   // (molecule, k)
+    const int64_t f = blockIdx.y;
+    if (i >= n_mol * 3)
+        return;
+    const int64_t m = i / 3;
+    const int k = int(i - 3 * m);
+    const double *row = x + f * c * 3 + k;
+    double acc = 0.0;
+    for (int64_t a = offsets[m0 + m]; a < offsets[m0 + m + 1]; ++a)
+        acc = __dadd_rn(acc, __dmul_rn(masses[a], row[3 * (a - a0)]));
+    double v = acc / total[m0 + m];
+    if (shift)
+        v = __dsub_rn(v, shift[3 * f + k]);
+    out[(f * n_mol + m) * 3 + k] = v;
+}
+
 // The first n_blocks * t_block listed frames of a trajectory file -> one group of the engine.
 static int msd_push_traj(mdx_msd *h, int group, Trajectory *t, const int64_t *frames,
                          const int32_t *index, int64_t n_sel, int unwrap, const double *dims,
                          int zero_dims, const double *shift)
 {
     const int64_t T = int64_t(h->n_blocks) * h->t_block;
-    // particle chunks: the float64 block of a chunk within ~30 % of the free HBM
+    const bool molecules = !h->mol_offsets.empty();
+    const int64_t n_mol = molecules ? (int64_t)h->mol_offsets.size() - 1 : 0;
+    if (molecules)
+        MDX_REQUIRE(h->mol_offsets.back() == n_sel,
+                    "%lld particles given, the grouping was defined for %lld", (long long)n_sel,
+                    (long long)h->mol_offsets.back());
+    // particle chunks: the float64 block of a chunk within ~30 % of the free HBM (with molecules:
+    // their centres need a second, smaller block)
     size_t free_b = 0, total_b = 0;
     MDX_HIP(hipMemGetInfo(&free_b, &total_b));
-    free_b += h->d_stage.bytes;
-    int64_t chunk = std::max<int64_t>(1, int64_t(double(free_b) * 0.3) / (T * 24));
+    free_b += h->d_stage.bytes + h->d_mol_com.bytes;
+    int64_t chunk = std::max<int64_t>(1, int64_t(double(free_b) * (molecules ? 0.2 : 0.3)) / (T * 24));
     chunk = std::min(chunk, n_sel);
     chunk = ceil_div(n_sel, ceil_div(n_sel, chunk));
+    // chunk boundaries in rows: whole molecules only
+    std::vector<int64_t> cuts{0};
+    if (molecules) {
+        int64_t largest = 0;
+        for (int64_t m = 0; m < n_mol; ++m)
+            largest = std::max(largest, h->mol_offsets[size_t(m) + 1] - h->mol_offsets[size_t(m)]);
+        chunk = std::max(chunk, largest);
+        for (int64_t m = 0; m < n_mol; ++m)
+            if (h->mol_offsets[size_t(m) + 1] - cuts.back() > chunk)
+                cuts.push_back(h->mol_offsets[size_t(m)]);
+        cuts.push_back(n_sel);
+    } else {
+        for (int64_t a0 = chunk; a0 < n_sel; a0 += chunk)
+            cuts.push_back(a0);
+        cuts.push_back(n_sel);
+    }
     std::vector<int32_t> iota;
     if (!index) {
         iota.resize(size_t(n_sel));
@@ -525,8 +576,14 @@ static int msd_push_traj(mdx_msd *h, int group, Trajectory *t, const int64_t *fr
         MDX_TRY(h->d_shift.ensure(size_t(24) * T));
         MDX_HIP(hipMemcpy(h->d_shift.ptr, shift, size_t(24) * T, hipMemcpyHostToDevice));
     }
-    for (int64_t a0 = 0; a0 < n_sel; a0 += chunk) {
-        const int64_t c = std::min(chunk, n_sel - a0);
+    // with molecules the shift is subtracted from the centres, as the reference orders it
+    // (transport.py:983-1014), not from the particles
+    const bool shift_rows = shift && !molecules;
+    int64_t m_lo = 0;
+    for (size_t ci = 0; ci + 1 < cuts.size(); ++ci) {
+        const int64_t a0 = cuts[ci], c = cuts[ci + 1] - a0;
+        if (c == 0)
+            continue;
         for (int64_t f0 = 0; f0 < T; f0 += block) {
             const int64_t nf = std::min(block, T - f0);
             TrajSelection sel{h->d_index.as<int>() + a0, c, h->d_f32.as<float>()};
@@ -536,10 +593,27 @@ static int msd_push_traj(mdx_msd *h, int group, Trajectory *t, const int64_t *fr
                                f0 == 0 ? 1 : 0, unwrap, dims ? dims[0] : 0.0, dims ? dims[1] : 0.0,
                                dims ? dims[2] : 0.0, h->d_prev.as<float>(), h->d_image.as<int>(),
                                h->d_stage.as<double>() + f0 * c * 3,
-                               shift ? h->d_shift.as<double>() + 3 * f0 : (const double *)nullptr);
+                               shift_rows ? h->d_shift.as<double>() + 3 * f0 : (const double *)nullptr);
             MDX_HIP(hipGetLastError());
         }
-        MDX_TRY(msd_push_device(h, group, h->d_stage.as<double>(), c, 0, c, zero_dims));
+        if (!molecules) {
+            MDX_TRY(msd_push_device(h, group, h->d_stage.as<double>(), c, 0, c, zero_dims));
+            continue;
+        }
+        int64_t m_hi = m_lo;
+        while (m_hi < n_mol && h->mol_offsets[size_t(m_hi) + 1] <= a0 + c)
+            ++m_hi;
+        const int64_t nm = m_hi - m_lo;
+        MDX_TRY(h->d_mol_com.ensure(size_t(T) * nm * 24));
+        hipLaunchKernelGGL(msd_molecule_com_kernel, dim3((unsigned)ceil_div(nm * 3, 256), (unsigned)T),
+                           dim3(256), 0, h->stream, h->d_stage.as<double>(), c, a0,
+                           h->d_mol_offsets.as<int64_t>(), h->d_mol_masses.as<double>(),
+                           h->d_mol_total.as<double>(), m_lo, nm,
+                           shift ? h->d_shift.as<double>() : (const double *)nullptr,
+                           h->d_mol_com.as<double>());
+        MDX_HIP(hipGetLastError());
+        MDX_TRY(msd_push_device(h, group, h->d_mol_com.as<double>(), nm, 0, nm, zero_dims));
+        m_lo = m_hi;
     }
     return MDX_OK;
 }
@@ -648,7 +722,8 @@ int mdx_msd_destroy(mdx_msd_t h)
     for (DeviceBuffer *b : {&h->d_acc, &h->d_traj, &h->d_series, &h->d_spec, &h->d_stage,
                             &h->d_inv_in, &h->d_inv_out, &h->d_f32, &h->d_index, &h->d_prev,
                             &h->d_image, &h->d_tw, &h->d_pfull, &h->d_masses, &h->d_com_x,
-                            &h->d_shift})
+                            &h->d_shift, &h->d_mol_offsets, &h->d_mol_masses, &h->d_mol_total,
+                            &h->d_mol_com})
         b->release();
     if (h->stream)
         (void)hipStreamDestroy(h->stream);
@@ -708,6 +783,36 @@ int mdx_msd_push(mdx_msd_t h, int group, const double *pos, int64_t n_total, int
         MDX_TRY(msd_push_device(h, group, h->d_stage.as<double>(), c, 0, c, zero_dims));
         MDX_HIP(hipStreamSynchronize(h->stream));
     }
+    return MDX_OK;
+}
+
+int mdx_msd_set_grouping(mdx_msd_t h, int64_t n_molecules, const int64_t *offsets, const double *masses)
+{
+    MDX_REQUIRE(h, "NULL handle");
+    MDX_TRY(set_device(h->dev));
+    MDX_HIP(hipStreamSynchronize(h->stream));
+    h->mol_offsets.clear();
+    if (n_molecules <= 0)
+        return MDX_OK;
+    MDX_REQUIRE(offsets && masses, "NULL argument");
+    MDX_REQUIRE(offsets[0] == 0, "offsets must start at 0");
+    std::vector<double> total((size_t)n_molecules);
+    for (int64_t g = 0; g < n_molecules; ++g) {
+        MDX_REQUIRE(offsets[g + 1] > offsets[g], "molecule %lld is empty", (long long)g);
+        double m = 0.0;
+        for (int64_t a = offsets[g]; a < offsets[g + 1]; ++a)
+            m += masses[a];   // sequential, as numpy.bincount sums the weights
+        MDX_REQUIRE(m > 0.0, "molecule %lld has no mass", (long long)g);
+        total[(size_t)g] = m;
+    }
+    const int64_t n_atoms = offsets[n_molecules];
+    MDX_TRY(h->d_mol_offsets.ensure(size_t(8) * (n_molecules + 1)));
+    MDX_TRY(h->d_mol_masses.ensure(size_t(8) * n_atoms));
+    MDX_TRY(h->d_mol_total.ensure(size_t(8) * n_molecules));
+    MDX_HIP(hipMemcpy(h->d_mol_offsets.ptr, offsets, size_t(8) * (n_molecules + 1), hipMemcpyHostToDevice));
+    MDX_HIP(hipMemcpy(h->d_mol_masses.ptr, masses, size_t(8) * n_atoms, hipMemcpyHostToDevice));
+    MDX_HIP(hipMemcpy(h->d_mol_total.ptr, total.data(), size_t(8) * n_molecules, hipMemcpyHostToDevice));
+    h->mol_offsets.assign(offsets, offsets + n_molecules + 1);
     return MDX_OK;
 }
 

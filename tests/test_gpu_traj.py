@@ -191,3 +191,55 @@ def test_onsager_center_from_file_on_device(tmp_path, mode):
         assert np.allclose(x, y, rtol=1e-8, atol=1e-8 * np.abs(y).max()), name
     # the subtraction matters for this drifting system
     assert not np.allclose(plain.results.msd_cross, b.results.msd_cross, rtol=1e-3)
+
+
+@pytest.mark.parametrize("mode", ["residues", "mixed, unwrap", "residues, unwrap, center", "segments, center_atom"])
+def test_onsager_molecule_groupings_from_file_on_device(tmp_path, mode):
+    """Onsager(groupings="residues"/"segments") on a trajectory file: the float64 centres of mass of
+    the unwrapped particles are formed on the device (mdx_msd_set_grouping); equals the per-frame
+    host analysis (center_of_mass with image flags, transport.py:983-1014)."""
+    import warnings
+    from mdhelper_amd.analysis import Onsager
+    rng = np.random.default_rng(91)
+    T, n_mol, per = 200, 40, 3
+    N = n_mol * per + 9                                              # 9 loose atoms at the end
+    L = np.array([10.0, 11.5, 9.25])
+    centres = rng.uniform(0, L, (1, n_mol, 1, 3)) + np.cumsum(rng.normal(0.02, 0.3, (T, n_mol, 1, 3)), axis=0)
+    shape = rng.normal(0, 0.4, (1, n_mol, per, 3)) + 0.02 * np.cumsum(rng.normal(size=(T, n_mol, per, 3)), axis=0)
+    loose = rng.uniform(0, L, (1, 9, 3)) + np.cumsum(rng.normal(0, 0.3, (T, 9, 3)), axis=0)
+    walk = np.concatenate([(centres + shape).reshape(T, n_mol * per, 3), loose], axis=1)
+    unwrap = "unwrap" in mode
+    stored = (np.mod(walk, L) if unwrap else walk).astype(np.float32)
+    path = tmp_path / "mol.nc"
+    write_amber_netcdf(path, stored, L, times=np.arange(T) * 0.5)
+    dims = np.array([*L, 90, 90, 90], dtype=np.float32)
+    masses = rng.uniform(1.0, 30.0, N)
+    resids = np.r_[np.repeat(np.arange(n_mol), per), n_mol + np.arange(9)]
+    segids = np.r_[np.repeat(np.arange(n_mol // 4), 4 * per), n_mol // 4 + np.arange(9) // 3]
+    kw_u = dict(dt=0.5, masses=masses, resids=resids, segids=segids,
+                charges=np.where(np.arange(N) % 2 == 0, 1.0, -1.0))
+    uf = mdhelper_amd.FileUniverse(path, **kw_u)
+    um = mdhelper_amd.ArrayUniverse(stored, dims, **kw_u)
+    half = (n_mol // 2) * per
+
+    def groups(u):
+        if mode.startswith("mixed"):
+            return [u.atoms[:half], u.atoms[n_mol * per:]], ["residues", "atoms"]
+        if mode.startswith("segments"):
+            return [u.atoms[:half], u.atoms[half:n_mol * per]], "segments"
+        return [u.atoms[:half], u.atoms[half:n_mol * per]], "residues"
+
+    kw = dict(temperature=300, n_blocks=2, verbose=False, unwrap=unwrap, center="center" in mode,
+              center_atom="center_atom" in mode)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ga, gra = groups(uf)
+        a = Onsager(ga, gra, **kw).run()
+        gb, grb = groups(um)
+        b = Onsager(gb, grb, **kw).run()
+    assert a._from_file and not b._from_file
+    assert a.results.msd_self.shape == b.results.msd_self.shape
+    for name in ("msd_self", "msd_cross"):
+        x, y = getattr(a.results, name), getattr(b.results, name)
+        assert np.allclose(x, y, rtol=1e-8, atol=1e-8 * np.abs(y).max()), name
+    assert np.abs(b.results.msd_self).max() > 1.0
