@@ -2,7 +2,7 @@
 """
 bench.py — headline benchmark of the MI355X-native mdhelper hot path.
 
-    python bench.py --gpus N --steps K --warmup W [--workload rdf|sq|msd]
+    python bench.py --gpus N --steps K --warmup W [--workload rdf|rdf_wide|sq|msd|isf]
 
 Default workload (BASELINE.json configs[1], "C2"): RDF on 32 768 atoms, cubic
 box L = 68.94 A (rho = 0.1 A^-3), n_bins = 201, range = (0, 15) A, self RDF with
@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="rdf", choices=["rdf", "rdf_wide", "sq", "msd"])
+    ap.add_argument("--workload", default="rdf", choices=["rdf", "rdf_wide", "sq", "msd", "isf"])
     ap.add_argument("--frames", type=int, default=None, help="frames per step per GPU")
     ap.add_argument("--atoms", type=int, default=None)
     ap.add_argument("--algo", default="auto", choices=["auto", "exact", "filter", "cell"])
@@ -350,6 +350,86 @@ def bench_sq(args, world):
     return out
 
 
+def bench_isf(args, world):
+    """coherent + incoherent intermediate scattering functions, C3's
+    particles and wavevectors, 64 lags; frames resident in HBM (``--host-path``: fed from pageable
+    host memory, PCIe inside the timed region)."""
+    from mdhelper_amd import _core
+    dev = world.local_rank
+    N = args.atoms or 32768
+    F = args.frames or 256
+    L = 68.94
+    n_lags = 64
+    grid = 2 * np.pi * np.arange(8) / L
+    q = np.stack(np.meshgrid(grid, grid, grid), -1).reshape(-1, 3)
+    sizes = [N // 2, N - N // 2]
+    pairs = ((0, 0), (0, 1), (1, 1))
+    traj = _core.synth_random_walk(F, N, [L, L, L], 0.3, seed=2 + world.rank, dev=dev)
+    pos = traj.to_host(0, F)
+    eng = _core.IsfEngine(q, sizes, pairs, n_lags, True, dev=dev, timing=True)
+
+    def step():
+        eng.reset()
+        if args.host_path:
+            eng.accumulate(pos)               # pageable host memory: PCIe inside the timed region
+        else:
+            eng.accumulate_device(traj.ptr, N, F)
+
+    for _ in range(args.warmup):
+        step()
+    dt = timed_region(world, dev, args.steps, step, lambda: None)
+    st = eng.stats()
+    cisf, iisf = eng.result()
+    # terms per frame: rho(q) of every particle + one displacement phase per (lag, particle, q)
+    lagged = sum(min(f + 1, n_lags) for f in range(F))
+    evals = args.steps * world.world * float(N) * len(q) * (F + lagged)
+    kernel_s = st["kernel_ms"] * 1e-3          # of the last step: reset() clears the timer
+    per_step = float(N) * len(q) * (F + lagged)
+    alg = (12 * N) * F
+    achieved = alg / kernel_s / 1e9 if kernel_s > 0 else 0.0
+    out = {
+        "metric": "exp(iq.r) evaluations/sec", "value": evals / dt, "unit": "evals/s",
+        "n_gpus": world.world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"ISF {N} atoms, {len(q)} wavevectors, 2 groups (partial), {n_lags} lags, "
+                               f"coherent + incoherent, {F} frames/GPU/step" + (" from host memory" if args.host_path else "")},
+        "frames_per_sec": args.steps * F * world.world / dt,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "isf_incoherent_quads_kernel + sq_rho_quads_kernel + isf_coherent_kernel",
+                     "note": "fp64 VALU bound like S(q): two FMAs per displacement term, four per rho term",
+                     "valu": {"evaluations_per_sec_kernel": per_step / max(kernel_s, 1e-9),
+                              # 2.5 v_fma_f64-class wave-instructions per 64 displacement terms
+                              "fp64_issue_bound_frac_est": per_step / max(kernel_s, 1e-9) * 2.5 / 64 * 4.76
+                                                           / (1024 * 2.4e9)}},
+        "checksum": float(cisf.sum() + iisf.sum()),
+    }
+    if world.rank == 0 and world.world == 1 and not args.no_cpu_baseline:
+        from oracle import fourier as of
+        n_s, f_s, lags_s = 2048, 8, 4
+        sample = pos[:f_s, :n_s].astype(np.float64)
+        t0 = time.perf_counter()
+        ref = of.isf_run_ref(sample, [n_s // 2, n_s - n_s // 2], q, lags_s, mode="partial", incoherent=True,
+                             sort=False, unique=False)
+        t_cpu = time.perf_counter() - t0
+        small = _core.IsfEngine(q, [n_s // 2, n_s - n_s // 2], pairs, lags_s, True, dev=dev)
+        small.accumulate(pos[:f_s, :n_s])
+        gc, gi = small.result()
+        small.close()
+        norm = n_s * np.arange(f_s, f_s - lags_s, -1)[:, None, None]
+        err = max(float(np.abs(gc / norm - ref["cisf"]).max() / np.abs(ref["cisf"]).max()),
+                  float(np.abs(gi / norm - ref["iisf"]).max() / np.abs(ref["iisf"]).max()))
+        terms = float(n_s) * len(q) * (f_s + sum(min(f + 1, lags_s) for f in range(f_s)))
+        out["cpu_baseline"] = {"value": terms / t_cpu, "unit": "evals/s", "cores": 1, "kind": "port",
+                               "sample": f"{f_s} frames x {n_s} atoms x {lags_s} lags, numpy restatement "
+                                         f"({t_cpu:.1f} s)",
+                               "gpu_max_rel_deviation_on_sample": err}
+    eng.close()
+    traj.free()
+    return out
+
+
 def bench_msd(args, world):
     from mdhelper_amd import _core
     dev = world.local_rank
@@ -446,6 +526,8 @@ def main():
         out = bench_rdf(args, world, wide=args.workload == "rdf_wide")
     elif args.workload == "sq":
         out = bench_sq(args, world)
+    elif args.workload == "isf":
+        out = bench_isf(args, world)
     else:
         out = bench_msd(args, world)
     sys.stdout.flush()

@@ -199,6 +199,8 @@ int mdx_isf_create(mdx_isf_t *out, int dev, const double *wavevectors, int64_t n
 int mdx_isf_destroy(mdx_isf_t h);
 int mdx_isf_reset(mdx_isf_t h);
 int mdx_isf_accumulate(mdx_isf_t h, const float *pos, int64_t n, int64_t n_frames);
+/* Same, positions already in HBM on the engine's device (float32[n_frames][n][3]). */
+int mdx_isf_accumulate_device(mdx_isf_t h, const float *d_pos, int64_t n, int64_t n_frames);
 /* As mdx_sq_set_grouping; only before the first frame of a series. */
 int mdx_isf_set_grouping(mdx_isf_t h, int64_t n_molecules, const int64_t *offsets, const double *masses);
 /* cisf: float64[n_lags][n_pairs][n_q]; iisf (may be NULL): float64[n_lags][n_slots][n_q] with

@@ -371,6 +371,10 @@ class IsfEngine(_Engine):
             p = p[None]
         check(lib().mdx_isf_accumulate(self.handle, _ptr(p), p.shape[1], p.shape[0]))
 
+    def accumulate_device(self, d_pos, n, n_frames):
+        """float32[n_frames][n][3] already in HBM (raw device pointer)."""
+        check(lib().mdx_isf_accumulate_device(self.handle, d_pos, n, n_frames))
+
     def accumulate_traj(self, traj_file, frames, index=None):
         """Frames (in analysis order) of a native trajectory file; ``index`` as for SqEngine."""
         f = np.ascontiguousarray(frames, dtype=np.int64)

@@ -422,6 +422,16 @@ int mdx_isf_accumulate(mdx_isf_t h, const float *pos, int64_t n, int64_t n_frame
     });
 }
 
+int mdx_isf_accumulate_device(mdx_isf_t h, const float *d_pos, int64_t n, int64_t n_frames)
+{
+    MDX_REQUIRE(h && d_pos, "NULL argument");
+    return isf_accumulate(h, n, n_frames, [&](float *d_dst, int64_t done, int64_t nf) -> int {
+        MDX_HIP(hipMemcpyAsync(d_dst, d_pos + done * n * 3, size_t(12) * n * nf,
+                               hipMemcpyDeviceToDevice, h->stream));
+        return MDX_OK;
+    });
+}
+
 // Frames straight from a trajectory file, in the order listed; index as for
 // mdx_sq_accumulate_traj.
 int mdx_isf_accumulate_traj(mdx_isf_t h, mdx_traj_t traj, const int64_t *frames, int64_t n_frames,
