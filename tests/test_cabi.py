@@ -60,6 +60,11 @@ def test_product_fails_loudly_without_gpu():
         StructureFactor(u.atoms, n_points=2).run()
     with pytest.raises(RuntimeError):
         Onsager(u.atoms, reduced=True, temperature=1).run()
+    from mdhelper_amd.analysis import EndToEndVector, IntermediateScatteringFunction
+    with pytest.raises(RuntimeError):
+        EndToEndVector(u.atoms, n_chains=5, n_monomers=10, verbose=False).run()
+    with pytest.raises(RuntimeError):
+        IntermediateScatteringFunction(u.atoms, n_points=2, n_lags=2, verbose=False).run()
     from mdhelper_amd.algorithm import correlation
     with pytest.raises(RuntimeError):
         correlation.correlation_fft(np.ones(8))
