@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=None, help="frames per step per GPU")
     ap.add_argument("--atoms", type=int, default=None)
     ap.add_argument("--algo", default="auto", choices=["auto", "exact", "filter", "cell"])
+    ap.add_argument("--blocks", type=int, default=1, help="msd: n_blocks (C4 is quoted for 1 and 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-path", action="store_true",
                     help="rdf: feed host (pageable) buffers through mdx_rdf_accumulate, i.e. the "
@@ -438,7 +439,8 @@ def bench_msd(args, world):
     # particles shard across ranks (transport.py:1036-1039: per-particle MSDs are independent)
     traj = _core.synth_random_walk(T, N, [1.0, 1.0, 1.0], 0.1, seed=4 + world.rank, dev=dev,
                                    dtype=np.float64)
-    eng = _core.MsdEngine(T, 1, 2, dev=dev, timing=True)
+    B = max(1, args.blocks)
+    eng = _core.MsdEngine(T // B, B, 2, dev=dev, timing=True)
 
     def step():
         eng.reset()
@@ -475,13 +477,13 @@ def bench_msd(args, world):
         "n_gpus": world.world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"C4 self-MSD {N} atoms x {T} frames, 2 groups, n_fft={eng.n_fft}"
-                               + (" (own two-pass transform)" if eng.n_fft in (1 << 18, 1 << 19, 1 << 20)
+        "config": {"workload": f"C4 self-MSD {N} atoms x {T} frames, 2 groups, n_blocks={B}, n_fft={eng.n_fft}"
+                               + (" (own two-pass transform)" if eng.n_fft in (1 << 15, 1 << 16, 1 << 18, 1 << 19, 1 << 20)
                                   and not os.environ.get("MDX_MSD_ROCFFT") else " (rocFFT)")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "msd pipeline of one step: sums + forward transforms + power "
-                               "(msd_fft_cols/rows_power kernels for n_fft = 2^18..2^20, else gather + "
+                               "(msd_fft_cols/rows_power kernels for n_fft = 2^15, 2^16, 2^18..2^20, else gather + "
                                "rocFFT R2C + power)",
                      "pipeline_bytes_model": st["bytes_moved"]},
         "physics_check_msd_over_3sigma2m": float(msd[10] / (3 * 0.01 * 10)),

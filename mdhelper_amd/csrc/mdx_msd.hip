@@ -290,7 +290,7 @@ struct mdx_msd {
     // trajectory-file path with groupings="residues"/"segments": rows sorted molecule by molecule
     std::vector<int64_t> mol_offsets;               // CSR over the rows of a push_traj call
     DeviceBuffer d_mol_offsets, d_mol_masses, d_mol_total, d_mol_com;
-    bool own_fft = false;                           // n_fft = 2^18..2^20: mdx_msd_fft.hpp, not rocFFT
+    bool own_fft = false;                           // n_fft = 2^15, 2^16, 2^18..2^20: mdx_msd_fft.hpp
     int64_t fft_batch_atoms = 0;                    // own transform: particles per batch (0: no batching)
     msdfft::Shape shape;
     DeviceBuffer d_tw, d_pfull;                     // twiddle tables [2][512], full-spectrum sums [B][N]
@@ -651,8 +651,10 @@ int mdx_msd_create(mdx_msd_t *out, int dev, int64_t n_frames_block, int n_blocks
         // whatever N_t is — whenever the rocFFT pipeline (~17.7 MB per series at 2^18, in
         // proportion for other lengths) would move more: from N_t = 40 000 up to 524 288
         int64_t own_len = 0;
-        if (!getenv("MDX_MSD_ROCFFT") && n_frames_block >= 40000)
-            own_len = std::max<int64_t>(p, int64_t(1) << 18);
+        // ... and 2^15 / 2^16 (64 x 512, 64 x 1024) for blocks of 8 193 .. 32 768 frames; 2^17 is
+        // served by 2^18
+        if (!getenv("MDX_MSD_ROCFFT") && n_frames_block > 8192)
+            own_len = p <= (int64_t(1) << 16) ? p : std::max<int64_t>(p, int64_t(1) << 18);
         if (own_len && msdfft::shape_for(own_len).r1 && !force_ref)
             h->n_fft = own_len;
         else if (force_pow2 || (!force_ref && 2 * p <= 3 * h->n_fft))

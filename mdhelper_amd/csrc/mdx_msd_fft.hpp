@@ -1,4 +1,4 @@
-// mdx_msd_fft.hpp — the MSD engine's own forward transforms for n_fft = 2^18, 2^19, 2^20.
+// mdx_msd_fft.hpp — the MSD engine's own forward transforms for n_fft = 2^15, 2^16, 2^18, 2^19, 2^20.
 //
 // The power spectrum sum_series |F_k|^2 of ~30 000 zero-padded real series of 10^5 points is
 // HBM traffic, not arithmetic.  Through rocFFT the pipeline moves ~17.7 MB per series at 2^18
@@ -19,7 +19,8 @@
 //
 // One wave owns one transform (radix-8 Stockham stages, a radix-16 last stage for 1024 points,
 // in place in a wave-private LDS buffer; a wave's LDS operations execute in order, so there is
-// no barrier inside a transform).  Shapes: 2^18 = 512 x 512, 2^19 = 1024 x 512, 2^20 = 1024 x 1024.
+// no barrier inside a transform).  Shapes: 2^15 = 64 x 512, 2^16 = 64 x 1024 (eight 64-point column
+// transforms per wave at a time), 2^18 = 512 x 512, 2^19 = 1024 x 512, 2^20 = 1024 x 1024.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -148,6 +149,34 @@ __device__ __forceinline__ void stockham_stage(double2 *z, const double2 *tw, in
     wave_lds_fence();
 }
 
+// The same stage for NC independent M-point transforms held by one wave (M / RADIX * NC == 64:
+// every lane owns one butterfly), transform c at z + c * zs.
+template <int M, int NC, int RADIX, int NS, bool FIRST>
+__device__ __forceinline__ void stockham_stage_batch(double2 *z, int zs, const double2 *tw, int lane,
+                                                     int n_live)
+{
+    constexpr int T = M / RADIX;
+    static_assert(T * NC == 64, "one butterfly per lane");
+    const int c = lane / T, j = lane % T;
+    const int k = j & (NS - 1);
+    double2 *zc = z + c * zs;
+    double2 v[RADIX];
+#pragma unroll
+    for (int r = 0; r < RADIX; ++r) {
+        const int idx = j + r * T;
+        v[r] = (!FIRST || idx < n_live) ? zc[idx] : make_double2(0.0, 0.0);
+        if (NS > 1 && r)
+            v[r] = cmul(v[r], tw_at<M>(tw, (r * k * (M / (RADIX * NS))) & (M - 1)));
+    }
+    dft<RADIX>(v);
+    wave_lds_fence();
+    const int j0 = (j - k) * RADIX + k;
+#pragma unroll
+    for (int r = 0; r < RADIX; ++r)
+        zc[j0 + r * NS] = v[r];
+    wave_lds_fence();
+}
+
 // In-place forward M-point transform of z[0..M) (LDS) by one wave.  tw: exp(-2 pi i m / M),
 // m < M / 2, in LDS (global twiddle loads would share the vmcnt queue with the streaming loads
 // of the callers and make every transform wait for HBM).
@@ -233,6 +262,71 @@ __global__ __launch_bounds__(THREADS, R1 == 512 ? 4 : 2) void msd_fft_cols_kerne
         __syncthreads();
     }
 #undef MDX_COLS_LOAD
+}
+
+// Pass A for R1 = 64 (n_fft = 2^15, 2^16: blocks of 8 193 .. 32 768 frames): a wave transforms
+// eight neighbouring columns of its pair at once (8 x 64 points = one butterfly per lane and
+// stage), so a block still moves 4 096 values per barrier; the eight columns of a (k1, pair
+// group) leave as one 1 KB run.  Same grid and arguments as msd_fft_cols_kernel; gridDim.y <= R2 / 8.
+template <int R2>
+__global__ __launch_bounds__(THREADS, 2) void msd_fft_cols64_kernel(
+    const double *__restrict__ pos, int64_t n_total, int64_t first, int64_t n_elem, int64_t t_block,
+    int zero_dims, int p_pad, const double2 *__restrict__ tw_r1, const double2 *__restrict__ twN,
+    double2 *__restrict__ Y)
+{
+    constexpr int R1 = 64, NC = 8, ZS = R1 + 1;
+    __shared__ double2 zb[PG][NC][ZS];
+    __shared__ double2 s_h[R1 / 2];   // exp(-2 pi i m / 64), m < 32
+    __shared__ double2 s_n[R2];       // exp(-2 pi i m / N),  m < R2
+    const int pg = blockIdx.x, b = blockIdx.z;
+    const int n2_count = R2 / int(gridDim.y);
+    const int n2_begin = blockIdx.y * n2_count;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < R1 / 2; i += THREADS)
+        s_h[i] = tw_r1[i];
+    for (int i = tid; i < R2; i += THREADS)
+        s_n[i] = twN[i];
+
+    const int s = tid & 15, n1 = tid >> 4;        // coordinate of the group, live row (< 32)
+    const int64_t e = int64_t(pg) * 16 + s;
+    const bool live = e < n_elem && !((zero_dims >> int(e % 3)) & 1);
+    const double *src = pos + (int64_t(b) * t_block * n_total + first) * 3 + e;
+    const int64_t row_stride = n_total * 3;
+    double *dst = reinterpret_cast<double *>(&zb[s >> 1][0][0]) + (s & 1);
+    const int p = tid & 7, k1 = tid >> 3;
+    double2 *out = Y + ((int64_t(b) * R1 + k1) * (p_pad / PG) + pg) * R2 * PG + p;
+
+    double x[NC];   // row n1 of the eight columns: eight consecutive frames
+#define MDX_COLS64_LOAD(N2)                                                         \
+    _Pragma("unroll") for (int i = 0; i < NC; ++i)                                  \
+    {                                                                               \
+        const int64_t t = int64_t(n1) * R2 + (N2) + i;                              \
+        x[i] = (live && t < t_block) ? src[t * row_stride] : 0.0;                   \
+    }
+    MDX_COLS64_LOAD(n2_begin)
+    __syncthreads();
+    for (int n2 = n2_begin; n2 < n2_begin + n2_count; n2 += NC) {
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+            dst[2 * (i * ZS + n1)] = x[i];
+        __syncthreads();
+        {
+            const int nxt = min(n2 + NC, R2 - NC);   // the last group reloads itself
+            MDX_COLS64_LOAD(nxt)
+        }
+        stockham_stage_batch<R1, NC, 8, 1, true>(&zb[wave][0][0], ZS, s_h, lane, R1 / 2);
+        stockham_stage_batch<R1, NC, 8, 8, false>(&zb[wave][0][0], ZS, s_h, lane, R1);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            // W_N^(n2 k1) = W_R1^(m / R2) * W_N^(m mod R2), m = n2 k1 < N
+            const unsigned m = unsigned(k1) * unsigned(n2 + i);
+            const double2 w = cmul(tw_at<R1>(s_h, int(m / R2)), s_n[m & (R2 - 1)]);
+            out[int64_t(n2 + i) * PG] = cmul(zb[p][i][k1], w);
+        }
+        __syncthreads();
+    }
+#undef MDX_COLS64_LOAD
 }
 
 // Pass B.  grid (k1 < R1, blocks of the trajectory), 512 threads; thread = k2 (and k2 + 512).
@@ -330,7 +424,11 @@ struct Shape {
 inline Shape shape_for(int64_t n_fft)
 {
     Shape s;
-    if (n_fft == (int64_t(1) << 18))
+    if (n_fft == (int64_t(1) << 15))
+        s.r1 = 64, s.r2 = 512;
+    else if (n_fft == (int64_t(1) << 16))
+        s.r1 = 64, s.r2 = 1024;
+    else if (n_fft == (int64_t(1) << 18))
         s.r1 = 512, s.r2 = 512;
     else if (n_fft == (int64_t(1) << 19))
         s.r1 = 1024, s.r2 = 512;
@@ -348,7 +446,7 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
 {
     // >= ~1024 blocks of pass A where the batch allows it
     int split = 4;
-    while (split < sh.r2 / 2 && int64_t(p_pad / PG) * split * n_blocks < 1024)
+    while (split < (sh.r1 == 64 ? sh.r2 / 8 : sh.r2 / 2) && int64_t(p_pad / PG) * split * n_blocks < 1024)
         split *= 2;
     const dim3 ga((unsigned)(p_pad / PG), (unsigned)split, (unsigned)n_blocks);
     const dim3 gb((unsigned)sh.r1, (unsigned)n_blocks);
@@ -357,7 +455,19 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
                        n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y);                          \
     hipLaunchKernelGGL((msd_fft_rows_power_kernel<A, B>), gb, dim3(THREADS), 0, stream, Y, p_pad,     \
                        tw_r2, Pfull, accumulate)
-    if (sh.r1 == 512 && sh.r2 == 512) {
+    if (sh.r1 == 64) {
+        if (sh.r2 == 512) {
+            hipLaunchKernelGGL((msd_fft_cols64_kernel<512>), ga, dim3(THREADS), 0, stream, pos, n_total, first,
+                               n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y);
+            hipLaunchKernelGGL((msd_fft_rows_power_kernel<64, 512>), gb, dim3(THREADS), 0, stream, Y, p_pad,
+                               tw_r2, Pfull, accumulate);
+        } else {
+            hipLaunchKernelGGL((msd_fft_cols64_kernel<1024>), ga, dim3(THREADS), 0, stream, pos, n_total,
+                               first, n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y);
+            hipLaunchKernelGGL((msd_fft_rows_power_kernel<64, 1024>), gb, dim3(THREADS), 0, stream, Y, p_pad,
+                               tw_r2, Pfull, accumulate);
+        }
+    } else if (sh.r1 == 512 && sh.r2 == 512) {
         MDX_MSDFFT_LAUNCH(512, 512);
     } else if (sh.r1 == 1024 && sh.r2 == 512) {
         MDX_MSDFFT_LAUNCH(1024, 512);
