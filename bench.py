@@ -478,12 +478,13 @@ def bench_msd(args, world):
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"C4 self-MSD {N} atoms x {T} frames, 2 groups, n_blocks={B}, n_fft={eng.n_fft}"
-                               + (" (own two-pass transform)" if eng.n_fft in (1 << 15, 1 << 16, 1 << 18, 1 << 19, 1 << 20)
+                               + (" (own two-pass transform)" if eng.n_fft in (1 << 13, 1 << 14, 1 << 15, 1 << 16, 1 << 18,
+                                                                                  1 << 19, 1 << 20)
                                   and not os.environ.get("MDX_MSD_ROCFFT") else " (rocFFT)")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "msd pipeline of one step: sums + forward transforms + power "
-                               "(msd_fft_cols/rows_power kernels for n_fft = 2^15, 2^16, 2^18..2^20, else gather + "
+                               "(msd_fft_cols/rows_power kernels for n_fft = 2^13..2^16, 2^18..2^20, else gather + "
                                "rocFFT R2C + power)",
                      "pipeline_bytes_model": st["bytes_moved"]},
         "physics_check_msd_over_3sigma2m": float(msd[10] / (3 * 0.01 * 10)),

@@ -651,9 +651,9 @@ int mdx_msd_create(mdx_msd_t *out, int dev, int64_t n_frames_block, int n_blocks
         // whatever N_t is — whenever the rocFFT pipeline (~17.7 MB per series at 2^18, in
         // proportion for other lengths) would move more: from N_t = 40 000 up to 524 288
         int64_t own_len = 0;
-        // ... and 2^15 / 2^16 (64 x 512, 64 x 1024) for blocks of 8 193 .. 32 768 frames; 2^17 is
-        // served by 2^18
-        if (!getenv("MDX_MSD_ROCFFT") && n_frames_block > 8192)
+        // ... and 2^13 .. 2^16 (16 or 64 x 512 or 1024) for blocks of 2 049 .. 32 768 frames; 2^17
+        // is served by 2^18
+        if (!getenv("MDX_MSD_ROCFFT") && n_frames_block > 2048)
             own_len = p <= (int64_t(1) << 16) ? p : std::max<int64_t>(p, int64_t(1) << 18);
         if (own_len && msdfft::shape_for(own_len).r1 && !force_ref)
             h->n_fft = own_len;
@@ -693,7 +693,8 @@ int mdx_msd_create(mdx_msd_t *out, int dev, int64_t n_frames_block, int n_blocks
                 rc = fail(MDX_ERR_HIP, "twiddle table upload failed");
                 break;
             }
-            if ((rc = h->d_pfull.ensure(size_t(8) * n_blocks * h->n_fft)) != MDX_OK) break;
+            if ((rc = h->d_pfull.ensure(size_t(8) * n_blocks * h->n_fft *
+                                        msdfft::rows_parts(h->shape, n_blocks))) != MDX_OK) break;
             // batch size in MiB of Y (MDX_MSD_BATCH_MB, 0 = whole chunks), whole groups of 16
             // particles = 3 pair groups
             const char *env = getenv("MDX_MSD_BATCH_MB");

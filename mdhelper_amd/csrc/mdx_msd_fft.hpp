@@ -1,4 +1,4 @@
-// mdx_msd_fft.hpp — the MSD engine's own forward transforms for n_fft = 2^15, 2^16, 2^18, 2^19, 2^20.
+// mdx_msd_fft.hpp — the MSD engine's own forward transforms for n_fft = 2^13 .. 2^16, 2^18, 2^19, 2^20.
 //
 // The power spectrum sum_series |F_k|^2 of ~30 000 zero-padded real series of 10^5 points is
 // HBM traffic, not arithmetic.  Through rocFFT the pipeline moves ~17.7 MB per series at 2^18
@@ -19,8 +19,8 @@
 //
 // One wave owns one transform (radix-8 Stockham stages, a radix-16 last stage for 1024 points,
 // in place in a wave-private LDS buffer; a wave's LDS operations execute in order, so there is
-// no barrier inside a transform).  Shapes: 2^15 = 64 x 512, 2^16 = 64 x 1024 (eight 64-point column
-// transforms per wave at a time), 2^18 = 512 x 512, 2^19 = 1024 x 512, 2^20 = 1024 x 1024.
+// no barrier inside a transform).  Shapes: 2^13 = 16 x 512, 2^14 = 16 x 1024, 2^15 = 64 x 512,
+// 2^16 = 64 x 1024 (32 or 8 short column transforms per wave at a time), 2^18 = 512 x 512, 2^19 = 1024 x 512, 2^20 = 1024 x 1024.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -156,10 +156,11 @@ __device__ __forceinline__ void stockham_stage_batch(double2 *z, int zs, const d
                                                      int n_live)
 {
     constexpr int T = M / RADIX;
-    static_assert(T * NC == 64, "one butterfly per lane");
+    static_assert(T * NC <= 64, "at most one butterfly per lane");
     const int c = lane / T, j = lane % T;
+    const bool busy = T * NC == 64 || c < NC;       // the other lanes idle (R1 = 16: 32 columns)
     const int k = j & (NS - 1);
-    double2 *zc = z + c * zs;
+    double2 *zc = z + (busy ? c : 0) * zs;
     double2 v[RADIX];
 #pragma unroll
     for (int r = 0; r < RADIX; ++r) {
@@ -171,9 +172,10 @@ __device__ __forceinline__ void stockham_stage_batch(double2 *z, int zs, const d
     dft<RADIX>(v);
     wave_lds_fence();
     const int j0 = (j - k) * RADIX + k;
+    if (busy)
 #pragma unroll
-    for (int r = 0; r < RADIX; ++r)
-        zc[j0 + r * NS] = v[r];
+        for (int r = 0; r < RADIX; ++r)
+            zc[j0 + r * NS] = v[r];
     wave_lds_fence();
 }
 
@@ -264,19 +266,22 @@ __global__ __launch_bounds__(THREADS, R1 == 512 ? 4 : 2) void msd_fft_cols_kerne
 #undef MDX_COLS_LOAD
 }
 
-// Pass A for R1 = 64 (n_fft = 2^15, 2^16: blocks of 8 193 .. 32 768 frames): a wave transforms
-// eight neighbouring columns of its pair at once (8 x 64 points = one butterfly per lane and
-// stage), so a block still moves 4 096 values per barrier; the eight columns of a (k1, pair
-// group) leave as one 1 KB run.  Same grid and arguments as msd_fft_cols_kernel; gridDim.y <= R2 / 8.
-template <int R2>
-__global__ __launch_bounds__(THREADS, 2) void msd_fft_cols64_kernel(
+// Pass A for short first factors, R1 = 64 (n_fft = 2^15, 2^16) and R1 = 16 (2^13, 2^14): a wave
+// transforms NC = 512 / R1 neighbouring columns of its pair at once (one butterfly per lane and
+// stage for R1 = 64; one radix-16 butterfly per column for R1 = 16), so a block still moves 4 096
+// values per barrier, and the NC columns of a (k1, pair group) leave as one run of NC x 128 B.
+// Same grid and arguments as msd_fft_cols_kernel; gridDim.y <= R2 / NC.
+template <int R1, int R2>
+__global__ __launch_bounds__(THREADS, 2) void msd_fft_cols_small_kernel(
     const double *__restrict__ pos, int64_t n_total, int64_t first, int64_t n_elem, int64_t t_block,
     int zero_dims, int p_pad, const double2 *__restrict__ tw_r1, const double2 *__restrict__ twN,
     double2 *__restrict__ Y)
 {
-    constexpr int R1 = 64, NC = 8, ZS = R1 + 1;
+    static_assert(R1 == 64 || R1 == 16, "supported first factors");
+    constexpr int NC = 512 / R1, ZS = R1 + 1, LIVE = R1 / 2;
+    constexpr int PER = 8;                         // columns per thread on either side
     __shared__ double2 zb[PG][NC][ZS];
-    __shared__ double2 s_h[R1 / 2];   // exp(-2 pi i m / 64), m < 32
+    __shared__ double2 s_h[R1 / 2];   // exp(-2 pi i m / R1), m < R1 / 2
     __shared__ double2 s_n[R2];       // exp(-2 pi i m / N),  m < R2
     const int pg = blockIdx.x, b = blockIdx.z;
     const int n2_count = R2 / int(gridDim.y);
@@ -287,50 +292,59 @@ __global__ __launch_bounds__(THREADS, 2) void msd_fft_cols64_kernel(
     for (int i = tid; i < R2; i += THREADS)
         s_n[i] = twN[i];
 
-    const int s = tid & 15, n1 = tid >> 4;        // coordinate of the group, live row (< 32)
+    // loads: coordinate s of the group, live row n1 (< R1 / 2), PER consecutive columns from c_in
+    const int s = tid & 15, n1 = (tid >> 4) % LIVE, c_in = (tid >> 4) / LIVE * PER;
     const int64_t e = int64_t(pg) * 16 + s;
     const bool live = e < n_elem && !((zero_dims >> int(e % 3)) & 1);
     const double *src = pos + (int64_t(b) * t_block * n_total + first) * 3 + e;
     const int64_t row_stride = n_total * 3;
-    double *dst = reinterpret_cast<double *>(&zb[s >> 1][0][0]) + (s & 1);
-    const int p = tid & 7, k1 = tid >> 3;
+    double *dst = reinterpret_cast<double *>(&zb[s >> 1][c_in][0]) + (s & 1);
+    // stores: pair p, line k1, PER consecutive columns from c_out
+    const int p = tid & 7, k1 = (tid >> 3) % R1, c_out = (tid >> 3) / R1 * PER;
     double2 *out = Y + ((int64_t(b) * R1 + k1) * (p_pad / PG) + pg) * R2 * PG + p;
 
-    double x[NC];   // row n1 of the eight columns: eight consecutive frames
-#define MDX_COLS64_LOAD(N2)                                                         \
-    _Pragma("unroll") for (int i = 0; i < NC; ++i)                                  \
+    double x[PER];   // row n1 of PER columns: consecutive frames
+#define MDX_COLS_SMALL_LOAD(N2)                                                     \
+    _Pragma("unroll") for (int i = 0; i < PER; ++i)                                 \
     {                                                                               \
-        const int64_t t = int64_t(n1) * R2 + (N2) + i;                              \
+        const int64_t t = int64_t(n1) * R2 + (N2) + c_in + i;                       \
         x[i] = (live && t < t_block) ? src[t * row_stride] : 0.0;                   \
     }
-    MDX_COLS64_LOAD(n2_begin)
+    MDX_COLS_SMALL_LOAD(n2_begin)
     __syncthreads();
     for (int n2 = n2_begin; n2 < n2_begin + n2_count; n2 += NC) {
 #pragma unroll
-        for (int i = 0; i < NC; ++i)
+        for (int i = 0; i < PER; ++i)
             dst[2 * (i * ZS + n1)] = x[i];
         __syncthreads();
         {
             const int nxt = min(n2 + NC, R2 - NC);   // the last group reloads itself
-            MDX_COLS64_LOAD(nxt)
+            MDX_COLS_SMALL_LOAD(nxt)
         }
-        stockham_stage_batch<R1, NC, 8, 1, true>(&zb[wave][0][0], ZS, s_h, lane, R1 / 2);
-        stockham_stage_batch<R1, NC, 8, 8, false>(&zb[wave][0][0], ZS, s_h, lane, R1);
+        if (R1 == 64) {
+            stockham_stage_batch<R1, NC, 8, 1, true>(&zb[wave][0][0], ZS, s_h, lane, LIVE);
+            stockham_stage_batch<R1, NC, 8, 8, false>(&zb[wave][0][0], ZS, s_h, lane, R1);
+        } else {
+            stockham_stage_batch<R1, NC, 16, 1, true>(&zb[wave][0][0], ZS, s_h, lane, LIVE);
+        }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < NC; ++i) {
+        for (int i = 0; i < PER; ++i) {
             // W_N^(n2 k1) = W_R1^(m / R2) * W_N^(m mod R2), m = n2 k1 < N
-            const unsigned m = unsigned(k1) * unsigned(n2 + i);
+            const int col = c_out + i;
+            const unsigned m = unsigned(k1) * unsigned(n2 + col);
             const double2 w = cmul(tw_at<R1>(s_h, int(m / R2)), s_n[m & (R2 - 1)]);
-            out[int64_t(n2 + i) * PG] = cmul(zb[p][i][k1], w);
+            out[int64_t(n2 + col) * PG] = cmul(zb[p][col][k1], w);
         }
         __syncthreads();
     }
-#undef MDX_COLS64_LOAD
+#undef MDX_COLS_SMALL_LOAD
 }
 
 // Pass B.  grid (k1 < R1, blocks of the trajectory), 512 threads; thread = k2 (and k2 + 512).
-// Pfull[b][k1][k2] (+)= sum over the pairs of this launch of |Z_{k1 + R1 k2}|^2.
+// Pfull[part][b][k1][k2] (+)= sum over the pairs of this launch of |Z_{k1 + R1 k2}|^2; blockIdx.z =
+// part: the pair groups are dealt round-robin to gridDim.z parts when R1 x blocks alone would not
+// fill the chip (the fold kernel adds the parts in order).
 template <int R1, int R2>
 __global__ __launch_bounds__(THREADS, R2 == 512 ? 4 : 2) void msd_fft_rows_power_kernel(
     const double2 *__restrict__ Y, int p_pad, const double2 *__restrict__ tw_r2,
@@ -346,8 +360,17 @@ __global__ __launch_bounds__(THREADS, R2 == 512 ? 4 : 2) void msd_fft_rows_power
     for (int i = tid; i < R2 / 2; i += THREADS)
         s_tw[i] = tw_r2[i];
     // Y[b][k1][pair group][n2][pair]: one group's R2 x 8 values are contiguous
-    const int n_groups = p_pad / PG;
-    const double2 *src = Y + (int64_t(b) * R1 + k1) * n_groups * (R2 * PG) + tid;
+    const int n_all = p_pad / PG, n_parts = gridDim.z, part = blockIdx.z;
+    const int n_groups = (n_all - part + n_parts - 1) / n_parts;      // groups part, part + n_parts, ...
+    const int64_t g_stride = int64_t(n_parts) * (R2 * PG);
+    const double2 *src = Y + ((int64_t(b) * R1 + k1) * n_all + part) * (R2 * PG) + tid;
+    if (n_groups <= 0) {   // more parts than pair groups: this part contributes nothing
+        if (!accumulate)
+#pragma unroll
+            for (int i = 0; i < OUTS; ++i)
+                Pfull[((int64_t(part) * gridDim.y + b) * R1 + k1) * R2 + tid + THREADS * i] = 0.0;
+        return;
+    }
     double acc[OUTS];
 #pragma unroll
     for (int i = 0; i < OUTS; ++i)
@@ -373,7 +396,7 @@ __global__ __launch_bounds__(THREADS, R2 == 512 ? 4 : 2) void msd_fft_rows_power
         __syncthreads();
         {   // the next group's rows are in flight during this transform (the last iteration
             // reloads its own group: no branch)
-            const int64_t off = int64_t(min(pg + 1, n_groups - 1)) * (R2 * PG);
+            const int64_t off = int64_t(min(pg + 1, n_groups - 1)) * g_stride;
             MDX_ROWS_EACH(MDX_ROWS_LOAD)
         }
         fft_wave<R2>(zb[wave], s_tw, lane, R2);
@@ -392,15 +415,15 @@ __global__ __launch_bounds__(THREADS, R2 == 512 ? 4 : 2) void msd_fft_rows_power
 #undef MDX_ROWS_PUT
 #pragma unroll
     for (int i = 0; i < OUTS; ++i) {
-        double *o = Pfull + (int64_t(b) * R1 + k1) * R2 + tid + THREADS * i;
+        double *o = Pfull + ((int64_t(part) * gridDim.y + b) * R1 + k1) * R2 + tid + THREADS * i;
         *o = accumulate ? *o + acc[i] : acc[i];
     }
 }
 
-// P[b][k] += (Pfull[b][k] + Pfull[b][N - k]) / 2 for the half spectrum k <= N/2, with Pfull
-// stored as [k1][k2], k = k1 + R1 k2.
+// P[b][k] += sum over the parts of (Pfull[part][b][k] + Pfull[part][b][N - k]) / 2 for the half
+// spectrum k <= N/2, with Pfull stored as [k1][k2], k = k1 + R1 k2.
 __global__ __launch_bounds__(256) void msd_power_fold_kernel(const double *__restrict__ Pfull,
-                                                            int r1, int r2, int64_t nc,
+                                                            int r1, int r2, int n_parts, int64_t nc,
                                                             double *__restrict__ P)
 {
     const int64_t k = int64_t(blockIdx.x) * 256 + threadIdx.x;
@@ -409,8 +432,11 @@ __global__ __launch_bounds__(256) void msd_power_fold_kernel(const double *__res
         return;
     const int64_t n = int64_t(r1) * r2;
     const int64_t km = (n - k) & (n - 1);
-    const double *pf = Pfull + int64_t(b) * n;
-    const double s = 0.5 * (pf[(k & (r1 - 1)) * r2 + k / r1] + pf[(km & (r1 - 1)) * r2 + km / r1]);
+    double s = 0.0;
+    for (int part = 0; part < n_parts; ++part) {
+        const double *pf = Pfull + (int64_t(part) * gridDim.y + b) * n;
+        s += 0.5 * (pf[(k & (r1 - 1)) * r2 + k / r1] + pf[(km & (r1 - 1)) * r2 + km / r1]);
+    }
     P[int64_t(b) * nc + k] += s;
 }
 
@@ -424,7 +450,11 @@ struct Shape {
 inline Shape shape_for(int64_t n_fft)
 {
     Shape s;
-    if (n_fft == (int64_t(1) << 15))
+    if (n_fft == (int64_t(1) << 13))
+        s.r1 = 16, s.r2 = 512;
+    else if (n_fft == (int64_t(1) << 14))
+        s.r1 = 16, s.r2 = 1024;
+    else if (n_fft == (int64_t(1) << 15))
         s.r1 = 64, s.r2 = 512;
     else if (n_fft == (int64_t(1) << 16))
         s.r1 = 64, s.r2 = 1024;
@@ -437,6 +467,16 @@ inline Shape shape_for(int64_t n_fft)
     return s;
 }
 
+// Parts of pass B (blockIdx.z): R1 x blocks x parts >= 512 blocks; Pfull holds one copy per part.
+constexpr int ROWS_PARTS_MAX = 32;
+inline int rows_parts(const Shape &sh, int n_blocks)
+{
+    int parts = 1;
+    while (int64_t(sh.r1) * n_blocks * parts < 512 && parts < ROWS_PARTS_MAX)
+        parts *= 2;
+    return parts;
+}
+
 // tw_r1 / tw_r2: half tables exp(-2 pi i m / R), m < R / 2; twN: exp(-2 pi i m / N), m < R2
 // One batch of coordinates -> Pfull; accumulate != 0 adds to what earlier batches left there.
 inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64_t n_total,
@@ -446,27 +486,31 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
 {
     // >= ~1024 blocks of pass A where the batch allows it
     int split = 4;
-    while (split < (sh.r1 == 64 ? sh.r2 / 8 : sh.r2 / 2) && int64_t(p_pad / PG) * split * n_blocks < 1024)
+    while (split < (sh.r1 <= 64 ? sh.r2 / (512 / sh.r1) : sh.r2 / 2) && int64_t(p_pad / PG) * split * n_blocks < 1024)
         split *= 2;
     const dim3 ga((unsigned)(p_pad / PG), (unsigned)split, (unsigned)n_blocks);
-    const dim3 gb((unsigned)sh.r1, (unsigned)n_blocks);
+    const dim3 gb((unsigned)sh.r1, (unsigned)n_blocks, (unsigned)rows_parts(sh, n_blocks));
 #define MDX_MSDFFT_LAUNCH(A, B)                                                                    \
     hipLaunchKernelGGL((msd_fft_cols_kernel<A, B>), ga, dim3(THREADS), 0, stream, pos, n_total, first, \
                        n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y);                          \
     hipLaunchKernelGGL((msd_fft_rows_power_kernel<A, B>), gb, dim3(THREADS), 0, stream, Y, p_pad,     \
                        tw_r2, Pfull, accumulate)
-    if (sh.r1 == 64) {
-        if (sh.r2 == 512) {
-            hipLaunchKernelGGL((msd_fft_cols64_kernel<512>), ga, dim3(THREADS), 0, stream, pos, n_total, first,
-                               n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y);
-            hipLaunchKernelGGL((msd_fft_rows_power_kernel<64, 512>), gb, dim3(THREADS), 0, stream, Y, p_pad,
-                               tw_r2, Pfull, accumulate);
+    if (sh.r1 <= 64) {
+#define MDX_MSDFFT_SMALL(A, B)                                                                           \
+    hipLaunchKernelGGL((msd_fft_cols_small_kernel<A, B>), ga, dim3(THREADS), 0, stream, pos, n_total, first, \
+                       n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y);                                \
+    hipLaunchKernelGGL((msd_fft_rows_power_kernel<A, B>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,     \
+                       Pfull, accumulate)
+        if (sh.r1 == 64 && sh.r2 == 512) {
+            MDX_MSDFFT_SMALL(64, 512);
+        } else if (sh.r1 == 64) {
+            MDX_MSDFFT_SMALL(64, 1024);
+        } else if (sh.r2 == 512) {
+            MDX_MSDFFT_SMALL(16, 512);
         } else {
-            hipLaunchKernelGGL((msd_fft_cols64_kernel<1024>), ga, dim3(THREADS), 0, stream, pos, n_total,
-                               first, n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y);
-            hipLaunchKernelGGL((msd_fft_rows_power_kernel<64, 1024>), gb, dim3(THREADS), 0, stream, Y, p_pad,
-                               tw_r2, Pfull, accumulate);
+            MDX_MSDFFT_SMALL(16, 1024);
         }
+#undef MDX_MSDFFT_SMALL
     } else if (sh.r1 == 512 && sh.r2 == 512) {
         MDX_MSDFFT_LAUNCH(512, 512);
     } else if (sh.r1 == 1024 && sh.r2 == 512) {
@@ -480,8 +524,9 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
 inline void launch_fold(const Shape &sh, hipStream_t stream, const double *Pfull, int n_blocks,
                         int64_t nc, double *P)
 {
+    const int n_parts = rows_parts(sh, n_blocks);
     hipLaunchKernelGGL(msd_power_fold_kernel, dim3((unsigned)((nc + 255) / 256), (unsigned)n_blocks),
-                       dim3(256), 0, stream, Pfull, sh.r1, sh.r2, nc, P);
+                       dim3(256), 0, stream, Pfull, sh.r1, sh.r2, n_parts, nc, P);
 }
 
 }  // namespace msdfft
