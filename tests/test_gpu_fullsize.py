@@ -146,3 +146,22 @@ def test_c5_size_cell_path_equals_filter_path():
     eng.accumulate(sub, None, dims)
     assert np.array_equal(eng.counts(), ref)
     eng.close()
+
+
+@pytest.mark.parametrize("n", [400_000, 1_000_000])
+def test_beyond_c5_cell_path_equals_filter_path(n):
+    """Far past the BASELINE sizes (10^6 particles: 10^12 ordered pairs in one frame, 7 813 tiles):
+    the cell-sorted culled kernel and the brute-force float32-filter tiles bin the same counts."""
+    rng = np.random.default_rng(6)
+    L = np.float32((n / 0.1) ** (1 / 3))
+    pos = (rng.random((1, n, 3)) * L).astype(np.float32)
+    dims = np.array([L, L, L, 90, 90, 90], dtype=np.float32)
+    edges = np.linspace(0.0, 15.0, 202)
+    out = {}
+    for algo in ("auto", "filter"):
+        eng = _core.RdfEngine(edges, (1, 1), algo=algo)
+        eng.accumulate(pos, None, dims)
+        out[algo] = eng.counts()
+        eng.close()
+    assert np.array_equal(out["auto"], out["filter"])
+    assert abs(out["auto"].sum() / n - 1413.7) < 10
