@@ -311,6 +311,14 @@ int mdx_msd_set_grouping(mdx_msd_t h, int64_t n_molecules, const int64_t *offset
 int mdx_msd_system_com_traj(mdx_msd_t h, mdx_traj_t traj, const int64_t *frames, int64_t n_frames,
                             const int32_t *index, int64_t n_index, const double *masses, int unwrap,
                             const double *dims, int wrap, double *out);
+/* The same frame preparation for frames in host memory (an in-memory trajectory): pos
+ * float32[n_frames][n_sel][3] holds the selection, already gathered, in analysis order (rows sorted
+ * molecule by molecule when mdx_msd_set_grouping is active); arguments otherwise as for
+ * mdx_msd_push_traj / mdx_msd_system_com_traj. */
+int mdx_msd_push_f32(mdx_msd_t h, int group, const float *pos, int64_t n_frames, int64_t n_sel,
+                     int unwrap, const double *dims, int zero_dims, const double *shift);
+int mdx_msd_system_com_f32(mdx_msd_t h, const float *pos, int64_t n_frames, int64_t n_sel,
+                           const double *masses, int unwrap, const double *dims, int wrap, double *out);
 
 #ifdef __cplusplus
 }

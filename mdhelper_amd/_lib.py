@@ -116,6 +116,8 @@ _SIGNATURES = {
     "mdx_sq_accumulate_traj": (c_int, [_vp, _vp, _vp, c_int64, _vp, c_int64]),
     "mdx_isf_accumulate_traj": (c_int, [_vp, _vp, _vp, c_int64, _vp, c_int64]),
     "mdx_msd_push_traj": (c_int, [_vp, c_int, _vp, _vp, c_int64, _vp, c_int64, c_int, _vp, c_int, _vp]),
+    "mdx_msd_push_f32": (c_int, [_vp, c_int, _vp, c_int64, c_int64, c_int, _vp, c_int, _vp]),
+    "mdx_msd_system_com_f32": (c_int, [_vp, _vp, c_int64, c_int64, _vp, c_int, _vp, c_int, _vp]),
     "mdx_msd_set_grouping": (c_int, [_vp, c_int64, _vp, _vp]),
     "mdx_msd_result_acf": (c_int, [_vp, _vp]),
     "mdx_msd_system_com_traj": (c_int, [_vp, _vp, _vp, c_int64, _vp, c_int64, _vp, c_int, _vp, c_int, _vp]),

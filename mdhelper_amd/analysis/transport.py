@@ -349,20 +349,34 @@ class Onsager(SerialAnalysisBase):
                 # frames stream file -> pinned memory -> HBM; unwrapping and the float64
                 # widening happen on the device (mdx_msd_push_traj)
                 numbers = self._frame_numbers()[:self._n_frames]
-                native = self._trajectory.native
+                native = getattr(self._trajectory, "native", None)
                 unwrap_dims = self._dimensions if self._unwrap else None
+                if native is not None:
+                    def system_com(rows, masses, **kw):
+                        return eng.system_com_traj(native, numbers, rows, masses, **kw)
+
+                    def push(g, rows, **kw):
+                        eng.push_traj(g, native, numbers, rows, **kw)
+                else:
+                    # in-memory float32 frames: the same device stages, fed from host memory
+                    block = self._trajectory.frame_block(numbers)
+
+                    def system_com(rows, masses, **kw):
+                        return eng.system_com_f32(block if rows is None else block[:, rows], masses, **kw)
+
+                    def push(g, rows, **kw):
+                        eng.push_f32(g, block[:, rows], **kw)
                 shift = None
                 if self._center:
                     # system centre of mass per frame (reference :993-1014), every rank the same
                     wrap_dims = self._dimensions if self._center_wrap else None
                     if self._center_atom:
-                        shift = eng.system_com_traj(native, numbers, None, self.universe.atoms.masses,
-                                                    unwrap_dims=unwrap_dims, wrap_dims=wrap_dims)
+                        shift = system_com(None, self.universe.atoms.masses,
+                                           unwrap_dims=unwrap_dims, wrap_dims=wrap_dims)
                     else:
-                        shift = eng.system_com_traj(
-                            native, numbers, np.concatenate([g.indices for g in self._groups]),
-                            np.concatenate([g.masses for g in self._groups]),
-                            unwrap_dims=unwrap_dims, wrap_dims=wrap_dims)
+                        shift = system_com(np.concatenate([g.indices for g in self._groups]),
+                                           np.concatenate([g.masses for g in self._groups]),
+                                           unwrap_dims=unwrap_dims, wrap_dims=wrap_dims)
                 from .structure import RadialDistributionFunction
                 for g, (grp, gr, (lo, hi)) in enumerate(zip(self._groups, self._groupings, self._own)):
                     if hi <= lo:
@@ -376,8 +390,7 @@ class Onsager(SerialAnalysisBase):
                         idx, off, m = RadialDistributionFunction._selection(grp, gr)
                         eng.set_grouping(off[lo:hi + 1] - off[lo], m[off[lo]:off[hi]])
                         rows = idx[off[lo]:off[hi]]
-                    eng.push_traj(g, native, numbers, rows, unwrap_dims=unwrap_dims,
-                                  zero_dims=zero_mask, shift=shift)
+                    push(g, rows, unwrap_dims=unwrap_dims, zero_dims=zero_mask, shift=shift)
             for g, own in enumerate(self._own_slices):
                 if own.stop > own.start and not self._from_file:
                     eng.push(g, self._positions, own.start, own.stop - own.start, zero_mask)
@@ -433,7 +446,14 @@ class Onsager(SerialAnalysisBase):
         # the *centres* for the system centre of mass, center_wrap without center_atom, is the
         # one combination left to the per-frame path.)
         on_device = atoms_only or not (self._center and self._center_wrap and not self._center_atom)
-        self._from_file = bool(on_device and self._fft and getattr(traj, "native", None) is not None)
+        native = getattr(traj, "native", None) is not None
+        # ... and in-memory float32 frames (what an MDAnalysis reader delivers) take the same device
+        # stages whenever there is something to prepare
+        stored = getattr(traj, "_positions", None)
+        f32_array = (not native and hasattr(traj, "frame_block") and stored is not None
+                     and stored.dtype == np.float32
+                     and (self._unwrap or self._center or not atoms_only))
+        self._from_file = bool(on_device and self._fft and (native or f32_array))
         fast = hasattr(traj, "frame_block") and (self._from_file or (
             atoms_only and not (self._unwrap or self._center)))
         if not fast:

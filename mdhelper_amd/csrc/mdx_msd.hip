@@ -450,24 +450,69 @@ __global__ __launch_bounds__(256) void msd_frame_com_kernel(const double *__rest
 
 // System centre of mass of every listed frame (transport.py:993-1014), positions unwrapped first
 // when requested — the state walk needs every listed particle, so the frames are staged whole.
-static int msd_system_com_traj(mdx_msd *h, Trajectory *t, const int64_t *frames, int64_t n_frames,
-                               const int32_t *index, int64_t n_sel, const double *masses, int unwrap,
-                               const double *dims, int wrap, double *out)
-{
-    std::vector<int32_t> iota;
-    if (!index) {
-        iota.resize(size_t(n_sel));
-        for (int64_t i = 0; i < n_sel; ++i)
-            iota[size_t(i)] = (int32_t)i;
-        index = iota.data();
+// Where the float32 frames of the frame-preparation path come from: rows [a0, a0 + c) of the
+// selection for frames [f0, f0 + nf) of the analysed series -> d_out float32[nf][c][3], queued on
+// the engine's stream.
+struct FrameSource {
+    virtual ~FrameSource() = default;
+    virtual int prepare(mdx_msd *h, int64_t n_sel) = 0;
+    virtual int stage(mdx_msd *h, int64_t a0, int64_t c, int64_t f0, int64_t nf, float *d_out) = 0;
+};
+
+// a trajectory file: listed frames, listed particles (gathered by the unpack kernel)
+struct TrajFrames final : FrameSource {
+    Trajectory *t;
+    const int64_t *frames;
+    const int32_t *index;
+    TrajFrames(Trajectory *t_, const int64_t *f, const int32_t *i) : t(t_), frames(f), index(i) {}
+    int prepare(mdx_msd *h, int64_t n_sel) override
+    {
+        std::vector<int32_t> iota;
+        if (!index) {
+            iota.resize(size_t(n_sel));
+            for (int64_t i = 0; i < n_sel; ++i)
+                iota[size_t(i)] = (int32_t)i;
+        }
+        MDX_HIP(hipStreamSynchronize(h->stream));
+        MDX_TRY(h->d_index.ensure(size_t(4) * n_sel));
+        MDX_HIP(hipMemcpy(h->d_index.ptr, index ? index : iota.data(), size_t(4) * n_sel,
+                          hipMemcpyHostToDevice));
+        return MDX_OK;
     }
+    int stage(mdx_msd *h, int64_t a0, int64_t c, int64_t f0, int64_t nf, float *d_out) override
+    {
+        TrajSelection sel{h->d_index.as<int>() + a0, c, d_out};
+        return t->stage_async(h->dev, h->stream, frames + f0, nf, &sel, 1);
+    }
+};
+
+// host memory: float32[n_frames][n_sel][3], the selection already gathered by the caller
+struct HostFrames final : FrameSource {
+    const float *pos;
+    int64_t n_sel;
+    HostFrames(const float *p, int64_t n) : pos(p), n_sel(n) {}
+    int prepare(mdx_msd *h, int64_t) override
+    {
+        MDX_HIP(hipStreamSynchronize(h->stream));
+        return MDX_OK;
+    }
+    int stage(mdx_msd *h, int64_t a0, int64_t c, int64_t f0, int64_t nf, float *d_out) override
+    {
+        MDX_HIP(hipMemcpy2DAsync(d_out, size_t(12) * c, pos + (f0 * n_sel + a0) * 3, size_t(12) * n_sel,
+                                 size_t(12) * c, (size_t)nf, hipMemcpyHostToDevice, h->stream));
+        return MDX_OK;
+    }
+};
+
+static int msd_system_com_frames(mdx_msd *h, FrameSource &src, int64_t n_frames, int64_t n_sel,
+                                 const double *masses, int unwrap, const double *dims, int wrap,
+                                 double *out)
+{
     double total = 0.0;
     for (int64_t i = 0; i < n_sel; ++i)
         total += masses[i];
     MDX_REQUIRE(total > 0.0, "the selection has no mass");
-    MDX_HIP(hipStreamSynchronize(h->stream));
-    MDX_TRY(h->d_index.ensure(size_t(4) * n_sel));
-    MDX_HIP(hipMemcpy(h->d_index.ptr, index, size_t(4) * n_sel, hipMemcpyHostToDevice));
+    MDX_TRY(src.prepare(h, n_sel));
     MDX_TRY(h->d_masses.ensure(size_t(8) * n_sel));
     MDX_HIP(hipMemcpy(h->d_masses.ptr, masses, size_t(8) * n_sel, hipMemcpyHostToDevice));
     MDX_TRY(h->d_prev.ensure(size_t(n_sel) * 12));
@@ -478,8 +523,7 @@ static int msd_system_com_traj(mdx_msd *h, Trajectory *t, const int64_t *frames,
     MDX_TRY(h->d_shift.ensure(size_t(24) * n_frames));
     for (int64_t f0 = 0; f0 < n_frames; f0 += block) {
         const int64_t nf = std::min(block, n_frames - f0);
-        TrajSelection sel{h->d_index.as<int>(), n_sel, h->d_f32.as<float>()};
-        MDX_TRY(t->stage_async(h->dev, h->stream, frames + f0, nf, &sel, 1));
+        MDX_TRY(src.stage(h, 0, n_sel, f0, nf, h->d_f32.as<float>()));
         hipLaunchKernelGGL(msd_unwrap_widen_kernel, dim3((unsigned)ceil_div(3 * n_sel, 256)), dim3(256),
                            0, h->stream, h->d_f32.as<float>(), 3 * n_sel, nf, f0 == 0 ? 1 : 0, unwrap,
                            dims ? dims[0] : 0.0, dims ? dims[1] : 0.0, dims ? dims[2] : 0.0,
@@ -522,9 +566,8 @@ __global__ __launch_bounds__(256) void msd_molecule_com_kernel(
 }
 
 // The first n_blocks * t_block listed frames of a trajectory file -> one group of the engine.
-static int msd_push_traj(mdx_msd *h, int group, Trajectory *t, const int64_t *frames,
-                         const int32_t *index, int64_t n_sel, int unwrap, const double *dims,
-                         int zero_dims, const double *shift)
+static int msd_push_frames(mdx_msd *h, int group, FrameSource &src, int64_t n_sel, int unwrap,
+                           const double *dims, int zero_dims, const double *shift)
 {
     const int64_t T = int64_t(h->n_blocks) * h->t_block;
     const bool molecules = !h->mol_offsets.empty();
@@ -557,16 +600,7 @@ static int msd_push_traj(mdx_msd *h, int group, Trajectory *t, const int64_t *fr
             cuts.push_back(a0);
         cuts.push_back(n_sel);
     }
-    std::vector<int32_t> iota;
-    if (!index) {
-        iota.resize(size_t(n_sel));
-        for (int64_t i = 0; i < n_sel; ++i)
-            iota[size_t(i)] = (int32_t)i;
-        index = iota.data();
-    }
-    MDX_HIP(hipStreamSynchronize(h->stream));
-    MDX_TRY(h->d_index.ensure(size_t(4) * n_sel));
-    MDX_HIP(hipMemcpy(h->d_index.ptr, index, size_t(4) * n_sel, hipMemcpyHostToDevice));
+    MDX_TRY(src.prepare(h, n_sel));
     MDX_TRY(h->d_stage.ensure(size_t(T) * chunk * 24));
     MDX_TRY(h->d_prev.ensure(size_t(chunk) * 12));
     MDX_TRY(h->d_image.ensure(size_t(chunk) * 12));
@@ -586,8 +620,7 @@ static int msd_push_traj(mdx_msd *h, int group, Trajectory *t, const int64_t *fr
             continue;
         for (int64_t f0 = 0; f0 < T; f0 += block) {
             const int64_t nf = std::min(block, T - f0);
-            TrajSelection sel{h->d_index.as<int>() + a0, c, h->d_f32.as<float>()};
-            MDX_TRY(t->stage_async(h->dev, h->stream, frames + f0, nf, &sel, 1));
+            MDX_TRY(src.stage(h, a0, c, f0, nf, h->d_f32.as<float>()));
             hipLaunchKernelGGL(msd_unwrap_widen_kernel, dim3((unsigned)ceil_div(3 * c, 256)),
                                dim3(256), 0, h->stream, h->d_f32.as<float>(), 3 * c, nf,
                                f0 == 0 ? 1 : 0, unwrap, dims ? dims[0] : 0.0, dims ? dims[1] : 0.0,
@@ -837,7 +870,41 @@ int mdx_msd_system_com_traj(mdx_msd_t h, mdx_traj_t traj, const int64_t *frames,
                         (long long)t->n_atoms);
     if (n_frames == 0)
         return MDX_OK;
-    return msd_system_com_traj(h, t, frames, n_frames, index, n, masses, unwrap, dims, wrap, out);
+    TrajFrames src(t, frames, index);
+    return msd_system_com_frames(h, src, n_frames, n, masses, unwrap, dims, wrap, out);
+}
+
+int mdx_msd_system_com_f32(mdx_msd_t h, const float *pos, int64_t n_frames, int64_t n_sel,
+                           const double *masses, int unwrap, const double *dims, int wrap, double *out)
+{
+    MDX_REQUIRE(h && pos && masses && out, "NULL argument");
+    MDX_REQUIRE(n_frames >= 0 && n_sel > 0, "bad size");
+    MDX_REQUIRE((!unwrap && !wrap) || (dims && dims[0] > 0 && dims[1] > 0 && dims[2] > 0),
+                "unwrapping / wrapping needs positive box dimensions");
+    MDX_TRY(set_device(h->dev));
+    if (n_frames == 0)
+        return MDX_OK;
+    HostFrames src(pos, n_sel);
+    return msd_system_com_frames(h, src, n_frames, n_sel, masses, unwrap, dims, wrap, out);
+}
+
+int mdx_msd_push_f32(mdx_msd_t h, int group, const float *pos, int64_t n_frames, int64_t n_sel,
+                     int unwrap, const double *dims, int zero_dims, const double *shift)
+{
+    MDX_REQUIRE(h && pos, "NULL argument");
+    MDX_REQUIRE(group >= 0 && group < h->n_groups, "group %d out of range", group);
+    MDX_REQUIRE(zero_dims >= 0 && zero_dims < 8, "zero_dims is a 3-bit mask");
+    const int64_t T = int64_t(h->n_blocks) * h->t_block;
+    MDX_REQUIRE(n_frames >= T, "%lld frames given, the engine needs %lld", (long long)n_frames,
+                (long long)T);
+    MDX_REQUIRE(!unwrap || (dims && dims[0] > 0 && dims[1] > 0 && dims[2] > 0),
+                "unwrapping needs positive box dimensions");
+    MDX_REQUIRE(n_sel >= 0, "negative particle count");
+    MDX_TRY(set_device(h->dev));
+    if (n_sel == 0)
+        return MDX_OK;
+    HostFrames src(pos, n_sel);
+    return msd_push_frames(h, group, src, n_sel, unwrap, dims, zero_dims, shift);
 }
 
 int mdx_msd_push_traj(mdx_msd_t h, int group, mdx_traj_t traj, const int64_t *frames,
@@ -862,7 +929,8 @@ int mdx_msd_push_traj(mdx_msd_t h, int group, mdx_traj_t traj, const int64_t *fr
         if (index[i] < 0 || index[i] >= t->n_atoms)
             return fail(MDX_ERR_INVALID_VALUE, "particle index %d out of range [0, %lld)", index[i],
                         (long long)t->n_atoms);
-    return msd_push_traj(h, group, t, frames, index, n, unwrap, dims, zero_dims, shift);
+    TrajFrames src(t, frames, index);
+    return msd_push_frames(h, group, src, n, unwrap, dims, zero_dims, shift);
 }
 
 static int msd_result(mdx_msd_t h, double *msd_self_sum, double *acf_sum, double *sum_traj);

@@ -14,7 +14,7 @@ from mdhelper_amd import _core  # noqa: E402
 from mdhelper_amd.analysis import RadialDistributionFunction  # noqa: E402
 from mdhelper_amd.io import TrajectoryFile  # noqa: E402
 from oracle import rdf as orf  # noqa: E402
-from trajfiles import write_amber_netcdf, write_dcd  # noqa: E402
+from trajfiles import per_frame, write_amber_netcdf, write_dcd  # noqa: E402
 
 
 def _frames(F, N, L, seed):
@@ -137,9 +137,13 @@ def test_onsager_from_file_with_device_unwrap(tmp_path, kind):
         warnings.simplefilter("ignore")
         a = Onsager([uf.select(cat), uf.select(an)], temperature=300, n_blocks=3, unwrap=True,
                     verbose=False).run()
-        b = Onsager([um.select(cat), um.select(an)], temperature=300, n_blocks=3, unwrap=True,
-                    verbose=False).run()
-    assert a._from_file and not b._from_file
+        b = per_frame(Onsager([um.select(cat), um.select(an)], temperature=300, n_blocks=3, unwrap=True,
+                              verbose=False)).run()
+        c = Onsager([um.select(cat), um.select(an)], temperature=300, n_blocks=3, unwrap=True,
+                    verbose=False).run()          # in-memory float32 frames, same device stages
+    assert a._from_file and c._from_file and not b._from_file
+    assert np.allclose(c.results.msd_self, b.results.msd_self, rtol=1e-9,
+                       atol=1e-9 * np.abs(b.results.msd_self).max())
     assert a.results.msd_self.shape == (2, 3, 133)
     scale = np.abs(b.results.msd_self).max()
     assert np.allclose(a.results.msd_self, b.results.msd_self, rtol=1e-9, atol=1e-9 * scale)
@@ -183,9 +187,12 @@ def test_onsager_center_from_file_on_device(tmp_path, mode):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         a = Onsager([uf.select(cat), uf.select(an)], **kw).run()
-        b = Onsager([um.select(cat), um.select(an)], **kw).run()
-        plain = Onsager([um.select(cat), um.select(an)], **{**kw, "center": False}).run()
-    assert a._from_file and not b._from_file
+        b = per_frame(Onsager([um.select(cat), um.select(an)], **kw)).run()
+        c = Onsager([um.select(cat), um.select(an)], **kw).run()
+        plain = per_frame(Onsager([um.select(cat), um.select(an)], **{**kw, "center": False})).run()
+    assert a._from_file and c._from_file and not b._from_file
+    assert np.allclose(c.results.msd_cross, b.results.msd_cross, rtol=1e-8,
+                       atol=1e-8 * np.abs(b.results.msd_cross).max())
     for name in ("msd_self", "msd_cross"):
         x, y = getattr(a.results, name), getattr(b.results, name)
         assert np.allclose(x, y, rtol=1e-8, atol=1e-8 * np.abs(y).max()), name
@@ -236,8 +243,12 @@ def test_onsager_molecule_groupings_from_file_on_device(tmp_path, mode):
         ga, gra = groups(uf)
         a = Onsager(ga, gra, **kw).run()
         gb, grb = groups(um)
-        b = Onsager(gb, grb, **kw).run()
-    assert a._from_file and not b._from_file
+        b = per_frame(Onsager(gb, grb, **kw)).run()
+        c = Onsager(gb, grb, **kw).run()
+    assert a._from_file and c._from_file and not b._from_file
+    for name in ("msd_self", "msd_cross"):
+        x, y = getattr(c.results, name), getattr(b.results, name)
+        assert np.allclose(x, y, rtol=1e-8, atol=1e-8 * np.abs(y).max()), name
     assert a.results.msd_self.shape == b.results.msd_self.shape
     for name in ("msd_self", "msd_cross"):
         x, y = getattr(a.results, name), getattr(b.results, name)

@@ -79,3 +79,29 @@ def write_dcd(path, positions, unitcell=None, *, big_endian=False, istart=0, nsa
             for k in range(3):
                 plane = positions[f, :, k].astype(e + "f4").tobytes()
                 fh.write(struct.pack(e + "i", 4 * N) + plane + struct.pack(e + "i", 4 * N))
+
+
+class PerFrameTrajectory:
+    """Wraps an in-memory trajectory and hides its block interface, so that an analysis takes the
+    generic frame-by-frame protocol (host NumPy frame preparation): the reference for the batched
+    and device-prepared paths."""
+
+    def __init__(self, traj):
+        self._traj = traj
+
+    def __getattr__(self, name):
+        if name in ("frame_block", "box_block", "native", "_positions"):
+            raise AttributeError(name)
+        return getattr(self._traj, name)
+
+    def __getitem__(self, item):
+        return self._traj[item]
+
+    def __len__(self):
+        return len(self._traj)
+
+
+def per_frame(analysis):
+    """Route an analysis object built on an in-memory universe through the per-frame protocol."""
+    analysis._trajectory = PerFrameTrajectory(analysis._trajectory)
+    return analysis
