@@ -1,0 +1,55 @@
+"""Randomised check of the MSD engine against the scipy-FFT restatement (test infrastructure):
+random block lengths around every transform-shape boundary, block counts, particle counts,
+zeroed dimensions, two groups.    python scripts/msd_fuzz.py [seconds] [seed]"""
+import sys
+import time
+
+sys.path.insert(0, ".")
+import numpy as np
+
+from mdhelper_amd import _core
+from oracle import correlation as oc
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+t_end = time.time() + budget
+cases = bad = 0
+edges = [2, 3, 17, 1000, 2047, 2048, 2049, 2050, 4095, 4096, 4097, 8191, 8192, 8193, 16383, 16384, 16385,
+         32767, 32768, 32769, 40000, 65536, 65537]
+while time.time() < t_end:
+    cases += 1
+    t_block = int(rng.choice(edges)) if rng.random() < 0.6 else int(rng.integers(2, 70000))
+    n_blocks = int(rng.integers(1, 5))
+    n_atoms = int(rng.integers(1, 24))
+    zero_dims = int(rng.choice([0, 0, 1, 2, 4, 5]))
+    T = t_block * n_blocks + int(rng.integers(0, 3))
+    pos = rng.uniform(0, 50, (1, n_atoms, 3)) + np.cumsum(rng.normal(0, 0.3, (T, n_atoms, 3)), axis=0)
+    eng = _core.MsdEngine(t_block, n_blocks, 2)
+    first = int(rng.integers(0, n_atoms))
+    eng.push(0, pos, 0, n_atoms, zero_dims)
+    eng.push(1, pos, first, n_atoms - first, zero_dims)
+    msd, traj = eng.result()
+    acf = eng.result_acf()
+    n_fft = eng.n_fft
+    eng.close()
+    p = pos[:t_block * n_blocks].reshape(n_blocks, t_block, n_atoms, 3).copy()
+    for k in range(3):
+        if (zero_dims >> k) & 1:
+            p[..., k] = 0
+    ok = True
+    for g, sl in enumerate((slice(0, n_atoms), slice(first, n_atoms))):
+        ref = oc.msd_fft_ref(p[:, :, sl], axis=1, average=False).sum(axis=-1)
+        scale = max(np.abs(ref).max(), 1e-300)
+        ok &= np.allclose(msd[g], ref, rtol=1e-7, atol=1e-9 * scale)
+        ok &= np.allclose(traj[g], p[:, :, sl].sum(axis=2), rtol=1e-12, atol=1e-9)
+        a_ref = oc.correlation_fft_ref(p[:, :, sl], axis=1, vector=True).sum(axis=-1) * (t_block - np.arange(t_block))
+        ok &= np.allclose(acf[g], a_ref, rtol=1e-9, atol=1e-9 * max(np.abs(a_ref).max(), 1e-300))
+    if not ok:
+        bad += 1
+        print(f"MISMATCH case {cases} seed {seed}: t_block={t_block} n_blocks={n_blocks} n_atoms={n_atoms} "
+              f"zero_dims={zero_dims} first={first} n_fft={n_fft}", flush=True)
+    if cases % 50 == 0:
+        print(f"{cases} cases, {bad} mismatches", flush=True)
+print(f"done: {cases} cases, {bad} mismatches (seed {seed})", flush=True)
+sys.exit(1 if bad else 0)
