@@ -17,8 +17,9 @@
  *     is not thread-safe (one handle per device per host thread);
  *   - positions are float32[n_frames][n][3] (MDAnalysis' native layout),
  *     boxes float32[n_frames][6] = (lx, ly, lz, alpha, beta, gamma), or NULL
- *     for no periodic boundaries.  Non-orthorhombic boxes are rejected with
- *     MDX_ERR_UNSUPPORTED rather than silently mis-binned.
+ *     for no periodic boundaries.  Orthorhombic and triclinic cells are both
+ *     handled by the RDF (a batch may mix them); the Fourier-space engines take
+ *     positions only.
  */
 #ifndef MDX_H
 #define MDX_H
@@ -110,15 +111,15 @@ int mdx_rdf_reset(mdx_rdf_t h);
  * bit-identical because the contract arithmetic is exactly antisymmetric. */
 int mdx_rdf_accumulate(mdx_rdf_t h, const float *pos1, int64_t n1, const float *pos2,
                        int64_t n2, const float *boxes, int64_t n_frames);
+/* 2-D mode, RadialDistributionFunction(drop_axis=...) (structure.py:761-770): coordinate `axis`
+ * (0, 1, 2; -1 switches the mode off) of both sets is set to zero after the centre-of-mass stage
+ * and the cell length along it becomes max(lx, ly, lz), on the device, for every entry point. */
+int mdx_rdf_set_drop_axis(mdx_rdf_t h, int axis);
 /* Centres of mass on the device for groupings="residues"/"segments" (structure.py:753-759 via
  * algorithm/molecule.py:300-306): the rows of set `which` (1 or 2) handed to any accumulate
  * call are then PARTICLES, molecule g owning rows [offsets[g], offsets[g+1]); the histogram is
  * taken over the float32 centres sum_a m_a x_a / M_g.  offsets: int64[n_groups+1], masses:
  * float64[offsets[n_groups]], both on the host; n_groups <= 0 removes the grouping. */
-/* 2-D mode, RadialDistributionFunction(drop_axis=...) (structure.py:761-770): coordinate `axis`
- * (0, 1, 2; -1 switches the mode off) of both sets is set to zero after the centre-of-mass stage
- * and the cell length along it becomes max(lx, ly, lz), on the device, for every entry point. */
-int mdx_rdf_set_drop_axis(mdx_rdf_t h, int axis);
 int mdx_rdf_set_grouping(mdx_rdf_t h, int which, int64_t n_groups, const int64_t *offsets,
                          const double *masses);
 /* Same, all pointers in HBM (from mdx_malloc); asynchronous on the handle's stream. */
