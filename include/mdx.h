@@ -216,8 +216,11 @@ int mdx_isf_enable_timing(mdx_isf_t h, int on);
  * Onsager._conclude (src/mdhelper/analysis/transport.py:1016-1059). */
 typedef struct mdx_msd *mdx_msd_t;
 
-/* One engine per (n_frames_block, n_blocks): plans a batched rocFFT R2C/C2R of
- * length n_fft = 2*next_fast_len(n_frames_block) (correlation.py:176-178). */
+/* One engine per (n_frames_block, n_blocks).  The transform length n_fft >= 2 n_frames_block - 1
+ * (any such length gives the same linear correlation; the reference pads to
+ * 2*next_fast_len(n_frames_block), correlation.py:176-178): a power of two served by the
+ * engine's own two-pass kernels for blocks of 2 049 .. 524 288 frames, else the reference
+ * length or the next power of two through rocFFT (mdx_msd_n_fft reports it). */
 int mdx_msd_create(mdx_msd_t *out, int dev, int64_t n_frames_block, int n_blocks,
                    int n_groups);
 int mdx_msd_destroy(mdx_msd_t h);
