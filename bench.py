@@ -469,6 +469,7 @@ def bench_msd(args, world):
     try:   # PMC pass of the same workload (scripts/profile_pmc.sh), per step
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
             if N == 10000 and T == 100000 and eng.n_fft == 262144 and not os.environ.get("MDX_MSD_ROCFFT"):
+                # (measured for the 2^18 transform, MDX_MSD_NFFT=pow2; not re-measured for 204 800)
                 traffic = json.load(fh)["msd_c4_step"]["hbm_bytes_per_step"]
     except (OSError, KeyError, ValueError):
         pass
@@ -478,8 +479,8 @@ def bench_msd(args, world):
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"C4 self-MSD {N} atoms x {T} frames, 2 groups, n_blocks={B}, n_fft={eng.n_fft}"
-                               + (" (own two-pass transform)" if eng.n_fft in (1 << 13, 1 << 14, 1 << 15, 1 << 16, 1 << 18,
-                                                                                  1 << 19, 1 << 20)
+                               + (" (own two-pass transform)" if eng.n_fft in (1 << 13, 1 << 14, 1 << 15, 1 << 16, 204800,
+                                                                                  1 << 18, 1 << 19, 1 << 20)
                                   and not os.environ.get("MDX_MSD_ROCFFT") else " (rocFFT)")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

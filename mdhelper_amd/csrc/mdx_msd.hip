@@ -339,7 +339,7 @@ static int msd_push_device(mdx_msd *h, int group, const double *d_pos, int64_t n
                            d_pos, n_total, first + a0, c, zero_dims, h->traj(group), h->dsq(group));
         if (h->own_fft) {
             // tables: half table of W_R1, half table of W_R2, W_N^m for m < R2
-            const double2 *tw_r1 = h->d_tw.as<double2>(), *tw_r2 = tw_r1 + h->shape.r1 / 2,
+            const double2 *tw_r1 = h->d_tw.as<double2>(), *tw_r2 = tw_r1 + msdfft::tw_r1_len(h->shape.r1),
                           *twN = tw_r2 + h->shape.r2 / 2;
             // Batches of `sub` particles whose half-transformed block Y (written by pass A, read
             // once by pass B) fits the 256 MB memory-side cache: pass B then reads it from there,
@@ -688,6 +688,10 @@ int mdx_msd_create(mdx_msd_t *out, int dev, int64_t n_frames_block, int n_blocks
         // is served by 2^18
         if (!getenv("MDX_MSD_ROCFFT") && n_frames_block > 2048)
             own_len = p <= (int64_t(1) << 16) ? p : std::max<int64_t>(p, int64_t(1) << 18);
+        // ... and 204 800 = 400 x 512 (16 x 5 x 5 first factor) where it covers the block and is
+        // shorter than the power of two: 32 769 .. 102 400 frames (MDX_MSD_NFFT=pow2 keeps 2^18)
+        if (own_len == (int64_t(1) << 18) && 2 * n_frames_block <= 204800 && !force_pow2)
+            own_len = 204800;
         if (own_len && msdfft::shape_for(own_len).r1 && !force_ref)
             h->n_fft = own_len;
         else if (force_pow2 || (!force_ref && 2 * p <= 3 * h->n_fft))
@@ -718,7 +722,7 @@ int mdx_msd_create(mdx_msd_t *out, int dev, int64_t n_frames_block, int n_blocks
                     tw.push_back(-std::sin(two_pi * m / period));
                 }
             };
-            push(r1 / 2, r1);
+            push(msdfft::tw_r1_len(r1), r1);   // half table; the whole one for 400 points
             push(r2 / 2, r2);
             push(r2, (double)h->n_fft);
             if ((rc = h->d_tw.ensure(tw.size() * 8)) != MDX_OK) break;

@@ -179,6 +179,70 @@ __device__ __forceinline__ void stockham_stage_batch(double2 *z, int zs, const d
     wave_lds_fence();
 }
 
+// forward 5-point transform, natural order in and out
+__device__ __forceinline__ void dft5(double2 *a)
+{
+    const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;   // cos(2 pi/5), cos(4 pi/5)
+    const double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;    // sin(2 pi/5), sin(4 pi/5)
+    const double2 t1 = cadd(a[1], a[4]), t2 = cadd(a[2], a[3]);
+    const double2 d1 = csub(a[1], a[4]), d2 = csub(a[2], a[3]);
+    const double2 a0 = a[0];
+    const double2 m1 = make_double2(a0.x + c1 * t1.x + c2 * t2.x, a0.y + c1 * t1.y + c2 * t2.y);
+    const double2 m2 = make_double2(a0.x + c2 * t1.x + c1 * t2.x, a0.y + c2 * t1.y + c1 * t2.y);
+    // -i (s1 d1 + s2 d2) and -i (s2 d1 - s1 d2)
+    const double2 u1 = make_double2(s1 * d1.y + s2 * d2.y, -(s1 * d1.x + s2 * d2.x));
+    const double2 u2 = make_double2(s2 * d1.y - s1 * d2.y, -(s2 * d1.x - s1 * d2.x));
+    a[0] = cadd(a0, cadd(t1, t2));
+    a[1] = cadd(m1, u1);
+    a[4] = csub(m1, u1);
+    a[2] = cadd(m2, u2);
+    a[3] = csub(m2, u2);
+}
+
+// One in-place Stockham stage for lengths that are not powers of two (M = 400 = 16 x 5 x 5):
+// M / RADIX butterflies dealt to the lanes in rounds, full twiddle table tw[m] = exp(-2 pi i m / M).
+template <int M, int RADIX, int NS, bool FIRST>
+__device__ __forceinline__ void stockham_stage_mixed(double2 *z, const double2 *tw, int lane, int n_live)
+{
+    constexpr int T = M / RADIX;             // butterflies
+    constexpr int PER = (T + 63) / 64;       // rounds
+    double2 v[PER][RADIX];
+#pragma unroll
+    for (int p = 0; p < PER; ++p) {
+        const int j = lane + 64 * p;
+        if (j < T) {
+            // k = j mod NS without a division where NS is a power of two or covers every j
+            const int k = NS >= T ? j : (NS & (NS - 1)) == 0 ? (j & (NS - 1)) : j % NS;
+            constexpr int STEP = M / (RADIX * NS);
+            constexpr bool WRAPS = (RADIX - 1) * (NS - 1) * STEP >= M;    // exponent can pass M
+#pragma unroll
+            for (int r = 0; r < RADIX; ++r) {
+                const int idx = j + r * T;
+                v[p][r] = (!FIRST || idx < n_live) ? z[idx] : make_double2(0.0, 0.0);
+                if (NS > 1 && r)   // W_(RADIX NS)^(r k)
+                    v[p][r] = cmul(v[p][r], tw[WRAPS ? (r * k * STEP) % M : r * k * STEP]);
+            }
+            if (RADIX == 5)
+                dft5(v[p]);
+            else
+                dft16(v[p]);
+        }
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int p = 0; p < PER; ++p) {
+        const int j = lane + 64 * p;
+        if (j < T) {
+            const int k = NS >= T ? j : (NS & (NS - 1)) == 0 ? (j & (NS - 1)) : j % NS;
+            const int j0 = (j - k) * RADIX + k;
+#pragma unroll
+            for (int r = 0; r < RADIX; ++r)
+                z[j0 + r * NS] = v[p][r];
+        }
+    }
+    wave_lds_fence();
+}
+
 // In-place forward M-point transform of z[0..M) (LDS) by one wave.  tw: exp(-2 pi i m / M),
 // m < M / 2, in LDS (global twiddle loads would share the vmcnt queue with the streaming loads
 // of the callers and make every transform wait for HBM).
@@ -264,6 +328,81 @@ __global__ __launch_bounds__(THREADS, R1 == 512 ? 4 : 2) void msd_fft_cols_kerne
         __syncthreads();
     }
 #undef MDX_COLS_LOAD
+}
+
+// Pass A for R1 = 400 = 16 x 5 x 5 (n_fft = 204 800 = 400 x 512: blocks of 32 769 .. 102 400 frames,
+// C4's 100 000 among them — 22 % less of the half-transformed block than 2^18).  As
+// msd_fft_cols_kernel, with guarded row / line loops (200 live rows, 400 lines are not multiples
+// of the 32 / 64 a thread steps by) and the full twiddle table of the 400-point transform.
+template <int R2>
+__global__ __launch_bounds__(THREADS, 2) void msd_fft_cols400_kernel(
+    const double *__restrict__ pos, int64_t n_total, int64_t first, int64_t n_elem, int64_t t_block,
+    int zero_dims, int p_pad, const double2 *__restrict__ tw_r1, const double2 *__restrict__ twN,
+    double2 *__restrict__ Y)
+{
+    constexpr int R1 = 400, ZS = R1 + 1, LIVE = R1 / 2;
+    constexpr int LOADS = (LIVE + 31) / 32;     // 7 row rounds
+    constexpr int OUTS = (R1 + 63) / 64;        // 7 line rounds
+    __shared__ double2 zb[PG][ZS];
+    __shared__ double2 s_h[R1];       // exp(-2 pi i m / 400), m < 400
+    __shared__ double2 s_n[R2];       // exp(-2 pi i m / N),  m < R2
+    const int pg = blockIdx.x, b = blockIdx.z;
+    const int n2_count = R2 / int(gridDim.y);
+    const int n2_begin = blockIdx.y * n2_count;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < R1; i += THREADS)
+        s_h[i] = tw_r1[i];
+    for (int i = tid; i < R2; i += THREADS)
+        s_n[i] = twN[i];
+
+    const int s = tid & 15, row0 = tid >> 4;
+    const int64_t e = int64_t(pg) * 16 + s;
+    const bool live = e < n_elem && !((zero_dims >> int(e % 3)) & 1);
+    const double *src = pos + (int64_t(b) * t_block * n_total + first) * 3 + e;
+    const int64_t row_stride = n_total * 3;
+    double *dst = reinterpret_cast<double *>(&zb[s >> 1][0]) + (s & 1);
+    const int p = tid & 7, kbase = tid >> 3;
+    double2 *out = Y + ((int64_t(b) * R1 * (p_pad / PG) + pg) * R2) * PG + p;
+    const int64_t k1_stride = int64_t(p_pad / PG) * R2 * PG;
+
+    double x[LOADS];
+#define MDX_COLS400_LOAD(N2)                                                        \
+    _Pragma("unroll") for (int i = 0; i < LOADS; ++i)                               \
+    {                                                                               \
+        const int n1 = row0 + 32 * i;                                               \
+        const int64_t t = int64_t(n1) * R2 + (N2);                                  \
+        x[i] = (live && n1 < LIVE && t < t_block) ? src[t * row_stride] : 0.0;      \
+    }
+    MDX_COLS400_LOAD(n2_begin)
+    __syncthreads();
+    for (int n2 = n2_begin; n2 < n2_begin + n2_count; ++n2) {
+#pragma unroll
+        for (int i = 0; i < LOADS; ++i)
+            if (row0 + 32 * i < LIVE)
+                dst[2 * (row0 + 32 * i)] = x[i];
+        __syncthreads();
+        {
+            const int nxt = min(n2 + 1, R2 - 1);   // the last column reloads itself
+            MDX_COLS400_LOAD(nxt)
+        }
+        stockham_stage_mixed<R1, 16, 1, true>(zb[wave], s_h, lane, LIVE);
+        stockham_stage_mixed<R1, 5, 16, false>(zb[wave], s_h, lane, R1);
+        stockham_stage_mixed<R1, 5, 80, false>(zb[wave], s_h, lane, R1);
+        __syncthreads();
+        double2 *o = out + int64_t(n2) * PG;
+#pragma unroll
+        for (int i = 0; i < OUTS; ++i) {
+            const int k1 = kbase + 64 * i;
+            if (k1 < R1) {
+                // W_N^(n2 k1) = W_R1^(m / R2) * W_N^(m mod R2), m = n2 k1 < N
+                const unsigned m = unsigned(k1) * unsigned(n2);
+                const double2 w = cmul(s_h[m / R2], s_n[m & (R2 - 1)]);
+                o[int64_t(k1) * k1_stride] = cmul(zb[p][k1], w);
+            }
+        }
+        __syncthreads();
+    }
+#undef MDX_COLS400_LOAD
 }
 
 // Pass A for short first factors, R1 = 64 (n_fft = 2^15, 2^16) and R1 = 16 (2^13, 2^14): a wave
@@ -431,11 +570,11 @@ __global__ __launch_bounds__(256) void msd_power_fold_kernel(const double *__res
     if (k >= nc)
         return;
     const int64_t n = int64_t(r1) * r2;
-    const int64_t km = (n - k) & (n - 1);
+    const int64_t km = (n - k) % n;
     double s = 0.0;
     for (int part = 0; part < n_parts; ++part) {
         const double *pf = Pfull + (int64_t(part) * gridDim.y + b) * n;
-        s += 0.5 * (pf[(k & (r1 - 1)) * r2 + k / r1] + pf[(km & (r1 - 1)) * r2 + km / r1]);
+        s += 0.5 * (pf[(k % r1) * r2 + k / r1] + pf[(km % r1) * r2 + km / r1]);
     }
     P[int64_t(b) * nc + k] += s;
 }
@@ -458,6 +597,8 @@ inline Shape shape_for(int64_t n_fft)
         s.r1 = 64, s.r2 = 512;
     else if (n_fft == (int64_t(1) << 16))
         s.r1 = 64, s.r2 = 1024;
+    else if (n_fft == 204800)
+        s.r1 = 400, s.r2 = 512;
     else if (n_fft == (int64_t(1) << 18))
         s.r1 = 512, s.r2 = 512;
     else if (n_fft == (int64_t(1) << 19))
@@ -467,12 +608,17 @@ inline Shape shape_for(int64_t n_fft)
     return s;
 }
 
-// Parts of pass B (blockIdx.z): R1 x blocks x parts >= 512 blocks; Pfull holds one copy per part.
+// entries of the first-factor twiddle table the kernels expect
+inline int tw_r1_len(int r1) { return r1 == 400 ? 400 : r1 / 2; }
+
+// Parts of pass B (blockIdx.z): R1 x blocks x parts >= 2048 blocks = four rounds of the 512 block
+// slots of the chip (with fewer, a block count that is not a multiple of 512 costs a whole extra
+// round: 800 blocks took as long as 1024); Pfull holds one copy per part.
 constexpr int ROWS_PARTS_MAX = 32;
 inline int rows_parts(const Shape &sh, int n_blocks)
 {
     int parts = 1;
-    while (int64_t(sh.r1) * n_blocks * parts < 512 && parts < ROWS_PARTS_MAX)
+    while (int64_t(sh.r1) * n_blocks * parts < 2048 && parts < ROWS_PARTS_MAX)
         parts *= 2;
     return parts;
 }
@@ -511,6 +657,11 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
             MDX_MSDFFT_SMALL(16, 1024);
         }
 #undef MDX_MSDFFT_SMALL
+    } else if (sh.r1 == 400) {
+        hipLaunchKernelGGL((msd_fft_cols400_kernel<512>), ga, dim3(THREADS), 0, stream, pos, n_total, first,
+                           n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y);
+        hipLaunchKernelGGL((msd_fft_rows_power_kernel<400, 512>), gb, dim3(THREADS), 0, stream, Y, p_pad,
+                           tw_r2, Pfull, accumulate);
     } else if (sh.r1 == 512 && sh.r2 == 512) {
         MDX_MSDFFT_LAUNCH(512, 512);
     } else if (sh.r1 == 1024 && sh.r2 == 512) {

@@ -493,10 +493,11 @@ def test_rdf_mixed_orthorhombic_and_triclinic_frames_in_one_batch():
                                   (140000, 1, 9, 0), (262144, 1, 6, 4), (150000, 2, 7, 0), (300000, 1, 5, 1),
                                   (524288, 1, 7, 0), (12500, 8, 30, 0), (8193, 3, 21, 2), (16384, 2, 40, 0),
                                   (16385, 5, 13, 4), (32768, 1, 19, 1), (25000, 4, 23, 0), (33000, 2, 11, 0),
-                                  (2049, 7, 50, 0), (4096, 1, 33, 2), (5000, 20, 16, 0), (8192, 2, 25, 1)])
+                                  (2049, 7, 50, 0), (4096, 1, 33, 2), (5000, 20, 16, 0), (8192, 2, 25, 1),
+                                  (100000, 1, 29, 0), (102400, 1, 8, 3), (102401, 1, 8, 0), (32769, 3, 17, 0)])
 def test_msd_own_two_pass_transform_equals_rocfft(case, monkeypatch):
-    """n_fft = 2^13 .. 2^16, 2^18, 2^19, 2^20: the engine's own packed two-pass transforms against
-    the rocFFT pipeline."""
+    """n_fft = 2^13 .. 2^16, 204 800, 2^18, 2^19, 2^20: the engine's own packed two-pass transforms
+    against the rocFFT pipeline."""
     t_block, n_blocks, n_atoms, zero_dims = case
     rng = np.random.default_rng(7)
     T = t_block * n_blocks
@@ -509,7 +510,8 @@ def test_msd_own_two_pass_transform_equals_rocfft(case, monkeypatch):
             monkeypatch.delenv("MDX_MSD_ROCFFT", raising=False)
         eng = _core.MsdEngine(t_block, n_blocks, 2)
         want = (8192 if t_block <= 4096 else 16384 if t_block <= 8192 else 32768 if t_block <= 16384
-                else 65536 if t_block <= 32768 else 262144 if t_block <= 131072
+                else 65536 if t_block <= 32768 else 204800 if t_block <= 102400
+                else 262144 if t_block <= 131072
                 else 524288 if t_block <= 262144 else 1048576)
         assert mode != "own" or eng.n_fft == want     # rocFFT runs its own choice of length
         eng.push(0, pos, 0, n_atoms, zero_dims)
