@@ -199,7 +199,18 @@ __device__ __forceinline__ void dft5(double2 *a)
     a[3] = csub(m2, u2);
 }
 
-// One in-place Stockham stage for lengths that are not powers of two (M = 400 = 16 x 5 x 5):
+// forward 4-point transform, natural order in and out
+__device__ __forceinline__ void dft4(double2 *a)
+{
+    const double2 t0 = cadd(a[0], a[2]), t1 = csub(a[0], a[2]);
+    const double2 t2 = cadd(a[1], a[3]), t3 = mul_mi(csub(a[1], a[3]));
+    a[0] = cadd(t0, t2);
+    a[1] = cadd(t1, t3);
+    a[2] = csub(t0, t2);
+    a[3] = csub(t1, t3);
+}
+
+// One in-place Stockham stage for lengths that are not powers of two (M = 400 = 4 x 4 x 5 x 5):
 // M / RADIX butterflies dealt to the lanes in rounds, full twiddle table tw[m] = exp(-2 pi i m / M).
 template <int M, int RADIX, int NS, bool FIRST>
 __device__ __forceinline__ void stockham_stage_mixed(double2 *z, const double2 *tw, int lane, int n_live)
@@ -218,12 +229,17 @@ __device__ __forceinline__ void stockham_stage_mixed(double2 *z, const double2 *
 #pragma unroll
             for (int r = 0; r < RADIX; ++r) {
                 const int idx = j + r * T;
-                v[p][r] = (!FIRST || idx < n_live) ? z[idx] : make_double2(0.0, 0.0);
+                // first stage: rows >= M / 2 are structurally zero (the zero padding), which is
+                // r >= RADIX / 2 for every butterfly — known at compile time, so the arithmetic
+                // on them folds away
+                v[p][r] = (!FIRST || r < RADIX / 2) ? z[idx] : make_double2(0.0, 0.0);
                 if (NS > 1 && r)   // W_(RADIX NS)^(r k)
                     v[p][r] = cmul(v[p][r], tw[WRAPS ? (r * k * STEP) % M : r * k * STEP]);
             }
             if (RADIX == 5)
                 dft5(v[p]);
+            else if (RADIX == 4)
+                dft4(v[p]);
             else
                 dft16(v[p]);
         }
@@ -330,12 +346,12 @@ __global__ __launch_bounds__(THREADS, R1 == 512 ? 4 : 2) void msd_fft_cols_kerne
 #undef MDX_COLS_LOAD
 }
 
-// Pass A for R1 = 400 = 16 x 5 x 5 (n_fft = 204 800 = 400 x 512: blocks of 32 769 .. 102 400 frames,
+// Pass A for R1 = 400 = 4 x 4 x 5 x 5 (n_fft = 204 800 = 400 x 512: blocks of 32 769 .. 102 400 frames,
 // C4's 100 000 among them — 22 % less of the half-transformed block than 2^18).  As
 // msd_fft_cols_kernel, with guarded row / line loops (200 live rows, 400 lines are not multiples
 // of the 32 / 64 a thread steps by) and the full twiddle table of the 400-point transform.
 template <int R2>
-__global__ __launch_bounds__(THREADS, 2) void msd_fft_cols400_kernel(
+__global__ __launch_bounds__(THREADS, 4) void msd_fft_cols400_kernel(
     const double *__restrict__ pos, int64_t n_total, int64_t first, int64_t n_elem, int64_t t_block,
     int zero_dims, int p_pad, const double2 *__restrict__ tw_r1, const double2 *__restrict__ twN,
     double2 *__restrict__ Y)
@@ -385,12 +401,13 @@ __global__ __launch_bounds__(THREADS, 2) void msd_fft_cols400_kernel(
             const int nxt = min(n2 + 1, R2 - 1);   // the last column reloads itself
             MDX_COLS400_LOAD(nxt)
         }
-        stockham_stage_mixed<R1, 16, 1, true>(zb[wave], s_h, lane, LIVE);
+        stockham_stage_mixed<R1, 4, 1, true>(zb[wave], s_h, lane, LIVE);
+        stockham_stage_mixed<R1, 4, 4, false>(zb[wave], s_h, lane, R1);
         stockham_stage_mixed<R1, 5, 16, false>(zb[wave], s_h, lane, R1);
         stockham_stage_mixed<R1, 5, 80, false>(zb[wave], s_h, lane, R1);
         __syncthreads();
         double2 *o = out + int64_t(n2) * PG;
-#pragma unroll
+#pragma unroll 1
         for (int i = 0; i < OUTS; ++i) {
             const int k1 = kbase + 64 * i;
             if (k1 < R1) {
