@@ -68,7 +68,7 @@ def test_rdf_two_groups_norms_and_drop_axis():
         assert np.allclose(r.results.rdf, ref["rdf"], rtol=1e-6)
         assert np.allclose(r._get_rdf(), orf.rdf_run_ref(frames, dims, 50, (0.5, 10.0), sel1=slice(0, 400),
                                                          sel2=slice(400, 900))["rdf"], rtol=1e-6)
-    # residue centres of mass go through the per-frame path
+    # residue centres of mass: formed on the device (mdx_rdf_set_grouping), float32 like the host path
     r = RadialDistributionFunction(u.atoms, n_bins=30, range=(0.0, 8.0), groupings="residues",
                                    exclusion=(1, 1)).run()
     com = frames.reshape(7, 300, 3, 3).astype(np.float64).mean(axis=2).astype(np.float32)
@@ -250,7 +250,7 @@ def test_onsager_blocks_warning_center_and_unwrap():
         ons = Onsager(u.atoms, temperature=1.0, reduced=True, n_blocks=4).run()
     cross, self_ = _onsager_ref(pos, (50,), 4)
     assert np.allclose(ons.results.msd_self, self_, rtol=1e-6, atol=1e-8)
-    # centre-of-mass removal (per-frame path)
+    # centre-of-mass removal (float64 positions here: the per-frame host path)
     cen = Onsager(u.atoms, temperature=1.0, reduced=True, center=True).run()
     centred = pos - pos.mean(axis=1, keepdims=True)
     _, self_c = _onsager_ref(centred, (50,), 1)
