@@ -226,3 +226,26 @@ def test_frame_prep_helpers():
                        molecule.center_of_mass(u.atoms))
     assert utility.get_closest_factors(35904, 3).tolist() == [32, 33, 34]
     assert utility.get_closest_factors(73440, 4, reverse=True).tolist() == [18, 17, 16, 15]
+
+
+def test_bench_contract_without_a_device(tmp_path):
+    """bench.py: flags of the driver's contract parse, a wrong launch geometry is refused with the
+    torch.distributed.run command line, and without a HIP device the run fails loudly (no CPU path)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True,
+                         text=True, env=env, timeout=120)
+    assert out.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup", "--workload", "--blocks", "--host-path", "--traj-file"):
+        assert flag in out.stdout
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True,
+                         text=True, env=env, timeout=120)
+    assert out.returncode != 0 and "torch.distributed.run" in (out.stderr + out.stdout)
+    from mdhelper_amd import _lib
+    if _lib.device_count() == 0:
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"],
+                             capture_output=True, text=True, env=env, timeout=300)
+        assert out.returncode != 0 and out.stdout.strip() == ""      # no JSON line without a GPU
