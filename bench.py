@@ -468,9 +468,10 @@ def bench_msd(args, world):
     traffic = None
     try:   # PMC pass of the same workload (scripts/profile_pmc.sh), per step
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
-            if N == 10000 and T == 100000 and eng.n_fft == 262144 and not os.environ.get("MDX_MSD_ROCFFT"):
-                # (measured for the 2^18 transform, MDX_MSD_NFFT=pow2; not re-measured for 204 800)
-                traffic = json.load(fh)["msd_c4_step"]["hbm_bytes_per_step"]
+            if N == 10000 and T == 100000 and B == 1 and not os.environ.get("MDX_MSD_ROCFFT"):
+                key = {204800: "msd_c4_step", 262144: "msd_c4_step_pow2"}.get(eng.n_fft)
+                if key:
+                    traffic = json.load(fh)[key]["hbm_bytes_per_step"]
     except (OSError, KeyError, ValueError):
         pass
     out = {
