@@ -8,20 +8,32 @@ Default workload (BASELINE.json configs[1], "C2"): RDF on 32 768 atoms, cubic
 box L = 68.94 A (rho = 0.1 A^-3), n_bins = 201, range = (0, 15) A, self RDF with
 exclusion = (1, 1); synthetic wrapped Gaussian random walk generated in HBM.
 One *step* = one pass of the hot path (mdx_rdf_accumulate_device) over one batch
-of `--frames` frames already resident in HBM.  For N > 1 (launched by
-torch.distributed.run, one rank per GPU) every rank owns its own batch of
-frames (weak scaling, frames shard with no data-path collective) and the
-per-rank histograms meet in ONE RCCL all-reduce at the end of the timed region.
+of `--frames` frames already resident in HBM.
+
+N > 1: one process per GPU.  `python bench.py --gpus N` starts its own N ranks
+(mdhelper_amd/launch.py: a parent that never touches the GPU spawns one fresh
+child per device and relays rank 0's line); under `python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N` the ranks are the launcher's.  Either way
+the ranks meet on a node-local rendezvous socket (the 128-byte RCCL id travels
+there; no torch in the path), every rank owns its own batch of frames (weak
+scaling, frames shard with no data-path collective) and the per-rank histograms
+meet in ONE RCCL all-reduce at the end of the timed region.
 
 Prints one JSON line on rank 0:
   value        = pair distances binned per second, whole job (sum of all counts / time)
-  roofline     = dominant kernel (rdf_cell_pair_kernel) algorithmic HBM bytes / its HIP-event time
-  cpu_baseline = the C restatement of the reference path (oracle/c/rdf_oracle.c,
-                 OpenMP on the host cores) on a bounded sample of the same frames;
-                 its counts are also checked bit-for-bit against the GPU's.
+  roofline     = dominant kernel (rdf_cell_pair_kernel): the VALU issue bound that binds it
+                 (hot-loop trips counted live x instruction counts from the SQ-counter profile of
+                 the same sources) with the HBM figure beside it under "hbm"
+  cpu_baseline = NumPy restatement of the reference path on one core; cpu_baseline_parallel =
+                 the same over every core of the affinity mask; cpu_baseline_c = the C/OpenMP
+                 restatement on whole frames, whose counts are also checked bit-for-bit
+                 against the GPU's.
+  extra        = short C3 S(q), C4 MSD and C2(ii) wide-range legs (N = 1 only), each a full
+                 line of its own workload with roofline + cpu_baseline.
 """
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -35,11 +47,14 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 FP64_VALU_PEAK_TFLOPS = 78.6   # vector fp64 spec
 FP32_VALU_PEAK_TFLOPS = 157.3
-CUS = 256                      # 4 SIMDs each
-CLOCK_HZ = 2.4e9
+CUS = 256                      # 4 SIMD-32 each
+SIMDS = 4 * CUS
+CLOCK_HZ = 2.4e9               # nominal peak engine clock (MI355X_MICROARCH.md)
+VALU_CYCLES = 2.0              # wave64 VALU instruction on a SIMD-32: 2 cycles (guide, constants table)
+VALU_TRANS_CYCLES = 4.0        # quarter-rate transcendentals (v_sqrt_f32, ...): twice that
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -50,37 +65,66 @@ def parse():
     ap.add_argument("--algo", default="auto", choices=["auto", "exact", "filter", "cell"])
     ap.add_argument("--blocks", type=int, default=1, help="msd: n_blocks (C4 is quoted for 1 and 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="rdf at N=1: skip the short C3 / C4 / C2(ii) legs embedded under 'extra'")
     ap.add_argument("--host-path", action="store_true",
                     help="rdf: feed host (pageable) buffers through mdx_rdf_accumulate, i.e. the "
                          "PCIe-inclusive rate; never the headline value")
     ap.add_argument("--traj-file", action="store_true",
                     help="rdf: write the frames to an AMBER NetCDF file first and feed the engine "
                          "through the native reader (file -> pinned -> HBM inside the timed region)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time")
-    return ap.parse_args()
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target time of each CPU-baseline leg")
+    ap.add_argument("--shard-fixed", action="store_true",
+                    help="strong scaling check: ONE fixed set of --frames frames (rdf, sq) or --atoms "
+                         "particles (msd), the same for any --gpus, sharded across the ranks; the reduced "
+                         "result must not depend on the rank count ('result_digest')")
+    ap.add_argument("--share-devices", action="store_true",
+                    help="tests on a box with fewer GPUs than ranks: rank r uses device r %% devices and the "
+                         "accumulators meet in a host all-reduce over the rendezvous socket (RCCL cannot put "
+                         "two ranks on one GPU); never a performance number")
+    return ap.parse_args(argv)
 
 
 class World:
-    """Control plane: env from torch.distributed.run; data plane: RCCL inside libmdx."""
+    """
+    One process per GPU.  Control plane: RANK / LOCAL_RANK / WORLD_SIZE from the launcher
+    (``mdhelper_amd.launch.launch`` when this script starts its own ranks, or
+    ``torch.distributed.run``) + the node-local rendezvous socket; data plane: RCCL inside libmdx.
+    """
 
-    def __init__(self, n_gpus):
+    def __init__(self, args):
+        from mdhelper_amd import _lib
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        if self.world != n_gpus:
-            if self.world == 1 and n_gpus > 1:
-                raise SystemExit(
-                    f"--gpus {n_gpus} needs one process per GPU: launch with\n  python -m "
-                    f"torch.distributed.run --nnodes=1 --nproc-per-node {n_gpus} --master-addr "
-                    f"127.0.0.1 --master-port 29500 bench.py --gpus {n_gpus} ...")
-            raise SystemExit(f"WORLD_SIZE={self.world} does not match --gpus {n_gpus}")
+        if self.world != args.gpus:
+            raise SystemExit(f"WORLD_SIZE={self.world} does not match --gpus {args.gpus}")
+        n_dev = _lib.device_count()
+        if n_dev == 0:
+            _lib.require_device(0)
+        self.dev = self.local_rank % n_dev if args.share_devices else self.local_rank
+        _lib.require_device(self.dev)
         self.comm = None
-        # MDX_FORCE_COMM=1 builds the communicator for a single rank too (exercises the
-        # rendezvous + RCCL path on a one-GPU box)
+        self.kind = None
+        self.rccl_ranks = None
+        # MDX_FORCE_COMM=1 builds the RCCL communicator for a single rank too
         if self.world > 1 or os.environ.get("MDX_FORCE_COMM") == "1":
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            from mdhelper_amd.comm import rccl_comm_from_env
-            self.comm = rccl_comm_from_env(self.local_rank)
+            from mdhelper_amd.launch import Rendezvous, SocketComm
+            rdzv = Rendezvous(self.rank, self.world) if self.world > 1 else None
+            if args.share_devices and self.world > 1:
+                self.comm, self.kind = SocketComm(rdzv), "host-socket (ranks share devices: test mode)"
+            else:
+                from mdhelper_amd.comm import rccl_comm_from_env
+                self.comm, self.kind = rccl_comm_from_env(self.dev, rdzv), "rccl"
+                n, r, d = self.comm.rccl_info()
+                if (n, r) != (self.world, self.rank):
+                    raise SystemExit(f"RCCL reports rank {r} of {n}, expected {self.rank} of {self.world}")
+                self.rccl_ranks = n
+
+    @property
+    def device_collectives(self):
+        return self.kind == "rccl"
 
     def barrier(self):
         if self.comm is not None:
@@ -96,8 +140,32 @@ class World:
             return x
         return float(self.comm.allreduce(np.array([x], dtype=np.float64), op="sum")[0])
 
+    def gather(self, x):
+        """Every rank's scalar, in rank order."""
+        if self.comm is None:
+            return [float(x)]
+        v = np.zeros(self.world, dtype=np.float64)
+        v[self.rank] = x
+        return [float(t) for t in self.comm.allreduce(v, op="sum")]
+
+    def reduce_host(self, arr):
+        """Sum of a host array over the ranks (the SocketComm route of the accumulators)."""
+        return arr if self.comm is None else self.comm.allreduce(arr, op="sum")
+
+    def describe(self):
+        return {"comm": self.kind, "rccl_ranks": self.rccl_ranks}
+
+    def close(self):
+        if self.comm is not None:
+            rdzv = getattr(self.comm, "rdzv", None)
+            self.comm.close()
+            if rdzv is not None and self.kind == "rccl":
+                rdzv.close()
+
 
 def timed_region(world, dev, steps, body, finish):
+    """Barrier + device synchronise on both sides; returns (max over ranks, this rank's own time
+    up to its last kernel, before the closing barrier)."""
     from mdhelper_amd import _core
     world.barrier()
     _core.synchronize(dev)
@@ -106,13 +174,43 @@ def timed_region(world, dev, steps, body, finish):
         body()
     finish()
     _core.synchronize(dev)
+    own = time.perf_counter() - t0
     world.barrier()
-    return world.max(time.perf_counter() - t0)
+    return world.max(time.perf_counter() - t0), own
+
+
+def source_digest(*names):
+    """sha256 of kernel source files: ties counter / traffic figures read from profiles/ to the
+    build they were measured on."""
+    h = hashlib.sha256()
+    for name in names:
+        with open(os.path.join(ROOT, "mdhelper_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def profiled(key, *sources):
+    """Entry ``key`` of profiles/counters.json (figures from separate rocprofv3 PMC passes, written by
+    scripts/profile_*.sh) — or None when it was measured on other kernel sources than these."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "counters.json")) as fh:
+            entry = json.load(fh)[key]
+    except (OSError, KeyError, ValueError):
+        return None
+    if entry.get("source_digest") != source_digest(*sources):
+        return None
+    return entry
+
+
+RDF_SOURCES = ("mdx_rdf.hip", "mdx_rdf_cell.hpp", "mdx_rdf_device.hpp")
+MSD_SOURCES = ("mdx_msd.hip", "mdx_msd_fft.hpp")
+SQ_SOURCES = ("mdx_sq.hip", "mdx_sq_device.hpp")
 
 
 def bench_rdf(args, world, wide=False):
     from mdhelper_amd import _core
-    dev = world.local_rank
+    from mdhelper_amd.comm import shard_range
+    dev = world.dev
     N = args.atoms or 32768
     F = args.frames or 10000
     L = 68.94 * (N / 32768.0) ** (1.0 / 3.0)
@@ -121,7 +219,12 @@ def bench_rdf(args, world, wide=False):
     edges = np.linspace(rng[0], rng[1], n_bins + 1)
     box = np.array([L, L, L, 90, 90, 90], dtype=np.float32)
 
-    traj = _core.synth_random_walk(F, N, box[:3], 0.3, seed=2 + world.rank, dev=dev)
+    # weak scaling: every rank owns its own F frames (seeded by rank); --shard-fixed: ONE set of F
+    # frames (same seed everywhere), rank r takes the contiguous share shard_range(F, r, world)
+    seed = 2 if args.shard_fixed else 2 + world.rank
+    traj = _core.synth_random_walk(F, N, box[:3], 0.3, seed=seed, dev=dev)
+    lo, hi = shard_range(F, world.rank, world.world) if args.shard_fixed else (0, F)
+    F_mine = hi - lo
     d_boxes = _core.DeviceArray.from_host(np.tile(box, (F, 1)), dev)
     eng = _core.RdfEngine(edges, (1, 1), algo=args.algo, dev=dev, timing=True)
 
@@ -151,94 +254,129 @@ def bench_rdf(args, world, wide=False):
                 v_a[f] = box[3:]
         del h_traj
         traj_file = TrajectoryFile(tmp.name)
-        h_boxes = traj_file.read_boxes(np.arange(F))
-        all_frames = np.arange(F)
+        my_frames = np.arange(lo, hi)
+        h_boxes = traj_file.read_boxes(my_frames)
 
         def step():
-            eng.accumulate_traj(traj_file, all_frames, h_boxes)
+            eng.accumulate_traj(traj_file, my_frames, h_boxes)
     elif args.host_path:
-        h_traj = traj.to_host()
-        h_boxes = np.tile(box, (F, 1))
+        h_traj = traj.to_host(lo, F_mine)
+        h_boxes = np.tile(box, (F_mine, 1))
 
         def step():
             eng.accumulate(h_traj, None, h_boxes)
     else:
         def step():
-            eng.accumulate_device(traj.ptr, N, None, N, d_boxes.ptr, F)
+            if F_mine:
+                eng.accumulate_device(traj.offset(lo), N, None, N, d_boxes.offset(lo), F_mine)
+
+    res = {}
+
+    def finish():
+        # ONE all-reduce of the accumulators: RCCL on the uint64 counts in HBM, or (ranks sharing a
+        # device in tests) the host copies over the rendezvous socket
+        if world.device_collectives:
+            eng.allreduce(world.comm)
+        eng.synchronize()
+        res["counts"] = eng.counts() if (world.comm is None or world.device_collectives) \
+            else world.reduce_host(eng.counts())
 
     for _ in range(args.warmup):
         step()
-    if world.comm is not None and args.warmup:
-        eng.allreduce(world.comm)      # the collective's first call (connection set-up) is warm-up too
+    if args.warmup:
+        finish()                       # the collective's first call (connection set-up) is warm-up too
     eng.synchronize()
     eng.reset()
 
-    def finish():
-        if world.comm is not None:
-            eng.allreduce(world.comm)
-        eng.synchronize()
-
-    dt = timed_region(world, dev, args.steps, step, finish)
-    counts = eng.counts()          # global sum after the all-reduce
+    dt, own = timed_region(world, dev, args.steps, step, finish)
+    counts = res["counts"]             # global sum after the all-reduce
     st = eng.stats()
     binned = int(counts.sum())
-    frames_total = args.steps * F * world.world
+    frames_total = args.steps * (F if args.shard_fixed else F * world.world)
     launches = max(st["launches"], 1)
     kernel_s = st["kernel_ms"] * 1e-3
     # one launch = one slab of frames (sort + pair kernel); algorithmic bytes 12 N + 24 per frame
-    alg_bytes_per_launch = args.steps * F * (12 * N + 24) / launches
+    alg_bytes_per_launch = args.steps * F_mine * (12 * N + 24) / launches
     achieved = alg_bytes_per_launch * launches / kernel_s / 1e9 if kernel_s > 0 else 0.0
-    pairs_eval_rate = st["pairs_evaluated"] / kernel_s if kernel_s > 0 else 0.0
-    # HBM bytes from the PMC counters come from a separate rocprofv3 run (profiles/traffic.json)
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
-            per_frame = json.load(fh)["rdf_cell_pair_kernel"]["hbm_bytes_per_frame"]
-        if N == 32768 and not wide and args.algo in ("auto", "cell"):
-            traffic = per_frame * F * args.steps / launches
-    except (OSError, KeyError, ValueError):
-        pass
+    steps64 = st["pairs_computed"] / 64.0          # hot-loop trips: 64 distance evaluations each
+    celled = args.algo in ("auto", "cell")
+    # VALU / SALU / LDS instructions per hot-loop trip and the engine clock under this kernel come from
+    # SQ counters of a separate rocprofv3 pass over the SAME sources (scripts/profile_counters.sh ->
+    # profiles/counters.json); dropped (None) when the kernel sources have changed since
+    ctr = profiled("rdf_wide" if wide else "rdf_c2", *RDF_SOURCES) if (celled and N == 32768) else None
+    clock = st.get("clock_hz") or None
+    valu = None
+    if ctr and kernel_s > 0:
+        clk = clock or ctr.get("clock_hz") or CLOCK_HZ
+        cyc_per_step = ctr["valu_plain_per_step"] * VALU_CYCLES + ctr["valu_trans_per_step"] * VALU_TRANS_CYCLES
+        issue = steps64 / kernel_s * cyc_per_step            # SIMD issue cycles consumed per second
+        valu = {"achieved": issue / 1e9, "peak": SIMDS * clk / 1e9, "frac": issue / (SIMDS * clk),
+                "frac_at_nominal_clock": issue / (SIMDS * CLOCK_HZ),
+                "clock_hz": clk, "clock_source": "s_memtime / s_memrealtime inside this run's kernel"
+                if clock else "profiles/counters.json",
+                "valu_instructions_per_step": ctr["valu_plain_per_step"] + ctr["valu_trans_per_step"],
+                "transcendentals_per_step": ctr["valu_trans_per_step"],
+                "salu_instructions_per_step": ctr.get("salu_per_step"),
+                "lds_instructions_per_step": ctr.get("lds_per_step"),
+                "valu_busy_fraction_of_simd_cycles": ctr.get("valu_busy_frac"),
+                "counters_source": ctr.get("source")}
+    traffic = ctr.get("hbm_bytes_per_frame") if ctr else None
+    hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": achieved / HBM_PEAK_GBS,
+           "traffic": traffic * F_mine * args.steps / launches if traffic else None,
+           "traffic_source": ctr.get("traffic_source") if (ctr and traffic) else None,
+           "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+           "note": "O(N^2) arithmetic on O(N) bytes: ~1e-3 of the HBM peak by construction"}
+    roofline = {
+        # the bound that binds: VALU issue of the pair loop (O(N^2) work on O(N) bytes)
+        "bound": "valu", "unit": "G SIMD issue cycles/s",
+        "achieved": valu["achieved"] if valu else None, "peak": valu["peak"] if valu else SIMDS * CLOCK_HZ / 1e9,
+        "frac": valu["frac"] if valu else None,
+        "traffic": hbm["traffic"],
+        "kernel": "rdf_cell_pair_kernel" if celled else "rdf_tile_kernel",
+        "kernel_ms_per_launch": st["kernel_ms"] / launches,
+        "definition": "hot-loop trips/s (64 distance evaluations each, counted by the kernel) x VALU issue "
+                      "cycles per trip (SQ_INSTS_VALU per trip from profiles/, 2 cycles per wave64 VALU "
+                      "instruction on a SIMD-32, 4 for v_sqrt_f32: MI355X_MICROARCH.md) / (1024 SIMDs x "
+                      "engine clock measured inside the kernel)",
+        "valu": valu,
+        "hbm": hbm,
+        "work": {
+            "ordered_pairs_covered_per_sec_kernel": st["pairs_evaluated"] / kernel_s if kernel_s > 0 else 0.0,
+            "distance_evaluations_per_sec_kernel": st["pairs_computed"] / kernel_s if kernel_s > 0 else 0.0,
+            "evaluated_fraction_of_pair_space": st["pairs_computed"] / max(st["pairs_evaluated"], 1),
+            "binned_fraction_of_pair_space": binned / max(frames_total * float(N) * N, 1.0),
+            "exact_path_fraction_of_evaluations": st["pairs_exact"] / max(st["pairs_computed"], 1),
+            "image_search_path_fraction": st["cell_units_general"] / max(st["cell_units"], 1),
+        },
+    }
+    per_rank = world.gather(args.steps * F_mine / own)
     out = {
         "metric": "pair-distances binned/sec",
         "value": binned / dt,
         "unit": "pairs/s",
         "n_gpus": world.world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if args.shard_fixed else "weak", "vs_baseline": None,
         "dtype": "f32 filter + f64 contract arithmetic, u64 counts",
         "data": "synthetic" + (" (host buffers, PCIe copy inside the timed region)"
                                if args.host_path else ""),
-        "config": {"workload": ("C2(ii)" if wide else "C2(i)") + f" RDF {N} atoms x {F} frames/GPU/step, "
-                   f"L={L:.2f} A, n_bins={n_bins}, range=({rng[0]:g},{rng[1]:.4g}), exclusion=(1,1), "
+        "config": {"workload": ("C2(ii)" if wide else "C2(i)") + f" RDF {N} atoms x {F} frames"
+                   + ("/job/step (fixed set, sharded)" if args.shard_fixed else "/GPU/step")
+                   + f", L={L:.2f} A, n_bins={n_bins}, range=({rng[0]:g},{rng[1]:.4g}), exclusion=(1,1), "
                    f"algo={args.algo}" + (", host path" if args.host_path else "")
                    + (", NetCDF file through the native reader" if args.traj_file else ""),
-                   "atoms": N, "frames_per_step_per_gpu": F, "n_bins": n_bins},
+                   "atoms": N, "frames_per_step_per_gpu": F_mine, "n_bins": n_bins},
         "frames_per_sec": frames_total / dt,
+        "per_rank_frames_per_sec": per_rank,
+        **world.describe(),
         "pair_distances_covered_per_sec": frames_total * float(N) * N / dt,
         "pairs_binned_per_frame": binned / max(frames_total, 1),
-        "roofline": {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "kernel": "rdf_cell_pair_kernel (algo cell/auto) or rdf_tile_kernel (exact/filter)",
-            "kernel_ms_per_launch": st["kernel_ms"] / launches,
-            "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-            "note": "O(N^2) arithmetic on O(N) bytes: the kernel is VALU/LDS-atomic bound, see 'valu'",
-            "valu": {
-                "ordered_pairs_covered_per_sec_kernel": pairs_eval_rate,
-                "distance_evaluations_per_sec_kernel": st["pairs_computed"] / kernel_s if kernel_s > 0 else 0.0,
-                "evaluated_fraction_of_pair_space": st["pairs_computed"] / max(st["pairs_evaluated"], 1),
-                "exact_path_fraction_of_evaluations": st["pairs_exact"] / max(st["pairs_computed"], 1),
-                "image_search_path_fraction": st["cell_units_general"] / max(st["cell_units"], 1),
-                # The hot step (64 evaluations) issues 10 plain VALU + v_sqrt_f32 + 2 v_cmp; at the
-                # measured issue costs (profiles/r01_d_valu_issue_microbench.txt: 3.0 / 8.3 / 4.2
-                # cycles per wave-instruction per SIMD) that is 46.7 cycles per step per SIMD.
-                "valu_issue_bound_frac_est": (st["pairs_computed"] / kernel_s / 64.0 / (4 * CUS)
-                                              * 46.7 / CLOCK_HZ) if kernel_s > 0 else 0.0,
-            },
-        },
+        "result_digest": hashlib.sha256(np.ascontiguousarray(counts, dtype=np.int64).tobytes()).hexdigest()[:16],
+        "roofline": roofline,
     }
     if world.rank == 0 and world.world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline_rdf(args, traj, box, edges, rng, n_bins, N, eng)
+        out.update(cpu_baseline_rdf(args, traj, box, edges, rng, n_bins, N, eng))
     if traj_file is not None:
         traj_file.close()
         os.unlink(tmp.name)
@@ -249,15 +387,47 @@ def bench_rdf(args, world, wide=False):
 
 
 def cpu_baseline_rdf(args, traj, box, edges, rng, n_bins, N, eng):
-    """C oracle (OpenMP, all host cores) on a bounded sample of the same frames + parity check."""
+    """
+    CPU restatements of the reference path on bounded samples of the bench frames:
+    ``cpu_baseline``          NumPy pair list + numpy.histogram on ONE core (the reference's serial run());
+    ``cpu_baseline_parallel`` the same over len(os.sched_getaffinity(0)) worker processes (parallel=True);
+    ``cpu_baseline_c``        brute-force C/OpenMP restatement (oracle/c/rdf_oracle.c) on whole frames, whose
+                              counts are also compared bit-for-bit with the GPU's on the same frames.
+    (An installed reference would take MDAnalysis' nsgrid cell list at this size; it is not available
+    here, so none of these is a statement about that code path.)
+    """
     from mdhelper_amd import _core
-    from oracle import cbind
-    # one GPU's share of the host (16 cores on the bench boxes) unless told otherwise
-    threads = int(os.environ.get("MDX_CPU_THREADS", min(16, max(1, len(os.sched_getaffinity(0))))))
-    frames = traj.to_host(0, 1)
+    from oracle import cbind, cpu_bench
+    # one GPU's share of the host (16 cores per GPU on the 8-GPU bench hosts) unless told otherwise
+    visible = max(1, len(os.sched_getaffinity(0)))
+    threads = int(os.environ.get("MDX_CPU_THREADS", min(16, visible)))
+    cores = threads
+    frame = traj.to_host(0, 1)[0]
+    out = {}
+    # -- NumPy, one core: calibrate on 32 rows, then a sample sized to --cpu-seconds
+    _c, p0, t0 = cpu_bench.time_rdf_numpy(frame, box, n_bins, rng, (1, 1), 32, 1)
+    rows = int(max(32, min(N, 32 * args.cpu_seconds / max(t0, 1e-3))))
+    c1, p1, t1 = cpu_bench.time_rdf_numpy(frame, box, n_bins, rng, (1, 1), rows, 1)
+    chk = cbind.c_radial_histogram(frame[:rows], frame, n_bins, rng, box, exclusion=(1, 1), n_threads=threads)
+    out["cpu_baseline"] = {
+        "value": float(c1.sum()) / t1, "unit": "pairs/s", "cores": 1, "kind": "port",
+        "sample": f"rows 0..{rows} of frame 0 against all {N} particles ({p1:.3g} ordered pairs), NumPy "
+                  f"restatement of structure.py:92-104 (pair distances + numpy.histogram, oracle/rdf.py), "
+                  f"{t1:.1f} s; numpy {np.__version__}",
+        "frames_per_sec": p1 / float(N) / N / t1,
+        "equals_c_restatement_on_sample": bool(np.array_equal(c1, chk))}
+    # -- NumPy, every core of this process's affinity mask
+    rows_w = max(8, min(N // cores, int(rows * 0.7)))
+    cp, pp, tp = cpu_bench.time_rdf_numpy(frame, box, n_bins, rng, (1, 1), rows_w, cores)
+    out["cpu_baseline_parallel"] = {
+        "value": float(cp.sum()) / tp, "unit": "pairs/s", "cores": cores, "kind": "port",
+        "sample": f"{cores} worker processes (one GPU's share of the {visible} cores in the affinity mask) x "
+                  f"{rows_w} rows of frame 0 ({pp:.3g} ordered pairs), same NumPy restatement, {tp:.1f} s "
+                  f"(longest worker)",
+        "frames_per_sec": pp / float(N) / N / tp}
+    # -- C/OpenMP brute force on whole frames + parity of those frames on the GPU
     t0 = time.perf_counter()
-    c0 = cbind.c_radial_histogram(frames[0], frames[0], n_bins, rng, box, exclusion=(1, 1),
-                                  n_threads=threads)
+    cbind.c_radial_histogram(frame, frame, n_bins, rng, box, exclusion=(1, 1), n_threads=threads)
     t_one = time.perf_counter() - t0
     n_sample = int(max(1, min(64, args.cpu_seconds // max(t_one, 1e-3))))
     sample = traj.to_host(0, n_sample)
@@ -267,21 +437,22 @@ def cpu_baseline_rdf(args, traj, box, edges, rng, n_bins, N, eng):
         cbind.c_radial_histogram(sample[f], sample[f], n_bins, rng, box, exclusion=(1, 1),
                                  n_threads=threads, counts=counts)
     t_cpu = time.perf_counter() - t0
-    # parity of the very same frames on the GPU
     chk = _core.RdfEngine(edges, (1, 1), algo=args.algo, dev=eng.dev)
     chk.accumulate(sample, None, box)
     same = bool(np.array_equal(chk.counts(), counts))
     chk.close()
-    return {"value": float(counts.sum()) / t_cpu, "unit": "pairs/s", "cores": threads,
-            "kind": "port",
-            "sample": f"{n_sample} of the bench frames, brute-force C restatement "
-                      f"(oracle/c/rdf_oracle.c, OpenMP x{threads}); {t_cpu:.1f} s",
-            "frames_per_sec": n_sample / t_cpu, "gpu_counts_bit_exact_on_sample": same}
+    out["cpu_baseline_c"] = {
+        "value": float(counts.sum()) / t_cpu, "unit": "pairs/s", "cores": threads, "kind": "port",
+        "sample": f"{n_sample} whole bench frames, brute-force C restatement (oracle/c/rdf_oracle.c, "
+                  f"OpenMP x{threads}); {t_cpu:.1f} s",
+        "frames_per_sec": n_sample / t_cpu, "gpu_counts_bit_exact_on_sample": same}
+    return out
 
 
 def bench_sq(args, world):
     from mdhelper_amd import _core
-    dev = world.local_rank
+    from mdhelper_amd.comm import shard_range
+    dev = world.dev
     N = args.atoms or 32768
     F = args.frames or 1000
     L = 68.94
@@ -290,61 +461,79 @@ def bench_sq(args, world):
     q = np.stack(np.meshgrid(grid, grid, grid), -1).reshape(-1, 3)
     sizes = [N // 2, N - N // 2]
     pairs = ((0, 0), (0, 1), (1, 1))               # mode="partial" (structure.py:1459-1464)
-    traj = _core.synth_random_walk(F, N, [L, L, L], 0.3, seed=2 + world.rank, dev=dev)
+    seed = 2 if args.shard_fixed else 2 + world.rank
+    traj = _core.synth_random_walk(F, N, [L, L, L], 0.3, seed=seed, dev=dev)
+    lo, hi = shard_range(F, world.rank, world.world) if args.shard_fixed else (0, F)
+    F_mine = hi - lo
     eng = _core.SqEngine(q, sizes, pairs, dev=dev, timing=True)
 
     def step():
-        eng.accumulate_device(traj.ptr, N, F)
+        if F_mine:
+            eng.accumulate_device(traj.offset(lo), N, F_mine)
+
+    res = {}
+
+    def finish():
+        if world.device_collectives:
+            eng.allreduce(world.comm)
+        res["ssf"] = eng.result() if (world.comm is None or world.device_collectives) \
+            else world.reduce_host(eng.result())
 
     for _ in range(args.warmup):
         step()
-    if world.comm is not None and args.warmup:
-        eng.allreduce(world.comm)
-    eng.result()
+    if args.warmup:
+        finish()
     eng.reset()
 
-    def finish():
-        if world.comm is not None:
-            eng.allreduce(world.comm)
-
-    dt = timed_region(world, dev, args.steps, step, finish)
+    dt, own = timed_region(world, dev, args.steps, step, finish)
     st = eng.stats()
-    ssf = eng.result()
-    evals = args.steps * F * world.world * float(N) * len(q)
+    ssf = res["ssf"]
+    frames_total = args.steps * (F if args.shard_fixed else F * world.world)
+    evals = frames_total * float(N) * len(q)
     kernel_s = st["kernel_ms"] * 1e-3
-    alg = F * (12 * N) + 24 * len(q)
-    achieved = alg * max(st["launches"], 1) / kernel_s / 1e9 if kernel_s > 0 else 0.0
+    evals_rank = args.steps * F_mine * float(N) * len(q)
+    alg = F_mine * (12 * N) + 24 * len(q)
+    achieved = alg * args.steps / kernel_s / 1e9 if kernel_s > 0 else 0.0
+    # fp64 VALU bound: 4.5 v_fma_f64-class wave-instructions per 64 terms in the register-blocked column
+    # kernel; a wave64 fp64 FMA takes 4 cycles on a SIMD-32 (half the fp32 rate: 78.6 vs 157.3 TFLOP/s)
+    issue = evals_rank / max(kernel_s, 1e-9) / 64.0 * 4.5 * 4.0
     out = {
         "metric": "exp(iq.r) evaluations/sec", "value": evals / dt, "unit": "evals/s",
         "n_gpus": world.world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong" if args.shard_fixed else "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"C3 partial S(q) {N} atoms, {len(q)} wavevectors, 2 groups, {F} frames/GPU/step"},
-        "frames_per_sec": args.steps * F * world.world / dt,
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        "config": {"workload": f"C3 partial S(q) {N} atoms, {len(q)} wavevectors, 2 groups, {F} frames"
+                               + ("/job/step (fixed set, sharded)" if args.shard_fixed else "/GPU/step")},
+        "frames_per_sec": frames_total / dt,
+        "per_rank_frames_per_sec": world.gather(args.steps * F_mine / own),
+        **world.describe(),
+        "roofline": {"bound": "valu", "unit": "G SIMD issue cycles/s", "achieved": issue / 1e9,
+                     "peak": SIMDS * CLOCK_HZ / 1e9, "frac": issue / (SIMDS * CLOCK_HZ), "traffic": None,
                      "kernel": "sq_rho_quads_kernel (grid wavevectors: separable phase tables in LDS, "
                                "4 columns x 8 m_z accumulators per thread)",
-                     "note": "fp64 VALU bound: 4 FMAs per term + 0.5 complex products, 0.5 16-B LDS reads per "
-                             "term, ~100 fp64 instructions per particle, axis and tile for the tables; "
-                             "non-lattice wavevector sets take sq_rho_kernel (~40 fp64 instr each)",
-                     "valu": {"evaluations_per_sec_kernel": evals / max(kernel_s, 1e-9),
-                              # 4.5 v_fma_f64-class wave-instructions per 64 terms, 4.76 cycles each at the
-                              # nominal 2.4 GHz on 1024 SIMDs (profiles/r01_g_valu_issue_microbench.txt)
-                              "fp64_issue_bound_frac_est": evals / max(kernel_s, 1e-9) * 4.5 / 64 * 4.76
-                                                           / (1024 * 2.4e9)}},
+                     "definition": "terms/s / 64 x 4.5 fp64 FMA-class wave-instructions per 64 terms x 4 cycles "
+                                   "(wave64 fp64 on a SIMD-32) / (1024 SIMDs x 2.4 GHz nominal); the table fill, "
+                                   "address arithmetic and the DVFS clock under fp64 load (~2.07 GHz measured) "
+                                   "are what is left",
+                     "evaluations_per_sec_kernel": evals_rank / max(kernel_s, 1e-9),
+                     "hbm": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_step": alg}},
         "checksum": float(ssf.sum()),
+        "result_digest": [float(x) for x in ssf[:, 1:4].ravel()],
     }
     if world.rank == 0 and world.world == 1 and not args.no_cpu_baseline:
         from oracle import fourier as of
-        sample = traj.to_host(0, 2).astype(np.float64)
+        n_f = 2
+        sample = traj.to_host(0, n_f).astype(np.float64)
         t0 = time.perf_counter()
-        refs = [of.fourier_sum_ref(q, sample[f]) for f in range(2)]
+        refs = [of.fourier_sum_ref(q, sample[f]) for f in range(n_f)]
         t_cpu = time.perf_counter() - t0
         got = _core.fourier_sum_device(q, sample[0], dev=dev)
         err = float(np.abs(got - refs[0]).max() / np.abs(refs[0]).max())
-        out["cpu_baseline"] = {"value": 2 * float(N) * len(q) / t_cpu, "unit": "evals/s", "cores": 1,
-                               "kind": "port", "sample": f"2 frames, numpy exp(1j q.r) ({t_cpu:.1f} s)",
+        out["cpu_baseline"] = {"value": n_f * float(N) * len(q) / t_cpu, "unit": "evals/s", "cores": 1,
+                               "kind": "port", "sample": f"{n_f} bench frames, numpy exp(1j q.r) in q-chunks "
+                                                         f"(oracle/fourier.py; accelerated.py:81-122), {t_cpu:.1f} s",
                                "gpu_max_rel_deviation_on_sample": err}
     eng.close()
     traj.free()
@@ -356,7 +545,7 @@ def bench_isf(args, world):
     particles and wavevectors, 64 lags; frames resident in HBM (``--host-path``: fed from pageable
     host memory, PCIe inside the timed region)."""
     from mdhelper_amd import _core
-    dev = world.local_rank
+    dev = world.dev
     N = args.atoms or 32768
     F = args.frames or 256
     L = 68.94
@@ -378,7 +567,7 @@ def bench_isf(args, world):
 
     for _ in range(args.warmup):
         step()
-    dt = timed_region(world, dev, args.steps, step, lambda: None)
+    dt, _own = timed_region(world, dev, args.steps, step, lambda: None)
     st = eng.stats()
     cisf, iisf = eng.result()
     # terms per frame: rho(q) of every particle + one displacement phase per (lag, particle, q)
@@ -433,63 +622,79 @@ def bench_isf(args, world):
 
 def bench_msd(args, world):
     from mdhelper_amd import _core
-    dev = world.local_rank
+    from mdhelper_amd.comm import shard_range
+    dev = world.dev
     N = args.atoms or 10000
     T = args.frames or 100000
-    # particles shard across ranks (transport.py:1036-1039: per-particle MSDs are independent)
-    traj = _core.synth_random_walk(T, N, [1.0, 1.0, 1.0], 0.1, seed=4 + world.rank, dev=dev,
-                                   dtype=np.float64)
+    # particles shard across ranks (transport.py:1036-1039: per-particle MSDs are independent).
+    # weak: every rank owns N particles; --shard-fixed: ONE set of N particles, rank r pushes its share
+    seed = 4 if args.shard_fixed else 4 + world.rank
+    traj = _core.synth_random_walk(T, N, [1.0, 1.0, 1.0], 0.1, seed=seed, dev=dev, dtype=np.float64)
     B = max(1, args.blocks)
     eng = _core.MsdEngine(T // B, B, 2, dev=dev, timing=True)
+    groups = [(0, N // 2), (N // 2, N - N // 2)]
+    mine = []
+    for first, count in groups:
+        lo, hi = shard_range(count, world.rank, world.world) if args.shard_fixed else (0, count)
+        mine.append((first + lo, hi - lo))
+    n_mine = sum(c for _f, c in mine)
 
     def step():
         eng.reset()
-        eng.push_device(0, traj.ptr, N, 0, N // 2)
-        eng.push_device(1, traj.ptr, N, N // 2, N - N // 2)
+        for g, (first, count) in enumerate(mine):
+            if count:
+                eng.push_device(g, traj.ptr, N, first, count)
 
     box = {}
 
     def finish():
-        if world.comm is not None:
+        if world.device_collectives:
             eng.allreduce(world.comm)
-        box["msd"], box["traj"] = eng.result()
+        msd, tr = eng.result()
+        if world.comm is not None and not world.device_collectives:
+            msd, tr = world.reduce_host(msd), world.reduce_host(tr)
+        box["msd"], box["traj"] = msd, tr
 
     for _ in range(args.warmup):     # includes the inverse-transform plan (rocFFT builds it once)
         step()
         finish()
 
-    dt = timed_region(world, dev, args.steps, step, finish)
+    dt, own = timed_region(world, dev, args.steps, step, finish)
     st = eng.stats()
-    atom_frames = args.steps * float(N) * T * world.world
-    alg_bytes = 24.0 * N * T
+    n_total = N if args.shard_fixed else N * world.world
+    atom_frames = args.steps * float(n_total) * T
+    alg_bytes = 24.0 * n_mine * T
     kernel_s = st["kernel_ms"] * 1e-3
     achieved = alg_bytes / max(kernel_s, 1e-9) / 1e9
-    msd = box["msd"][0, 0] / (N // 2)
-    traffic = None
-    try:   # PMC pass of the same workload (scripts/profile_pmc.sh), per step
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
-            if N == 10000 and T == 100000 and B == 1 and not os.environ.get("MDX_MSD_ROCFFT"):
-                key = {204800: "msd_c4_step", 262144: "msd_c4_step_pow2"}.get(eng.n_fft)
-                if key:
-                    traffic = json.load(fh)[key]["hbm_bytes_per_step"]
-    except (OSError, KeyError, ValueError):
-        pass
+    msd = box["msd"][0, 0] / (N // 2 if args.shard_fixed else (N // 2) * world.world)
+    own_fft = (eng.n_fft in (1 << 13, 1 << 14, 1 << 15, 1 << 16, 204800, 1 << 18, 1 << 19, 1 << 20)
+               and not os.environ.get("MDX_MSD_ROCFFT"))
+    ctr = None
+    if N == 10000 and T == 100000 and B == 1 and own_fft and world.world == 1:
+        ctr = profiled({204800: "msd_c4", 262144: "msd_c4_pow2"}.get(eng.n_fft, ""), *MSD_SOURCES)
     out = {
         "metric": "MSD atom-frames/sec", "value": atom_frames / dt, "unit": "atom-frames/s",
         "n_gpus": world.world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong" if args.shard_fixed else "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"C4 self-MSD {N} atoms x {T} frames, 2 groups, n_blocks={B}, n_fft={eng.n_fft}"
-                               + (" (own two-pass transform)" if eng.n_fft in (1 << 13, 1 << 14, 1 << 15, 1 << 16, 204800,
-                                                                                  1 << 18, 1 << 19, 1 << 20)
-                                  and not os.environ.get("MDX_MSD_ROCFFT") else " (rocFFT)")},
+        "config": {"workload": f"C4 self-MSD {N} atoms" + (" (fixed set, sharded)" if args.shard_fixed else "/GPU")
+                               + f" x {T} frames, 2 groups, n_blocks={B}, n_fft={eng.n_fft}"
+                               + (" (own two-pass transform)" if own_fft else " (rocFFT)")},
+        "per_rank_atom_frames_per_sec": world.gather(args.steps * float(n_mine) * T / own),
+        **world.describe(),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "msd pipeline of one step: sums + forward transforms + power "
-                               "(msd_fft_cols/rows_power kernels for n_fft = 2^13..2^16, 2^18..2^20, else gather + "
-                               "rocFFT R2C + power)",
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": ctr.get("hbm_bytes_per_step") if ctr else None,
+                     "traffic_source": ctr.get("traffic_source") if ctr else None,
+                     "kernel": "msd pipeline of one step: forward transforms with the per-frame sums fused in + "
+                               "power (msd_fft_cols/rows_power kernels for n_fft = 2^13..2^16, 204800, "
+                               "2^18..2^20, else gather + rocFFT R2C + power)",
+                     "kernel_ms_per_step": st["kernel_ms"],
+                     "algorithmic_bytes_per_step": alg_bytes,
                      "pipeline_bytes_model": st["bytes_moved"]},
         "physics_check_msd_over_3sigma2m": float(msd[10] / (3 * 0.01 * 10)),
+        "result_digest": [float(x) for x in box["msd"][:, 0, 1:4].ravel()],
     }
     if world.rank == 0 and world.world == 1 and not args.no_cpu_baseline:
         # the reference's msd_fft (scipy FFTs, one core) on a bounded sample of particles, and
@@ -510,23 +715,72 @@ def bench_msd(args, world):
         out["cpu_baseline"] = {"value": n_s * float(T) / t_cpu, "unit": "atom-frames/s", "cores": 1,
                                "kind": "port",
                                "sample": f"{n_s} particles x {T} frames, scipy-FFT msd_fft restatement "
-                                         f"(oracle/correlation.py), {t_cpu:.1f} s",
+                                         f"(oracle/correlation.py; correlation.py:461-668), {t_cpu:.1f} s",
                                "gpu_max_rel_deviation_on_sample": err}
     eng.close()
     traj.free()
     return out
 
 
+def run_extras(args, world):
+    """Short C3 / C4 / C2(ii) legs after the headline one, embedded in the same JSON line so that the
+    S(q) and MSD paths (accelerated.py:81-165, correlation.py:461-668) are in the driver-timed record
+    too.  Each is a complete line of its own workload (value, roofline, cpu_baseline)."""
+    import copy
+    extra = {}
+    plan = (("sq", dict(workload="sq", frames=1000, steps=3, warmup=1)),
+            ("msd", dict(workload="msd", frames=None, steps=3, warmup=1)),
+            ("rdf_wide", dict(workload="rdf_wide", frames=1000, steps=2, warmup=1)))
+    for name, over in plan:
+        a = copy.copy(args)
+        a.atoms, a.blocks, a.algo, a.host_path, a.traj_file, a.shard_fixed = None, 1, "auto", False, False, False
+        a.cpu_seconds = min(args.cpu_seconds, 5.0)
+        for k, v in over.items():
+            setattr(a, k, v)
+        t0 = time.perf_counter()
+        try:
+            if name == "sq":
+                extra[name] = bench_sq(a, world)
+            elif name == "msd":
+                extra[name] = bench_msd(a, world)
+            else:
+                extra[name] = bench_rdf(a, world, wide=True)
+            extra[name]["leg_wall_s"] = time.perf_counter() - t0
+        except Exception as exc:            # an extra leg never takes the headline line down
+            extra[name] = {"error": f"{type(exc).__name__}: {exc}"}
+    return extra
+
+
+def launch_ranks(args):
+    """``python bench.py --gpus N`` outside any launcher: start N fresh ranks of this script (one per
+    GPU) from this process, which never touches the GPU, and relay rank 0's line."""
+    from mdhelper_amd import launch
+    try:
+        rc, text = launch.launch(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:],
+                                 share_devices=args.share_devices)
+    except RuntimeError as exc:
+        sys.stderr.write(f"bench.py: {exc}\n")
+        return 2
+    line = launch.last_json_line(text)
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: rank 0 printed no result line\n")
+        rc = 1
+    if line is not None:
+        line["launcher"] = "bench.py (mdhelper_amd.launch: one fresh process per GPU)"
+        print(json.dumps(line), flush=True)
+    return rc
+
+
 def main():
     args = parse()
-    # Libraries underneath (gloo, RCCL) print banners on stdout; keep stdout clean for the
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    # Libraries underneath (RCCL) print banners on stdout; keep stdout clean for the
     # one JSON line by pointing fd 1 at stderr until the result is ready.
     sys.stdout.flush()
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
-    world = World(args.gpus)
-    from mdhelper_amd import _lib
-    _lib.require_device(world.local_rank)
+    world = World(args)
     if args.workload in ("rdf", "rdf_wide"):
         out = bench_rdf(args, world, wide=args.workload == "rdf_wide")
     elif args.workload == "sq":
@@ -535,20 +789,16 @@ def main():
         out = bench_isf(args, world)
     else:
         out = bench_msd(args, world)
+    plain = not (args.host_path or args.traj_file or args.shard_fixed or args.atoms or args.algo != "auto")
+    if args.workload == "rdf" and world.world == 1 and plain and not args.no_extras:
+        out["extra"] = run_extras(args, world)
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)
     os.close(saved_stdout)
     if world.rank == 0:
         print(json.dumps(out), flush=True)
     os.dup2(2, 1)          # teardown chatter goes to stderr as well
-    if world.comm is not None:
-        world.comm.close()
-        try:
-            import torch.distributed as dist
-            if dist.is_initialized():
-                dist.destroy_process_group()
-        except ImportError:
-            pass
+    world.close()
 
 
 if __name__ == "__main__":

@@ -74,14 +74,17 @@ int mdx_synth_random_walk_f64(int dev, double *d_out, int64_t n_frames, int64_t 
 /* ---------------------------------------------------------------- collectives
  * One process per GPU; the communicator is RCCL over xGMI.  Rank 0 calls
  * mdx_comm_unique_id() and ships the 128-byte id to the other ranks through
- * whatever rendezvous the launcher offers (bench.py: the torch.distributed
- * TCPStore); then every rank calls mdx_comm_init_rank(). */
+ * whatever rendezvous the launcher offers (mdhelper_amd/launch.py: a node-local
+ * unix socket); then every rank calls mdx_comm_init_rank(). */
 typedef struct mdx_comm *mdx_comm_t;
 #define MDX_COMM_ID_BYTES 128
 int mdx_comm_unique_id(unsigned char id[MDX_COMM_ID_BYTES]);
 int mdx_comm_init_rank(mdx_comm_t *comm, int dev, const unsigned char id[MDX_COMM_ID_BYTES],
                        int rank, int world_size);
 int mdx_comm_destroy(mdx_comm_t comm);
+/* what RCCL itself reports for this communicator (ncclCommCount / UserRank / CuDevice);
+ * any out pointer may be NULL */
+int mdx_comm_count(mdx_comm_t comm, int *count, int *rank, int *device);
 int mdx_comm_barrier(mdx_comm_t comm);
 /* in-place sum / max all-reduce of small host vectors (staged through HBM) */
 int mdx_comm_allreduce_f64(mdx_comm_t comm, double *host_inout, int64_t n, int op_max);

@@ -115,6 +115,12 @@ class RcclComm:
     def barrier(self):
         check(lib().mdx_comm_barrier(self.handle))
 
+    def rccl_info(self):
+        """(ranks, this rank, device) as RCCL reports them for the communicator."""
+        n, r, d = c_int(), c_int(), c_int()
+        check(lib().mdx_comm_count(self.handle, byref(n), byref(r), byref(d)))
+        return n.value, r.value, d.value
+
     def allreduce(self, arr, op="sum"):
         arr = np.ascontiguousarray(arr)
         if arr.dtype == np.int64 and op == "sum":

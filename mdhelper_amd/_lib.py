@@ -49,6 +49,7 @@ _SIGNATURES = {
     "mdx_comm_unique_id": (c_int, [_vp]),
     "mdx_comm_init_rank": (c_int, [POINTER(_vp), c_int, _vp, c_int, c_int]),
     "mdx_comm_destroy": (c_int, [_vp]),
+    "mdx_comm_count": (c_int, [_vp, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "mdx_comm_barrier": (c_int, [_vp]),
     "mdx_comm_allreduce_f64": (c_int, [_vp, _vp, c_int64, c_int]),
     "mdx_comm_allreduce_i64": (c_int, [_vp, _vp, c_int64]),

@@ -4,6 +4,8 @@ Communicators for frame- / particle-sharded runs (one process per GPU).
 * ``SerialComm``     — world of one (default).
 * ``RcclComm``       — RCCL over xGMI through ``libmdx.so`` (``mdx_comm_*``); the
                        accumulators are all-reduced in HBM (``engine.allreduce``).
+* ``launch.SocketComm`` — host all-reduce over the node-local rendezvous socket (no torch,
+                       no RCCL): ranks that share one GPU in tests.
 * ``TorchDistComm``  — any initialised ``torch.distributed`` process group
                        (``gloo`` on CPU, ``nccl`` = RCCL on GPUs); the host copies
                        of the accumulators are all-reduced.  Used by the
@@ -66,11 +68,12 @@ class TorchDistComm:
         self._dist.barrier(group=self._group)
 
 
-def rccl_comm_from_env(device: int | None = None):
+def rccl_comm_from_env(device: int | None = None, rdzv=None):
     """
-    Build an ``RcclComm`` for a process launched by ``torch.distributed.run``:
-    rank 0 creates the RCCL unique id and ships it through a gloo broadcast
-    (control plane only); the data plane is RCCL inside ``libmdx.so``.
+    Build an ``RcclComm`` for one rank of a one-process-per-GPU job (``launch.launch`` or
+    ``torch.distributed.run``): rank 0 creates the RCCL unique id and ships its 128 bytes through
+    the node-local ``launch.Rendezvous`` (control plane only); the data plane is RCCL inside
+    ``libmdx.so``.  The rendezvous stays attached as ``comm.rdzv``.
     """
     import os
 
@@ -79,13 +82,12 @@ def rccl_comm_from_env(device: int | None = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1 and "MASTER_ADDR" not in os.environ:
+    if world == 1 and rdzv is None:
         return RcclComm(0, 1, RcclComm.unique_id(), device)
-    import torch.distributed as dist
-    if not dist.is_initialized():
-        dist.init_process_group(backend="gloo")
-    box = [RcclComm.unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(box, src=0)
-    comm = RcclComm(rank, world, box[0], device)
-    comm.device_collectives = True
+    if rdzv is None:
+        from .launch import Rendezvous
+        rdzv = Rendezvous(rank, world)
+    uid = rdzv.bcast(RcclComm.unique_id() if rank == 0 else None)
+    comm = RcclComm(rank, world, uid, device)
+    comm.rdzv = rdzv
     return comm

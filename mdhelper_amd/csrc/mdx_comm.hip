@@ -94,6 +94,22 @@ static int allreduce_host(mdx_comm *c, void *host, int64_t n, ncclDataType_t dt,
     return MDX_OK;
 }
 
+int mdx_comm_count(mdx_comm_t c, int *count, int *rank, int *device)
+{
+    MDX_REQUIRE(c, "NULL communicator");
+    int n = 0, r = 0, d = 0;
+    MDX_NCCL(ncclCommCount(c->comm, &n));
+    MDX_NCCL(ncclCommUserRank(c->comm, &r));
+    MDX_NCCL(ncclCommCuDevice(c->comm, &d));
+    if (count)
+        *count = n;
+    if (rank)
+        *rank = r;
+    if (device)
+        *device = d;
+    return MDX_OK;
+}
+
 int mdx_comm_barrier(mdx_comm_t c)
 {
     MDX_REQUIRE(c, "NULL communicator");

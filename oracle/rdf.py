@@ -136,13 +136,15 @@ def pair_distances(pos1: np.ndarray, pos2: np.ndarray, box) -> np.ndarray:
 
 
 def radial_histogram_ref(pos1, pos2, n_bins, range, dims, *, exclusion=None,
-                         chunk_pairs: int = 4_000_000) -> np.ndarray:
+                         chunk_pairs: int = 4_000_000, i_offset: int = 0) -> np.ndarray:
     """
     int64[n_bins] histogram of in-range ordered pair distances.
 
     Mirrors ``structure.py:92-104``: capped pairs with
     ``range[0] - eps < d <= range[1]``, optional exclusion
     ``i // e0 != j // e1``, then ``numpy.histogram(dist, n_bins, range)``.
+    ``i_offset``: index of ``pos1[0]`` in the full first set when ``pos1`` is a block of its rows
+    (the exclusion rule counts rows of the full set).
     """
     box = check_box(dims)
     ref = np.ascontiguousarray(pos1, dtype=np.float32).reshape(-1, 3)
@@ -165,7 +167,7 @@ def radial_histogram_ref(pos1, pos2, n_bins, range, dims, *, exclusion=None,
              else pair_distances(ref[lo:hi], conf, box))
         keep = (d <= max_cut) & (d > min_cut)
         if exclusion is not None:
-            i_idx = np.arange(lo, hi)
+            i_idx = np.arange(lo, hi) + i_offset
             keep &= (i_idx[:, None] // exclusion[0]) != (j_idx[None, :] // exclusion[1])
         counts += np.histogram(d[keep], bins=n_bins, range=range)[0]
     return counts

@@ -1,0 +1,81 @@
+"""
+The torch-free launcher and rendezvous (mdhelper_amd/launch.py) on CPU: collectives among fresh child
+processes, failure handling, and the sharded analysis drivers at world_size 2 through the launcher +
+SocketComm (device engines replaced by oracle stand-ins IN THE CHILDREN only), equal to a single rank.
+The reference's counterpart: the worker fan-out and parent-side sum of analysis/base.py:385-386,
+491-501 and analysis/structure.py:841-844.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCRIPT = os.path.join(ROOT, "tests", "helpers", "rank_script.py")
+
+
+def test_rendezvous_collectives_three_ranks():
+    from mdhelper_amd import launch
+    rc, text = launch.launch(3, [SCRIPT, "collectives"], share_devices=True, timeout=120)
+    assert rc == 0, text
+    out = launch.last_json_line(text)
+    assert out["uid_ok"] and out["local_rank"] == "0"
+    assert out["ints"] == (np.arange(5) * 6).tolist()
+    assert out["flt"] == [[1.5, -6.0]]
+    assert out["max"] == [2.0, 0.0]
+    assert out["names"] == "r0;r1;r2;"
+    assert out["big"] == 300_000 * 6.0
+
+
+def test_launcher_stops_the_job_when_a_rank_fails():
+    from mdhelper_amd import launch
+    # rank 1 exits with code 3 while rank 0 sits in a collective: the job must end, non-zero, promptly
+    # (either the launcher sees rank 1's code first, or rank 0 sees the service go away and fails)
+    rc, _text = launch.launch(2, [SCRIPT, "fail"], share_devices=True, timeout=120)
+    assert rc in (1, 3)
+
+
+def test_launcher_refuses_more_ranks_than_devices():
+    from mdhelper_amd import _lib, launch
+    n = _lib.device_count()
+    ranks = max(2, n + 1)
+    with pytest.raises(RuntimeError, match=rf"only {n} HIP device"):
+        launch.launch(ranks, [SCRIPT, "collectives"])
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks)],
+                         capture_output=True, text=True, timeout=300,
+                         env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert out.returncode != 0 and f"only {n} HIP device" in out.stderr and out.stdout.strip() == ""
+
+
+def test_world_size_2_through_the_launcher_matches_single_rank(tmp_path):
+    from mdhelper_amd import launch
+    rc, text = launch.launch(2, [SCRIPT, "analyses", str(tmp_path)], share_devices=True, timeout=600)
+    assert rc == 0 and launch.last_json_line(text) == {"done": True}
+    rc, _ = launch.launch(1, [SCRIPT, "analyses", str(tmp_path / "one")], share_devices=True, timeout=600) \
+        if (tmp_path / "one").mkdir() is None else (1, "")
+    assert rc == 0
+    single = np.load(tmp_path / "one" / "rank0.npz")
+    for rank in range(2):
+        got = np.load(tmp_path / f"rank{rank}.npz")
+        for name in ("counts", "counts_slow", "counts_com"):
+            assert np.array_equal(got[name], single[name]), name          # integer sums: bit-exact
+        for name in ("rdf", "ssf", "cisf", "iisf", "msd_self", "msd_cross", "acf", "ssf_res", "cisf_res",
+                     "iisf_res"):
+            assert np.allclose(got[name], single[name], rtol=1e-9, atol=1e-10), name
+    assert single["counts"].sum() > 0
+
+
+def test_rendezvous_under_torch_distributed_run():
+    """The driver's launch line: no MDX_RDZV_KEY, the key comes from the agent's pid and MASTER_PORT."""
+    port = 29600 + os.getpid() % 1000
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MDX_RDZV_KEY")}
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), SCRIPT, "collectives"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    from mdhelper_amd import launch
+    res = launch.last_json_line(out.stdout)
+    assert res["uid_ok"] and res["ints"] == (np.arange(5) * 3).tolist() and res["names"] == "r0;r1;"
