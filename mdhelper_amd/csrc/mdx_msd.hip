@@ -291,6 +291,8 @@ struct mdx_msd {
     std::vector<int64_t> mol_offsets;               // CSR over the rows of a push_traj call
     DeviceBuffer d_mol_offsets, d_mol_masses, d_mol_total, d_mol_com;
     bool own_fft = false;                           // n_fft = 2^15, 2^16, 2^18..2^20: mdx_msd_fft.hpp
+    bool fused_sums = false;                        // pass A of this shape also forms the per-frame sums
+    DeviceBuffer d_part;                            // its partial-sum records
     int64_t fft_batch_atoms = 0;                    // own transform: particles per batch (0: no batching)
     msdfft::Shape shape;
     DeviceBuffer d_tw, d_pfull;                     // twiddle tables [2][512], full-spectrum sums [B][N]
@@ -327,6 +329,8 @@ static int msd_push_device(mdx_msd *h, int group, const double *d_pos, int64_t n
         const int64_t most = h->fft_batch_atoms > 0 ? std::min(h->fft_batch_atoms, chunk) : chunk;
         const int64_t p_pad_max = ceil_div(ceil_div(most * 3, 2), msdfft::PG) * msdfft::PG;
         MDX_TRY(h->d_spec.ensure(size_t(B) * h->n_fft * p_pad_max * 16));
+        if (h->fused_sums)
+            MDX_TRY(h->d_part.ensure(msdfft::fused_part_bytes(h->shape, (int)p_pad_max, B)));
     } else {
         MDX_TRY(h->d_series.ensure(size_t(chunk) * 3 * B * h->n_fft * 8));
         MDX_TRY(h->d_spec.ensure(size_t(chunk) * 3 * B * h->nc * 16));
@@ -335,8 +339,9 @@ static int msd_push_device(mdx_msd *h, int group, const double *d_pos, int64_t n
     for (int64_t a0 = 0; a0 < count; a0 += chunk) {
         const int64_t c = std::min(chunk, count - a0);
         const int64_t n_elem = c * 3;
-        hipLaunchKernelGGL(msd_sums_kernel, dim3((unsigned)(B * h->t_block)), dim3(192), 0, h->stream,
-                           d_pos, n_total, first + a0, c, zero_dims, h->traj(group), h->dsq(group));
+        if (!h->fused_sums)
+            hipLaunchKernelGGL(msd_sums_kernel, dim3((unsigned)(B * h->t_block)), dim3(192), 0, h->stream,
+                               d_pos, n_total, first + a0, c, zero_dims, h->traj(group), h->dsq(group));
         if (h->own_fft) {
             // tables: half table of W_R1, half table of W_R2, W_N^m for m < R2
             const double2 *tw_r1 = h->d_tw.as<double2>(), *tw_r2 = tw_r1 + msdfft::tw_r1_len(h->shape.r1),
@@ -350,11 +355,13 @@ static int msd_push_device(mdx_msd *h, int group, const double *d_pos, int64_t n
                 const int p_pad = (int)(ceil_div(ceil_div(ne, 2), msdfft::PG) * msdfft::PG);
                 msdfft::launch(h->shape, h->stream, d_pos, n_total, first + a0 + s0, ne, h->t_block, B,
                                zero_dims, p_pad, tw_r1, tw_r2, twN, h->d_spec.as<double2>(),
-                               h->d_pfull.as<double>(), s0 > 0 ? 1 : 0);
+                               h->d_pfull.as<double>(), s0 > 0 ? 1 : 0,
+                               h->fused_sums ? h->d_part.as<double2>() : nullptr, h->traj(group),
+                               h->dsq(group));
             }
             msdfft::launch_fold(h->shape, h->stream, h->d_pfull.as<double>(), B, h->nc, h->power(group));
-            // positions read twice (sums, pass A), Y written and read once
-            h->bytes_moved += c * 3 * B * (2 * h->t_block * 8 + 2 * h->n_fft * 8);
+            // positions read once (twice where the sums are a kernel of their own), Y written and read once
+            h->bytes_moved += c * 3 * B * ((h->fused_sums ? 1 : 2) * h->t_block * 8 + 2 * h->n_fft * 8);
             continue;
         }
         dim3 g1((unsigned)ceil_div(h->n_fft, GT), (unsigned)ceil_div(n_elem, GT), (unsigned)B);
@@ -712,6 +719,7 @@ int mdx_msd_create(mdx_msd_t *out, int dev, int64_t n_frames_block, int n_blocks
         // (MDX_MSD_ROCFFT=1 keeps rocFFT for them too)
         h->shape = msdfft::shape_for(h->n_fft);
         h->own_fft = h->shape.r1 != 0 && !getenv("MDX_MSD_ROCFFT");
+        h->fused_sums = h->own_fft && msdfft::fuses_sums(h->shape) && !getenv("MDX_MSD_NO_FUSED_SUMS");
         if (h->own_fft) {
             const int r1 = h->shape.r1, r2 = h->shape.r2;
             std::vector<double> tw;
@@ -761,7 +769,7 @@ int mdx_msd_destroy(mdx_msd_t h)
     h->fft.destroy();
     for (DeviceBuffer *b : {&h->d_acc, &h->d_traj, &h->d_series, &h->d_spec, &h->d_stage,
                             &h->d_inv_in, &h->d_inv_out, &h->d_f32, &h->d_index, &h->d_prev,
-                            &h->d_image, &h->d_tw, &h->d_pfull, &h->d_masses, &h->d_com_x,
+                            &h->d_image, &h->d_tw, &h->d_pfull, &h->d_part, &h->d_masses, &h->d_com_x,
                             &h->d_shift, &h->d_mol_offsets, &h->d_mol_masses, &h->d_mol_total,
                             &h->d_mol_com})
         b->release();

@@ -12,9 +12,10 @@
 //         16 consecutive coordinates = 128 B per frame row, only the t < T_b rows — the zero
 //         padding is never materialised), R1-point transforms over n1 in LDS, twiddle
 //         W_N^(n2 k1), writes Y[k1][pair group][n2][pair] (8 pairs = 128 B contiguous);
-//       pass B (msd_fft_rows_power_kernel): streams Y once (R2 x 128 B contiguous per step),
-//         R2-point transforms over n2 in LDS, accumulates |Z|^2 over all pairs in registers —
-//         the spectrum itself is never written;
+//       pass B (msd_fft_rows512_power_kernel; msd_fft_rows_power_kernel for 1024-point rows): streams
+//         Y once (R2 x 128 B contiguous per step), R2-point transforms over n2 — first stage on the
+//         registers the loads land in, middle stage in LDS, last stage back in registers —
+//         accumulates |Z|^2 over all pairs in registers: the spectrum itself is never written;
 //   * msd_power_fold_kernel folds the N-point sums into the half spectrum the inverse step uses.
 //
 // One wave owns one transform (radix-8 Stockham stages, a radix-16 last stage for 1024 points,
@@ -26,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 namespace msdfft {
 
@@ -422,6 +424,214 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols400_kernel(
 #undef MDX_COLS400_LOAD
 }
 
+// Pass A for R1 = 400 with the per-frame sums fused in (the separate sums kernel read the positions
+// a second time: 12 GB per 5 000-particle group at C4).
+//
+// A block owns a SUPER GROUP of SG = 8 pair groups (64 pairs = 128 consecutive coordinates = 1 KB of
+// every frame row) and a range of columns; per column it runs the eight pair groups one after the
+// other through the same stage -> transform -> store iteration as msd_fft_cols400_kernel, so what a
+// block reads of one frame is one run of 1 KB.  While a pair group's rows sit in LDS, threads 0..199
+// (one per live row = frame) add up x^2 and the coordinate sums of their row; after the eighth pair
+// group the four sums of a frame leave as ONE 32-byte record part[super group][b][n2][row][4]
+// (1/32 of the bytes read), and msd_partials_reduce_kernel adds the super groups in a fixed order:
+// no atomics, run-to-run reproducible.
+//
+// Everything inside the loop is branch-free on the memory side: rows past the block's last frame and
+// coordinates past the chunk read a valid dummy address and are zeroed when they are staged.  (With
+// exec-masked loads the compiler drained vmcnt at every join — and the older kernel also spilled a few
+// registers to scratch, whose reloads wait for vmcnt(0): every column waited for its own stores.)
+constexpr int SG = 8;              // pair groups per super group
+constexpr int SUMS_ROWS = 200;     // live rows of the 400-point first factor
+
+template <int R2>
+__global__ __launch_bounds__(THREADS, 4) void msd_fft_cols400_fused_kernel(
+    const double *__restrict__ pos, int64_t n_total, int64_t first, int64_t n_elem, int64_t t_block,
+    int zero_dims, int p_pad, const double2 *__restrict__ tw_r1, const double2 *__restrict__ twN,
+    double2 *__restrict__ Y, double2 *__restrict__ part)
+{
+    constexpr int R1 = 400, ZS = R1 + 1, LIVE = R1 / 2;
+    constexpr int LOADS = (LIVE + 31) / 32;     // 7 row rounds
+    constexpr int OUTS = (R1 + 63) / 64;        // 7 line rounds
+    static_assert(LIVE == SUMS_ROWS, "row count of the partial sums");
+    __shared__ double2 zb[PG][ZS];
+    __shared__ double2 s_h[R1];       // exp(-2 pi i m / 400), m < 400
+    __shared__ double2 s_n[R2];       // exp(-2 pi i m / N),  m < R2
+    __shared__ double2 s_acc[LIVE][2];   // running (x^2, x, y, z) sums of the column's rows
+    const int sg = blockIdx.x, b = blockIdx.z;
+    const int n_pg = p_pad / PG;
+    const int pg0 = sg * SG;
+    const int n_q = min(SG, n_pg - pg0);
+    const int n2_count = R2 / int(gridDim.y);
+    const int n2_begin = blockIdx.y * n2_count;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < R1; i += THREADS)
+        s_h[i] = tw_r1[i];
+    for (int i = tid; i < R2; i += THREADS)
+        s_n[i] = twN[i];
+
+    // loads: coordinate s of the pair group, rows row0 + 32 i
+    const int s = tid & 15, row0 = tid >> 4;
+    const double *base = pos + (int64_t(b) * t_block * n_total + first) * 3;
+    const int64_t row_stride = n_total * 3;
+    const int64_t istr = int64_t(32) * R2 * row_stride;       // rows row0 + 32 i -> + i * istr
+    // stores: pair p of line kbase + 64 i
+    const int p = tid & 7, kbase = tid >> 3;
+    const int64_t k1_stride = int64_t(n_pg) * R2 * PG;
+    double2 *out = Y + (int64_t(b) * R1 + kbase) * k1_stride + p;
+
+    // rows of the current iteration: coordinate e = 16 (pg0 + q) + s, column n2
+    const double *cur = base + (int64_t(row0) * R2 + n2_begin) * row_stride + int64_t(pg0) * 16 + s;
+    double x[LOADS];
+    // entry i of (column N2, pair group pg0 + Q) is a live value (else it is staged as zero): the
+    // coordinate lies in the chunk and its dimension is kept, the row exists (row0 + 32 i < 200) and
+    // its frame (row0 + 32 i) R2 + N2 lies in the block.  32-bit tests against two per-thread limits.
+    const int e_lim = int(min<int64_t>(n_elem - int64_t(pg0) * 16 - s, 1 << 20));      // 16 Q < e_lim
+    const int t_lim = int(min<int64_t>(t_block - int64_t(row0) * R2, int64_t(1) << 30));   // 32 i R2 + N2 < t_lim
+    const int i_lim = row0 < LIVE - 32 * (LOADS - 1) ? LOADS : LOADS - 1;                 // i < i_lim
+#define MDX_FUSED_OK(N2, Q, I)                                                               \
+    (16 * (Q) < e_lim && !((zero_dims >> ((pg0 + (Q) + s) % 3)) & 1) && (I) < i_lim &&       \
+     32 * R2 * (I) + (N2) < t_lim)
+    // issue the loads of (column N2, pair group pg0 + Q) from CUR; dead entries read `base`
+#define MDX_FUSED_LOAD(N2, Q, CUR)                                                          \
+    _Pragma("unroll") for (int i = 0; i < LOADS; ++i)                                       \
+    {                                                                                       \
+        const double *q_ = MDX_FUSED_OK(N2, Q, i) ? (CUR) + i * istr : base;                \
+        x[i] = *q_;                                                                         \
+    }
+    MDX_FUSED_LOAD(n2_begin, 0, cur)
+    // Seven placeholder stores into the first iteration's own output slots (overwritten there): the
+    // loop is then entered with the same queue of memory operations as it is re-entered with — seven
+    // loads followed by seven stores — and the compiler's wait for the loads at the top of the loop
+    // becomes vmcnt(7 + ...) on both paths instead of draining the previous iteration's stores.
+    {
+        double2 *o = out + (int64_t(pg0) * R2 + n2_begin) * PG;
+#pragma unroll
+        for (int i = 0; i < OUTS; ++i) {
+            const int k1 = kbase + 64 * i;
+            o[int64_t(k1 < R1 ? 64 * i : 64 * (OUTS - 2)) * k1_stride] = make_double2(0.0, 0.0);
+        }
+    }
+    __syncthreads();
+
+    int n2 = n2_begin, q = 0;
+    const int n_iter = n2_count * n_q;
+    for (int it = 0; it < n_iter; ++it) {
+        {
+            double *dst = reinterpret_cast<double *>(&zb[s >> 1][0]) + (s & 1);
+#pragma unroll
+            for (int i = 0; i < LOADS; ++i)
+                if (row0 + 32 * i < LIVE)
+                    dst[2 * (row0 + 32 * i)] = MDX_FUSED_OK(n2, q, i) ? x[i] : 0.0;
+        }
+        __syncthreads();
+        const bool wrap = q + 1 == n_q;
+        {   // per-frame sums of this pair group's 16 coordinates, every wave taking part: lane pair
+            // (2 r, 2 r + 1) of wave w owns row 32 w + r, the even lane pairs 0..3, the odd one 4..7
+            const int row = 32 * wave + (lane >> 1), half = lane & 1;
+            double c0 = 0.0, c1 = 0.0, c2 = 0.0, d = 0.0;
+            if (row < LIVE) {
+#pragma unroll
+                for (int k = 0; k < PG / 2; ++k) {
+                    const double2 v = zb[4 * half + k][row];
+                    d = fma(v.x, v.x, fma(v.y, v.y, d));
+                    // coordinate 2 pp (+1), pp = 4 half + k, of pair group pg has dimension
+                    // (pg + 2 pp (+1)) % 3 = (pg + 2 half + 2 k (+1)) % 3 (8 = 2 mod 3)
+                    if ((2 * k) % 3 == 0) c0 += v.x; else if ((2 * k) % 3 == 1) c1 += v.x; else c2 += v.x;
+                    if ((2 * k + 1) % 3 == 0) c0 += v.y; else if ((2 * k + 1) % 3 == 1) c1 += v.y; else c2 += v.y;
+                }
+            }
+            // bring (c0, c1, c2) to absolute dimensions: rotate by (pg + 2 half) % 3
+            const int rot = (pg0 + q + 2 * half) % 3;
+            double sx = rot == 0 ? c0 : rot == 1 ? c2 : c1;
+            double sy = rot == 0 ? c1 : rot == 1 ? c0 : c2;
+            double sz = rot == 0 ? c2 : rot == 1 ? c1 : c0;
+            // pairs 0..3 first, then 4..7: the even lane adds its odd neighbour's sums
+            d += __shfl_xor(d, 1);
+            sx += __shfl_xor(sx, 1);
+            sy += __shfl_xor(sy, 1);
+            sz += __shfl_xor(sz, 1);
+            if (half == 0 && row < LIVE) {
+                double2 u = s_acc[row][0], v = s_acc[row][1];
+                if (q == 0)
+                    u = v = make_double2(0.0, 0.0);
+                u.x += d;
+                u.y += sx;
+                v.x += sy;
+                v.y += sz;
+                if (wrap) {
+                    double2 *o = part + (((int64_t(sg) * gridDim.z + b) * R2 + n2) * LIVE + row) * 2;
+                    o[0] = u;
+                    o[1] = v;
+                } else {
+                    s_acc[row][0] = u;
+                    s_acc[row][1] = v;
+                }
+            }
+        }
+        __syncthreads();   // the sums read every pair's rows; the transforms below overwrite them
+        stockham_stage_mixed<R1, 4, 1, true>(zb[wave], s_h, lane, LIVE);
+        stockham_stage_mixed<R1, 4, 4, false>(zb[wave], s_h, lane, R1);
+        stockham_stage_mixed<R1, 5, 16, false>(zb[wave], s_h, lane, R1);
+        stockham_stage_mixed<R1, 5, 80, false>(zb[wave], s_h, lane, R1);
+        // next iteration: the following pair group of this column, else the next column's first
+        // (the last iteration reloads itself).  Issued after the transform: during it the 40
+        // registers of a radix-5 stage leave no room for seven rows in flight.
+        const int q_n = wrap ? 0 : q + 1;
+        const int n2_n = wrap ? min(n2 + 1, n2_begin + n2_count - 1) : n2;
+        cur += wrap ? (n2_n - n2) * row_stride - int64_t(n_q - 1) * 16 : 16;
+        MDX_FUSED_LOAD(n2_n, q_n, cur)
+        __syncthreads();
+        double2 *o = out + (int64_t(pg0 + q) * R2 + n2) * PG;
+#pragma unroll
+        for (int i = 0; i < OUTS; ++i) {
+            // the last round holds lines for kbase < 16 only: the other threads repeat round 5
+            const int ii = (i < OUTS - 1 || kbase + 64 * i < R1) ? i : OUTS - 2;
+            const int k1 = kbase + 64 * ii;
+            // W_N^(n2 k1) = W_R1^(m / R2) * W_N^(m mod R2), m = n2 k1 < N
+            const unsigned m = unsigned(k1) * unsigned(n2);
+            const double2 w = cmul(s_h[m / R2], s_n[m & (R2 - 1)]);
+            o[int64_t(64 * ii) * k1_stride] = cmul(zb[p][k1], w);
+        }
+        __syncthreads();
+        q = q_n;
+        n2 = n2_n;
+    }
+#undef MDX_FUSED_LOAD
+#undef MDX_FUSED_OK
+}
+
+// D[b][t] += sum over the super groups (in order) of the partial x^2 sums, traj[b][t][k] likewise;
+// frame t = row * r2 + n2 of block b.  One thread per (n2, row) record of 32 bytes.
+__global__ __launch_bounds__(256) void msd_partials_reduce_kernel(const double2 *__restrict__ part,
+                                                                  int n_sg, int r2, int64_t t_block,
+                                                                  double *__restrict__ traj,
+                                                                  double *__restrict__ D)
+{
+    const int64_t idx = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    const int64_t per_b = int64_t(r2) * SUMS_ROWS;
+    if (idx >= per_b)
+        return;
+    const int n2 = int(idx / SUMS_ROWS), row = int(idx % SUMS_ROWS);
+    const int64_t t = int64_t(row) * r2 + n2;
+    if (t >= t_block)
+        return;
+    double d = 0.0, x = 0.0, y = 0.0, z = 0.0;
+    for (int sg = 0; sg < n_sg; ++sg) {
+        const double2 *r = part + ((int64_t(sg) * gridDim.y + b) * per_b + idx) * 2;
+        const double2 u = r[0], v = r[1];
+        d += u.x;
+        x += u.y;
+        y += v.x;
+        z += v.y;
+    }
+    const int64_t f = int64_t(b) * t_block + t;
+    D[f] += d;
+    traj[3 * f] += x;
+    traj[3 * f + 1] += y;
+    traj[3 * f + 2] += z;
+}
+
 // Pass A for short first factors, R1 = 64 (n_fft = 2^15, 2^16) and R1 = 16 (2^13, 2^14): a wave
 // transforms NC = 512 / R1 neighbouring columns of its pair at once (one butterfly per lane and
 // stage for R1 = 64; one radix-16 butterfly per column for R1 = 16), so a block still moves 4 096
@@ -576,6 +786,92 @@ __global__ __launch_bounds__(THREADS, R2 == 512 ? 4 : 2) void msd_fft_rows_power
     }
 }
 
+// Pass B for R2 = 512 with the first and the last stage kept out of LDS.  The LDS write path (a
+// ds_write_b128 costs 13 cycles of it per wave) is what bounds the general kernel above: per 64 KB
+// piece it stages 8 values per thread, runs three in-place stages (8 reads + 8 writes each) and reads
+// the result back for the power sums.  Here
+//   * a thread's eight loads ARE the inputs of one first-stage butterfly (pair tid & 7, points
+//     j + 64 r, j = tid >> 3), so stage 1 runs on the registers the loads land in and only its
+//     outputs go to LDS (one barrier; no staging pass);
+//   * stage 2 is the wave-private in-place stage;
+//   * the outputs of stage 3 stay in registers: lane l of wave w holds X[l + 64 r] of pair w and adds
+//     |X|^2 to eight running sums; the eight waves' sums meet once, at the end of the block.
+// LDS traffic per piece: 8 writes + (8 + 7) reads + 8 writes + (8 + 7) reads per thread instead of
+// 32 writes + 24 + 14 + 8 reads; two barriers per piece instead of three.
+template <int R1>
+__global__ __launch_bounds__(THREADS, 4) void msd_fft_rows512_power_kernel(
+    const double2 *__restrict__ Y, int p_pad, const double2 *__restrict__ tw_r2,
+    double *__restrict__ Pfull, int accumulate)
+{
+    constexpr int R2 = 512, ZS = R2 + 1;
+    __shared__ double2 zb[PG][ZS];
+    __shared__ double2 s_tw[R2 / 2];
+    const int k1 = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < R2 / 2; i += THREADS)
+        s_tw[i] = tw_r2[i];
+    const int n_all = p_pad / PG, n_parts = gridDim.z, part = blockIdx.z;
+    const int n_groups = (n_all - part + n_parts - 1) / n_parts;      // groups part, part + n_parts, ...
+    double *pout = Pfull + ((int64_t(part) * gridDim.y + b) * R1 + k1) * R2 + tid;
+    if (n_groups <= 0) {   // more parts than pair groups: this part contributes nothing
+        if (!accumulate)
+            *pout = 0.0;
+        return;
+    }
+    const int64_t g_stride = int64_t(n_parts) * (R2 * PG);
+    const double2 *src = Y + ((int64_t(b) * R1 + k1) * n_all + part) * (R2 * PG) + tid;
+    const int p = tid & 7, j = tid >> 3;
+    double2 v[8];
+    double acc[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        acc[r] = 0.0;
+        v[r] = src[THREADS * r];
+    }
+    __syncthreads();   // twiddle table
+    for (int pg = 0; pg < n_groups; ++pg) {
+        // stage 1 (NS = 1, no twiddles) on the loaded values: butterfly j of pair p -> points 8 j + r
+        dft8(v);
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            zb[p][8 * j + r] = v[r];
+        __syncthreads();
+        {   // the next group's rows are in flight during stages 2 and 3 (the last iteration reloads
+            // its own group: no branch)
+            const int64_t off = int64_t(min(pg + 1, n_groups - 1)) * g_stride;
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                v[r] = src[off + THREADS * r];
+        }
+        stockham_stage<R2, 8, 8, false>(zb[wave], s_tw, lane, R2);
+        {   // stage 3 (NS = 64): butterfly l reads points l + 64 r, output r is X[l + 64 r]
+            double2 u[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                u[r] = zb[wave][lane + 64 * r];
+                if (r)
+                    u[r] = cmul(u[r], tw_at<R2>(s_tw, r * lane));
+            }
+            dft8(u);
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                acc[r] = fma(u[r].x, u[r].x, fma(u[r].y, u[r].y, acc[r]));
+        }
+        __syncthreads();
+    }
+    // the eight waves' sums (one pair index each), added in wave order
+    double *red = reinterpret_cast<double *>(&zb[0][0]);      // 8 x 512 doubles
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        red[wave * R2 + lane + 64 * r] = acc[r];
+    __syncthreads();
+    double total = 0.0;
+#pragma unroll
+    for (int w = 0; w < PG; ++w)
+        total += red[w * R2 + tid];
+    *pout = accumulate ? *pout + total : total;
+}
+
 // P[b][k] += sum over the parts of (Pfull[part][b][k] + Pfull[part][b][N - k]) / 2 for the half
 // spectrum k <= N/2, with Pfull stored as [k1][k2], k = k1 + R1 k2.
 __global__ __launch_bounds__(256) void msd_power_fold_kernel(const double *__restrict__ Pfull,
@@ -640,12 +936,36 @@ inline int rows_parts(const Shape &sh, int n_blocks)
     return parts;
 }
 
+// Shapes whose pass A carries the per-frame sums (x^2 and the coordinate sums of every frame) itself:
+// the caller then skips its own sums kernel and hands `part`, `traj`, `dsq` to launch().
+inline bool fuses_sums(const Shape &sh) { return sh.r1 == 400; }
+inline int fused_super_groups(int p_pad) { return (p_pad / PG + SG - 1) / SG; }
+// bytes of the partial-sum records of one launch: [super group][block][R2][200 rows][4 doubles]
+inline size_t fused_part_bytes(const Shape &sh, int p_pad, int n_blocks)
+{
+    return size_t(fused_super_groups(p_pad)) * n_blocks * sh.r2 * SUMS_ROWS * 32;
+}
+
+// pass B of shape R1 x R2: the register-staged kernel for 512-point rows, the general one for 1024
+template <int R1, int R2>
+inline void launch_rows(dim3 gb, hipStream_t stream, const double2 *Y, int p_pad, const double2 *tw_r2,
+                        double *Pfull, int accumulate)
+{
+    if constexpr (R2 == 512)
+        hipLaunchKernelGGL((msd_fft_rows512_power_kernel<R1>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,
+                           Pfull, accumulate);
+    else
+        hipLaunchKernelGGL((msd_fft_rows_power_kernel<R1, R2>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,
+                           Pfull, accumulate);
+}
+
 // tw_r1 / tw_r2: half tables exp(-2 pi i m / R), m < R / 2; twN: exp(-2 pi i m / N), m < R2
 // One batch of coordinates -> Pfull; accumulate != 0 adds to what earlier batches left there.
 inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64_t n_total,
                    int64_t first, int64_t n_elem, int64_t t_block, int n_blocks, int zero_dims,
                    int p_pad, const double2 *tw_r1, const double2 *tw_r2, const double2 *twN,
-                   double2 *Y, double *Pfull, int accumulate)
+                   double2 *Y, double *Pfull, int accumulate, double2 *part = nullptr,
+                   double *traj = nullptr, double *dsq = nullptr)
 {
     // >= ~1024 blocks of pass A where the batch allows it
     int split = 4;
@@ -656,14 +976,12 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
 #define MDX_MSDFFT_LAUNCH(A, B)                                                                    \
     hipLaunchKernelGGL((msd_fft_cols_kernel<A, B>), ga, dim3(THREADS), 0, stream, pos, n_total, first, \
                        n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y);                          \
-    hipLaunchKernelGGL((msd_fft_rows_power_kernel<A, B>), gb, dim3(THREADS), 0, stream, Y, p_pad,     \
-                       tw_r2, Pfull, accumulate)
+    launch_rows<A, B>(gb, stream, Y, p_pad, tw_r2, Pfull, accumulate)
     if (sh.r1 <= 64) {
 #define MDX_MSDFFT_SMALL(A, B)                                                                           \
     hipLaunchKernelGGL((msd_fft_cols_small_kernel<A, B>), ga, dim3(THREADS), 0, stream, pos, n_total, first, \
                        n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y);                                \
-    hipLaunchKernelGGL((msd_fft_rows_power_kernel<A, B>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,     \
-                       Pfull, accumulate)
+    launch_rows<A, B>(gb, stream, Y, p_pad, tw_r2, Pfull, accumulate)
         if (sh.r1 == 64 && sh.r2 == 512) {
             MDX_MSDFFT_SMALL(64, 512);
         } else if (sh.r1 == 64) {
@@ -674,10 +992,24 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
             MDX_MSDFFT_SMALL(16, 1024);
         }
 #undef MDX_MSDFFT_SMALL
+    } else if (sh.r1 == 400 && part) {
+        // per-frame sums fused into pass A: super groups of SG pair groups, >= ~1024 blocks
+        const int n_sg = fused_super_groups(p_pad);
+        int fsplit = 4;
+        while (fsplit < sh.r2 / 2 && int64_t(n_sg) * fsplit * n_blocks < 1024)
+            fsplit *= 2;
+        hipLaunchKernelGGL((msd_fft_cols400_fused_kernel<512>), dim3((unsigned)n_sg, (unsigned)fsplit, (unsigned)n_blocks),
+                           dim3(THREADS), 0, stream, pos, n_total, first, n_elem, t_block, zero_dims, p_pad,
+                           tw_r1, twN, Y, part);
+        hipLaunchKernelGGL(msd_partials_reduce_kernel,
+                           dim3((unsigned)((int64_t(sh.r2) * SUMS_ROWS + 255) / 256), (unsigned)n_blocks), dim3(256), 0,
+                           stream, part, n_sg, sh.r2, t_block, traj, dsq);
+        hipLaunchKernelGGL((msd_fft_rows512_power_kernel<400>), gb, dim3(THREADS), 0, stream, Y, p_pad,
+                           tw_r2, Pfull, accumulate);
     } else if (sh.r1 == 400) {
         hipLaunchKernelGGL((msd_fft_cols400_kernel<512>), ga, dim3(THREADS), 0, stream, pos, n_total, first,
                            n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y);
-        hipLaunchKernelGGL((msd_fft_rows_power_kernel<400, 512>), gb, dim3(THREADS), 0, stream, Y, p_pad,
+        hipLaunchKernelGGL((msd_fft_rows512_power_kernel<400>), gb, dim3(THREADS), 0, stream, Y, p_pad,
                            tw_r2, Pfull, accumulate);
     } else if (sh.r1 == 512 && sh.r2 == 512) {
         MDX_MSDFFT_LAUNCH(512, 512);

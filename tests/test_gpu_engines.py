@@ -519,8 +519,11 @@ def test_msd_own_two_pass_transform_equals_rocfft(case, monkeypatch):
         out[mode] = eng.result()
         eng.close()
     for a, b in zip(out["own"], out["rocfft"]):
+        # the two pipelines add up the per-frame sums D_t in different orders; at the last lags
+        # S_m = (2 sum D - cumulative sums) / (T - m) cancels ~10 digits of them, so a few 1e-10 of
+        # the largest value is the rounding floor of either
         scale = np.abs(b).max()
-        assert np.allclose(a, b, rtol=1e-10, atol=1e-10 * scale)
+        assert np.allclose(a, b, rtol=1e-10, atol=5e-10 * scale)
     # and against the direct definition on a few lags
     msd = out["own"][0][0, 0] / n_atoms
     keep = [k for k in range(3) if not (zero_dims >> k) & 1]
