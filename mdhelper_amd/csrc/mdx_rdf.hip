@@ -461,9 +461,9 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
     size_t base = sizeof(float4) * 256 + sizeof(double) * (h->n_bins + 1);
     const size_t lds_budget = 64 * 1024;
     int n_hist = 4;
-    while (n_hist > 1 && base + size_t(n_hist) * (h->n_bins + 1) * 4 > lds_budget)
+    while (n_hist > 1 && base + size_t(n_hist) * cell_hist_stride(h->n_bins) * 4 > lds_budget)
         n_hist >>= 1;
-    size_t lds = base + size_t(n_hist) * (h->n_bins + 1) * 4;
+    size_t lds = base + size_t(n_hist) * cell_hist_stride(h->n_bins) * 4;
     const bool gh = lds > lds_budget;
     if (gh)
         lds = sizeof(float4) * 256;

@@ -54,6 +54,9 @@ constexpr int CELL_QCAP = 1024;   // surviving j tiles queued per round of the p
 constexpr int CELL_CHUNK = 2;     // particles per j chunk of the second-level cull (2, 4, 8, 16)
 constexpr int CELL_NCHUNK = 64 / CELL_CHUNK;
 constexpr int CELL_TODO = 128;    // per-wave list of pairs waiting for the exact arithmetic
+// Per-wave LDS histogram: n_bins bins and one slot that absorbs a (proven impossible)
+// index n_bins instead of letting it alias the next histogram's bin 0.
+__host__ __device__ constexpr int cell_hist_stride(int n_bins) { return n_bins + 1; }
 
 struct CellGrid {
     int nc[3];
@@ -394,18 +397,74 @@ __device__ inline void cell_step(const CellHot &c, const CellArgs &a, const Hist
                                  float fy, float fz, int tag_i, int tag_j, unsigned i_base,
                                  unsigned j_idx, unsigned w, CellWave &wv)
 {
-    float pos;
-    bool cand, sure;
-    cell_filter<LOWER, TAGS>(c, fx, fy, fz, tag_i, tag_j, pos, cand, sure);
-    // Scalar mask arithmetic (no extra VALU compare for the negation); the wave-uniform test
-    // puts the cold block out of line so the hot path falls through.
-    const unsigned long long m_cand = __builtin_amdgcn_ballot_w64(cand);
-    const unsigned long long m_sure = __builtin_amdgcn_ballot_w64(sure);
-    const unsigned long long m_todo = m_cand & ~m_sure;
+    float r2 = __fmaf_rn(fz, fz, __fmaf_rn(fy, fy, fx * fx));
+    // pos = (sqrt(r2) - r0) / width - eta; raw v_sqrt_f32 (a denormal r2 ends on the exact path).
+    // "Farther than eta from both neighbouring bin edges" is fract(pos) < 1 - 2 eta (see cell_filter).
+    const float pos = __fmaf_rn(__builtin_amdgcn_sqrtf(r2), c.inv_w, c.pos0);
+    const float t = __builtin_amdgcn_fractf(pos);
+    unsigned long long m_todo;
+    if (MODE == 1) {   // global histogram (bin tables too large for LDS): compiler-generated masks
+        bool cand = LOWER ? (r2 < c.cand_hi && r2 >= c.cand_lo) : (r2 < c.cand_hi);
+        if (TAGS)
+            cand = cand && (tag_i != tag_j);
+        const bool sure = t < c.sure_w;
+        m_todo = __builtin_amdgcn_ballot_w64(cand && !sure);
+        if (cand && sure && pos < (float)a.n_bins)
+            hist.add((int)pos, w);
+    } else {
+        // The scalar unit issues one instruction per ~4 cycles per SIMD (scripts/issue_bench.hip), and
+        // the compiler's predication of the add (s_andn2, s_cmp, s_and, s_and_saveexec, s_or exec +
+        // two branches per step) made that unit, not the VALU, the bound of this loop.  Hand-placed:
+        // the candidate test narrows EXEC itself (v_cmpx), the undecided test is one compare inside
+        // it, the sure lanes are what is left, and EXEC is restored once — two scalar instructions.
+        // EXEC is all ones here: every call site sits in wave-uniform control flow of full waves.
+        const unsigned hbase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned *)hist.h;
+        unsigned tmp;
+        if (LOWER && TAGS)
+            asm volatile("v_cmpx_gt_f32_e32 %[hi], %[r2]\n\tv_cmpx_le_f32_e32 %[lo], %[r2]\n\tv_cmpx_ne_u32_e32 %[ti], %[tj]\n\t"
+                         "v_cmp_le_f32_e64 %[mt], %[sw], %[t]\n\tv_cvt_i32_f32_e32 %[tmp], %[pos]\n\t"
+                         "s_andn2_b64 exec, exec, %[mt]\n\tv_lshl_add_u32 %[tmp], %[tmp], 2, %[hb]\n\t"
+                         "ds_add_u32 %[tmp], %[w]\n\ts_mov_b64 exec, -1"
+                         : [mt] "=&s"(m_todo), [tmp] "=&v"(tmp)
+                         : [hi] "s"(c.cand_hi), [lo] "s"(c.cand_lo), [r2] "v"(r2), [sw] "s"(c.sure_w), [t] "v"(t),
+                           [pos] "v"(pos), [hb] "v"(hbase), [w] "v"(w), [ti] "v"(tag_i), [tj] "v"(tag_j)
+                         : "memory");
+        else if (LOWER)
+            asm volatile("v_cmpx_gt_f32_e32 %[hi], %[r2]\n\tv_cmpx_le_f32_e32 %[lo], %[r2]\n\t"
+                         "v_cmp_le_f32_e64 %[mt], %[sw], %[t]\n\tv_cvt_i32_f32_e32 %[tmp], %[pos]\n\t"
+                         "s_andn2_b64 exec, exec, %[mt]\n\tv_lshl_add_u32 %[tmp], %[tmp], 2, %[hb]\n\t"
+                         "ds_add_u32 %[tmp], %[w]\n\ts_mov_b64 exec, -1"
+                         : [mt] "=&s"(m_todo), [tmp] "=&v"(tmp)
+                         : [hi] "s"(c.cand_hi), [lo] "s"(c.cand_lo), [r2] "v"(r2), [sw] "s"(c.sure_w), [t] "v"(t),
+                           [pos] "v"(pos), [hb] "v"(hbase), [w] "v"(w)
+                         : "memory");
+        else if (TAGS)
+            asm volatile("v_cmpx_gt_f32_e32 %[hi], %[r2]\n\tv_cmpx_ne_u32_e32 %[ti], %[tj]\n\t"
+                         "v_cmp_le_f32_e64 %[mt], %[sw], %[t]\n\tv_cvt_i32_f32_e32 %[tmp], %[pos]\n\t"
+                         "s_andn2_b64 exec, exec, %[mt]\n\tv_lshl_add_u32 %[tmp], %[tmp], 2, %[hb]\n\t"
+                         "ds_add_u32 %[tmp], %[w]\n\ts_mov_b64 exec, -1"
+                         : [mt] "=&s"(m_todo), [tmp] "=&v"(tmp)
+                         : [hi] "s"(c.cand_hi), [r2] "v"(r2), [sw] "s"(c.sure_w), [t] "v"(t), [pos] "v"(pos),
+                           [hb] "v"(hbase), [w] "v"(w), [ti] "v"(tag_i), [tj] "v"(tag_j)
+                         : "memory");
+        else
+            asm volatile("v_cmpx_gt_f32_e32 %[hi], %[r2]\n\t"
+                         "v_cmp_le_f32_e64 %[mt], %[sw], %[t]\n\tv_cvt_i32_f32_e32 %[tmp], %[pos]\n\t"
+                         "s_andn2_b64 exec, exec, %[mt]\n\tv_lshl_add_u32 %[tmp], %[tmp], 2, %[hb]\n\t"
+                         "ds_add_u32 %[tmp], %[w]\n\ts_mov_b64 exec, -1"
+                         : [mt] "=&s"(m_todo), [tmp] "=&v"(tmp)
+                         : [hi] "s"(c.cand_hi), [r2] "v"(r2), [sw] "s"(c.sure_w), [t] "v"(t), [pos] "v"(pos),
+                           [hb] "v"(hbase), [w] "v"(w)
+                         : "memory");
+    }
+    // An undecided pair is not evaluated here, a lane or two at a time with fp64 temporaries in the
+    // middle of the hot loop: it is appended to the wave's list in LDS (slot = list length + rank
+    // among the undecided lanes; the length lives in a scalar register) and cell_flush evaluates the
+    // list 64 pairs at a time.
     if (__builtin_expect(m_todo != 0ull, 0)) {
         const unsigned cnt = (unsigned)__popcll(m_todo);
         if (wv.n_todo + cnt <= (unsigned)CELL_TODO) {
-            if (cand && !sure) {
+            if ((m_todo >> (threadIdx.x & 63u)) & 1ull) {
                 const unsigned rank = __builtin_amdgcn_mbcnt_hi(
                     (unsigned)(m_todo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_todo, 0u));
                 // i index = (wave-uniform base of the half tile) + lane, formed only here
@@ -419,10 +478,6 @@ __device__ inline void cell_step(const CellHot &c, const CellArgs &a, const Hist
             wv.overflow = 1u;
         }
     }
-    if (MODE == 1)   // global histogram: no spare slot behind the last bin
-        cand = cand && pos < (float)a.n_bins;
-    if (cand && sure)
-        hist.add((int)pos, w);
 }
 
 // Exact arithmetic for the listed pairs, 64 at a time, one per lane (the list is wave-private).
@@ -498,7 +553,7 @@ __device__ inline void cell_slow_unit(const CellHot &c, const CellArgs &a, const
 }
 
 template <bool EXCL, bool LOWER, int MODE, bool TRI = false>
-__global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
+__global__ __launch_bounds__(256, TRI ? 4 : 6) void rdf_cell_pair_kernel(CellArgs a)
 {
     constexpr bool GH = MODE == 1;
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -530,7 +585,7 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
     if (!GH) {
         for (int b = tid; b <= a.n_bins; b += 256)
             sT[b] = a.thresh[b];
-        for (int b = tid; b < a.n_hist * (a.n_bins + 1); b += 256)
+        for (int b = tid; b < a.n_hist * cell_hist_stride(a.n_bins); b += 256)
             sh[b] = 0u;
     }
     if (tid == 0) {
@@ -609,7 +664,7 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
     const double *thr = GH ? a.thresh : sT;
     // per-wave histograms of n_bins + 1 slots: the extra slot absorbs a (proven impossible,
     // DESIGN.md §4.2) index n_bins instead of letting it alias the next histogram's bin 0
-    HistLds hl{sh + (GH ? 0 : (wave % a.n_hist) * (a.n_bins + 1))};
+    HistLds hl{sh + (GH ? 0 : (wave % a.n_hist) * cell_hist_stride(a.n_bins))};
     HistGlobal hg{out};
 
     const float4 *PW1 = a.pw1 + int64_t(frame) * a.n1p + int64_t(I) * 128;
@@ -784,7 +839,8 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const bool diag = a.self && Jt <= 2 * I + 1;
-            const unsigned w = (a.self && !diag) ? 2u : 1u;
+            unsigned w = (a.self && !diag) ? 2u : 1u;
+            asm volatile("" : "+v"(w));   // the add's data operand: one VGPR per tile, not a v_mov per step
             const unsigned jbase = unsigned(Jt) * 64u;
             // exclusion tags can only collide inside the diagonal tiles when exclusion == (1, 1)
             const bool tags = EXCL && (a.tags_everywhere || diag);
@@ -895,7 +951,7 @@ __global__ __launch_bounds__(256) void rdf_cell_pair_kernel(CellArgs a)
         for (int b = tid; b < a.n_bins; b += 256) {
             unsigned long long s = 0;
             for (int h = 0; h < a.n_hist; ++h)
-                s += sh[h * (a.n_bins + 1) + b];
+                s += sh[h * cell_hist_stride(a.n_bins) + b];
             if (s)
                 atomicAdd(out + b, s);
         }
