@@ -145,6 +145,10 @@ int mdx_rdf_enable_timing(mdx_rdf_t h, int on);
 /* Raw device counters since reset: [0] exact re-evaluations, [1] (64 x 16)-pair units run by
  * the cell kernel, [2] units on its per-pair image-search path, [3] brute-force evaluations. */
 int mdx_rdf_debug_counters(mdx_rdf_t h, int64_t out[4]);
+/* Timing runs (mdx_rdf_enable_timing): the engine clock the cell-sorted pair kernel actually ran
+ * at since reset, in Hz — every block adds its span in s_memtime and in 100 MHz s_memrealtime
+ * ticks; 0 when no such kernel has run. */
+int mdx_rdf_kernel_clock(mdx_rdf_t h, double *hz);
 /* Cell path: the sorted copies (wrapped and original float4 rows, n_pad rows) of one frame of
  * the most recent slab — for debugging the tile logic on the host. */
 int mdx_rdf_debug_sorted(mdx_rdf_t h, int64_t frame, int64_t n_pad, float *pw, float *po);
@@ -326,6 +330,16 @@ int mdx_msd_push_f32(mdx_msd_t h, int group, const float *pos, int64_t n_frames,
                      int unwrap, const double *dims, int zero_dims, const double *shift);
 int mdx_msd_system_com_f32(mdx_msd_t h, const float *pos, int64_t n_frames, int64_t n_sel,
                            const double *masses, int unwrap, const double *dims, int wrap, double *out);
+/* ... and for float64 frames (an in-memory float64 trajectory: the reference's positions are the
+ * float64 copies of transport.py:978); same stages, the unwrap state kept in float64. */
+int mdx_msd_push_f64(mdx_msd_t h, int group, const double *pos, int64_t n_frames, int64_t n_sel,
+                     int unwrap, const double *dims, int zero_dims, const double *shift);
+int mdx_msd_system_com_f64(mdx_msd_t h, const double *pos, int64_t n_frames, int64_t n_sel,
+                           const double *masses, int unwrap, const double *dims, int wrap, double *out);
+/* With a grouping declared (mdx_msd_set_grouping) both mdx_msd_system_com_* variants return the
+ * centre of mass of the molecules' CENTRES (wrapped into the box first when wrap != 0), each
+ * weighted with its molecule's mass: Onsager(center=True, center_atom=False, center_wrap=True)
+ * with residue / segment groupings (transport.py:1004-1014). */
 
 #ifdef __cplusplus
 }

@@ -246,9 +246,12 @@ class RdfEngine(_Engine):
         check(lib().mdx_rdf_stats(self.handle, byref(n), byref(ms), byref(pe), byref(px), byref(pc)))
         raw = np.zeros(4, dtype=np.int64)
         check(lib().mdx_rdf_debug_counters(self.handle, _ptr(raw)))
+        hz = c_double()
+        check(lib().mdx_rdf_kernel_clock(self.handle, byref(hz)))
         return {"launches": n.value, "kernel_ms": ms.value, "pairs_evaluated": pe.value,
                 "pairs_exact": px.value, "pairs_computed": pc.value,
-                "cell_units": int(raw[1]), "cell_units_general": int(raw[2])}
+                "cell_units": int(raw[1]), "cell_units_general": int(raw[2]),
+                "clock_hz": hz.value}
 
 
 def radial_histogram_device(pos1, pos2, n_bins, edges, dims, exclusion=None, dev=0):
@@ -456,24 +459,29 @@ class MsdEngine(_Engine):
         check(lib().mdx_msd_set_grouping(self.handle, len(o) - 1, _ptr(o), _ptr(m)))
 
     def push_f32(self, group, positions, *, unwrap_dims=None, zero_dims=0, shift=None):
-        """A group's float32 positions ``[T, n_sel, 3]`` from host memory through the device-side
-        frame preparation (unwrap, molecule centres, shift): ``mdx_msd_push_f32``."""
-        p = np.ascontiguousarray(positions, dtype=np.float32)
+        """A group's float32 (or float64) positions ``[T, n_sel, 3]`` from host memory through the
+        device-side frame preparation (unwrap, molecule centres, shift): ``mdx_msd_push_f32`` /
+        ``mdx_msd_push_f64``."""
+        f64 = np.asarray(positions).dtype == np.float64
+        p = np.ascontiguousarray(positions, dtype=np.float64 if f64 else np.float32)
         d = None if unwrap_dims is None else np.ascontiguousarray(unwrap_dims, dtype=np.float64)[:3]
         sh = None if shift is None else np.ascontiguousarray(shift, dtype=np.float64)
-        check(lib().mdx_msd_push_f32(self.handle, group, _ptr(p), p.shape[0], p.shape[1],
-                                     0 if d is None else 1, _ptr(d), zero_dims, _ptr(sh)))
+        fn = lib().mdx_msd_push_f64 if f64 else lib().mdx_msd_push_f32
+        check(fn(self.handle, group, _ptr(p), p.shape[0], p.shape[1], 0 if d is None else 1, _ptr(d),
+                 zero_dims, _ptr(sh)))
 
     def system_com_f32(self, positions, masses, *, unwrap_dims=None, wrap_dims=None):
-        """float64[T, 3] system centre of mass per frame of float32 positions ``[T, n_sel, 3]``."""
-        p = np.ascontiguousarray(positions, dtype=np.float32)
+        """float64[T, 3] system centre of mass per frame of float32 / float64 positions
+        ``[T, n_sel, 3]``; with a grouping set: of the molecules' (wrapped) centres."""
+        f64 = np.asarray(positions).dtype == np.float64
+        p = np.ascontiguousarray(positions, dtype=np.float64 if f64 else np.float32)
         m = np.ascontiguousarray(masses, dtype=np.float64)
         dims = unwrap_dims if unwrap_dims is not None else wrap_dims
         d = None if dims is None else np.ascontiguousarray(dims, dtype=np.float64)[:3]
         out = np.empty((p.shape[0], 3), dtype=np.float64)
-        check(lib().mdx_msd_system_com_f32(self.handle, _ptr(p), p.shape[0], p.shape[1], _ptr(m),
-                                           0 if unwrap_dims is None else 1, _ptr(d),
-                                           0 if wrap_dims is None else 1, _ptr(out)))
+        fn = lib().mdx_msd_system_com_f64 if f64 else lib().mdx_msd_system_com_f32
+        check(fn(self.handle, _ptr(p), p.shape[0], p.shape[1], _ptr(m), 0 if unwrap_dims is None else 1,
+                 _ptr(d), 0 if wrap_dims is None else 1, _ptr(out)))
         return out
 
     def system_com_traj(self, traj_file, frames, index, masses, *, unwrap_dims=None, wrap_dims=None):

@@ -68,6 +68,7 @@ _SIGNATURES = {
                               POINTER(c_int64)]),
     "mdx_rdf_enable_timing": (c_int, [_vp, c_int]),
     "mdx_rdf_debug_counters": (c_int, [_vp, _vp]),
+    "mdx_rdf_kernel_clock": (c_int, [_vp, POINTER(c_double)]),
     "mdx_rdf_debug_sorted": (c_int, [_vp, c_int64, c_int64, _vp, _vp]),
     "mdx_radial_histogram": (c_int, [c_int, _vp, c_int64, _vp, c_int64, c_int, _vp, _vp, c_int64, c_int64, _vp]),
     # structure factor
@@ -119,6 +120,8 @@ _SIGNATURES = {
     "mdx_msd_push_traj": (c_int, [_vp, c_int, _vp, _vp, c_int64, _vp, c_int64, c_int, _vp, c_int, _vp]),
     "mdx_msd_push_f32": (c_int, [_vp, c_int, _vp, c_int64, c_int64, c_int, _vp, c_int, _vp]),
     "mdx_msd_system_com_f32": (c_int, [_vp, _vp, c_int64, c_int64, _vp, c_int, _vp, c_int, _vp]),
+    "mdx_msd_push_f64": (c_int, [_vp, c_int, _vp, c_int64, c_int64, c_int, _vp, c_int, _vp]),
+    "mdx_msd_system_com_f64": (c_int, [_vp, _vp, c_int64, c_int64, _vp, c_int, _vp, c_int, _vp]),
     "mdx_msd_set_grouping": (c_int, [_vp, c_int64, _vp, _vp]),
     "mdx_msd_result_acf": (c_int, [_vp, _vp]),
     "mdx_msd_system_com_traj": (c_int, [_vp, _vp, _vp, c_int64, _vp, c_int64, _vp, c_int, _vp, c_int, _vp]),

@@ -373,10 +373,27 @@ class Onsager(SerialAnalysisBase):
                     if self._center_atom:
                         shift = system_com(None, self.universe.atoms.masses,
                                            unwrap_dims=unwrap_dims, wrap_dims=wrap_dims)
-                    else:
+                    elif wrap_dims is None or all(gr == "atoms" for gr in self._groupings):
                         shift = system_com(np.concatenate([g.indices for g in self._groups]),
                                            np.concatenate([g.masses for g in self._groups]),
                                            unwrap_dims=unwrap_dims, wrap_dims=wrap_dims)
+                    else:
+                        # wrapped CENTRES of the molecules (reference :1004-1014: wrap(frame) acts on
+                        # the residue / segment centres): per group on the device, mass-weighted here
+                        from .structure import RadialDistributionFunction as _R
+                        num, mass = 0.0, 0.0
+                        for grp, gr in zip(self._groups, self._groupings):
+                            if gr == "atoms":
+                                eng.set_grouping(None, None)
+                                rows, m = grp.indices, np.asarray(grp.masses, dtype=float)
+                            else:
+                                rows, off, m = _R._selection(grp, gr)
+                                eng.set_grouping(off, m)
+                            com = system_com(rows, m, unwrap_dims=unwrap_dims, wrap_dims=wrap_dims)
+                            num = num + com * m.sum()
+                            mass += m.sum()
+                        eng.set_grouping(None, None)
+                        shift = num / mass
                 from .structure import RadialDistributionFunction
                 for g, (grp, gr, (lo, hi)) in enumerate(zip(self._groups, self._groupings, self._own)):
                     if hi <= lo:
@@ -442,18 +459,16 @@ class Onsager(SerialAnalysisBase):
         traj = self._trajectory
         atoms_only = all(g == "atoms" for g in self._groupings)
         # trajectory files: nothing is staged on the host — unwrapping, residue / segment centres
-        # of mass and the removal of the system centre of mass happen on the device.  (Wrapping
-        # the *centres* for the system centre of mass, center_wrap without center_atom, is the
-        # one combination left to the per-frame path.)
-        on_device = atoms_only or not (self._center and self._center_wrap and not self._center_atom)
+        # of mass and the removal of the system centre of mass (of atoms, of group particles, or of
+        # the wrapped molecule centres) happen on the device
         native = getattr(traj, "native", None) is not None
-        # ... and in-memory float32 frames (what an MDAnalysis reader delivers) take the same device
-        # stages whenever there is something to prepare
+        # ... and in-memory float32 frames (what an MDAnalysis reader delivers) or float64 frames take
+        # the same device stages whenever there is something to prepare
         stored = getattr(traj, "_positions", None)
         f32_array = (not native and hasattr(traj, "frame_block") and stored is not None
-                     and stored.dtype == np.float32
+                     and stored.dtype in (np.float32, np.float64)
                      and (self._unwrap or self._center or not atoms_only))
-        self._from_file = bool(on_device and self._fft and (native or f32_array))
+        self._from_file = bool(self._fft and (native or f32_array))
         fast = hasattr(traj, "frame_block") and (self._from_file or (
             atoms_only and not (self._unwrap or self._center)))
         if not fast:

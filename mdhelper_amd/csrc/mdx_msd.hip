@@ -289,6 +289,7 @@ struct mdx_msd {
     DeviceBuffer d_masses, d_com_x, d_shift;        // system centre of mass per frame
     // trajectory-file path with groupings="residues"/"segments": rows sorted molecule by molecule
     std::vector<int64_t> mol_offsets;               // CSR over the rows of a push_traj call
+    double mol_mass = 0.0;                          // total mass of the grouping's molecules
     DeviceBuffer d_mol_offsets, d_mol_masses, d_mol_total, d_mol_com;
     bool own_fft = false;                           // n_fft = 2^15, 2^16, 2^18..2^20: mdx_msd_fft.hpp
     bool fused_sums = false;                        // pass A of this shape also forms the per-frame sums
@@ -387,9 +388,12 @@ static int msd_push_device(mdx_msd *h, int group, const double *d_pos, int64_t n
 // with the same float64 operations (one multiply, one add, no contraction), so the unwrapped
 // trajectory is the one the reference builds.  One thread owns one coordinate and walks the
 // frames of the block in order; the state (x_old, image) persists between blocks.
+// In: float (what an MDAnalysis reader and the trajectory files deliver) or double (in-memory
+// float64 trajectories).
+template <typename In>
 __global__ __launch_bounds__(256) void msd_unwrap_widen_kernel(
-    const float *__restrict__ in, int64_t n_coord, int64_t n_frames, int first_block, int unwrap,
-    double lx, double ly, double lz, float *__restrict__ prev, int *__restrict__ image,
+    const In *__restrict__ in, int64_t n_coord, int64_t n_frames, int first_block, int unwrap,
+    double lx, double ly, double lz, In *__restrict__ prev, int *__restrict__ image,
     double *__restrict__ out, const double *__restrict__ shift /* [n_frames][3] or nullptr */)
 {
     const int64_t e = blockIdx.x * int64_t(256) + threadIdx.x;
@@ -398,10 +402,10 @@ __global__ __launch_bounds__(256) void msd_unwrap_widen_kernel(
     const int k = int(e % 3);
     const double L = k == 0 ? lx : (k == 1 ? ly : lz);
     const double half = 0.5 * L;
-    float x_old = first_block ? in[e] : prev[e];
+    In x_old = first_block ? in[e] : prev[e];
     int img = first_block ? 0 : image[e];
     for (int64_t f = 0; f < n_frames; ++f) {
-        const float x = in[f * n_coord + e];
+        const In x = in[f * n_coord + e];
         double v = (double)x;
         if (unwrap) {
             const double d = __dsub_rn(v, (double)x_old);
@@ -462,9 +466,14 @@ __global__ __launch_bounds__(256) void msd_frame_com_kernel(const double *__rest
 // the engine's stream.
 struct FrameSource {
     virtual ~FrameSource() = default;
+    virtual int elem() const { return 4; }   // bytes per staged coordinate: float32, or float64 frames
     virtual int prepare(mdx_msd *h, int64_t n_sel) = 0;
-    virtual int stage(mdx_msd *h, int64_t a0, int64_t c, int64_t f0, int64_t nf, float *d_out) = 0;
+    virtual int stage(mdx_msd *h, int64_t a0, int64_t c, int64_t f0, int64_t nf, void *d_out) = 0;
 };
+
+// unwrap + widen (+ shift) of one staged block of frames, in the block's element type
+static void msd_launch_unwrap(mdx_msd *h, const FrameSource &src, int64_t n_coord, int64_t nf, int first,
+                              int unwrap, const double *dims, double *d_out, const double *d_shift);
 
 // a trajectory file: listed frames, listed particles (gathered by the unpack kernel)
 struct TrajFrames final : FrameSource {
@@ -486,35 +495,69 @@ struct TrajFrames final : FrameSource {
                           hipMemcpyHostToDevice));
         return MDX_OK;
     }
-    int stage(mdx_msd *h, int64_t a0, int64_t c, int64_t f0, int64_t nf, float *d_out) override
+    int stage(mdx_msd *h, int64_t a0, int64_t c, int64_t f0, int64_t nf, void *d_out) override
     {
-        TrajSelection sel{h->d_index.as<int>() + a0, c, d_out};
+        TrajSelection sel{h->d_index.as<int>() + a0, c, static_cast<float *>(d_out)};
         return t->stage_async(h->dev, h->stream, frames + f0, nf, &sel, 1);
     }
 };
 
-// host memory: float32[n_frames][n_sel][3], the selection already gathered by the caller
-struct HostFrames final : FrameSource {
-    const float *pos;
+// host memory: float32 or float64 [n_frames][n_sel][3], the selection already gathered by the caller
+template <typename In> struct HostFrames final : FrameSource {
+    const In *pos;
     int64_t n_sel;
-    HostFrames(const float *p, int64_t n) : pos(p), n_sel(n) {}
+    HostFrames(const In *p, int64_t n) : pos(p), n_sel(n) {}
+    int elem() const override { return (int)sizeof(In); }
     int prepare(mdx_msd *h, int64_t) override
     {
         MDX_HIP(hipStreamSynchronize(h->stream));
         return MDX_OK;
     }
-    int stage(mdx_msd *h, int64_t a0, int64_t c, int64_t f0, int64_t nf, float *d_out) override
+    int stage(mdx_msd *h, int64_t a0, int64_t c, int64_t f0, int64_t nf, void *d_out) override
     {
-        MDX_HIP(hipMemcpy2DAsync(d_out, size_t(12) * c, pos + (f0 * n_sel + a0) * 3, size_t(12) * n_sel,
-                                 size_t(12) * c, (size_t)nf, hipMemcpyHostToDevice, h->stream));
+        const size_t row = 3 * sizeof(In);
+        MDX_HIP(hipMemcpy2DAsync(d_out, row * c, pos + (f0 * n_sel + a0) * 3, row * n_sel, row * c,
+                                 (size_t)nf, hipMemcpyHostToDevice, h->stream));
         return MDX_OK;
     }
 };
 
+static void msd_launch_unwrap(mdx_msd *h, const FrameSource &src, int64_t n_coord, int64_t nf, int first,
+                              int unwrap, const double *dims, double *d_out, const double *d_shift)
+{
+    const dim3 grid((unsigned)ceil_div(n_coord, 256));
+    const double lx = dims ? dims[0] : 0.0, ly = dims ? dims[1] : 0.0, lz = dims ? dims[2] : 0.0;
+    if (src.elem() == 8)
+        hipLaunchKernelGGL(msd_unwrap_widen_kernel<double>, grid, dim3(256), 0, h->stream,
+                           h->d_f32.as<double>(), n_coord, nf, first, unwrap, lx, ly, lz,
+                           h->d_prev.as<double>(), h->d_image.as<int>(), d_out, d_shift);
+    else
+        hipLaunchKernelGGL(msd_unwrap_widen_kernel<float>, grid, dim3(256), 0, h->stream,
+                           h->d_f32.as<float>(), n_coord, nf, first, unwrap, lx, ly, lz,
+                           h->d_prev.as<float>(), h->d_image.as<int>(), d_out, d_shift);
+}
+
+__global__ void msd_molecule_com_kernel(const double *__restrict__ x, int64_t c, int64_t a0,
+                                        const int64_t *__restrict__ offsets,
+                                        const double *__restrict__ masses,
+                                        const double *__restrict__ total, int64_t m0, int64_t n_mol,
+                                        const double *__restrict__ shift, double *__restrict__ out);
+
+// With a grouping declared (mdx_msd_set_grouping) the selection's rows are particles of molecules and
+// the result is the centre of mass of the molecules' (optionally wrapped) CENTRES, each weighted
+// with its molecule's mass — Onsager(center=True, center_atom=False) with residue / segment
+// groupings (transport.py:1004-1014: wrap(frame) acts on the centres); `masses` is then ignored
+// in favour of the grouping's.
 static int msd_system_com_frames(mdx_msd *h, FrameSource &src, int64_t n_frames, int64_t n_sel,
                                  const double *masses, int unwrap, const double *dims, int wrap,
                                  double *out)
 {
+    const bool molecules = !h->mol_offsets.empty();
+    const int64_t n_mol = molecules ? (int64_t)h->mol_offsets.size() - 1 : 0;
+    if (molecules)
+        MDX_REQUIRE(h->mol_offsets.back() == n_sel,
+                    "%lld particles given, the grouping was defined for %lld", (long long)n_sel,
+                    (long long)h->mol_offsets.back());
     double total = 0.0;
     for (int64_t i = 0; i < n_sel; ++i)
         total += masses[i];
@@ -522,24 +565,35 @@ static int msd_system_com_frames(mdx_msd *h, FrameSource &src, int64_t n_frames,
     MDX_TRY(src.prepare(h, n_sel));
     MDX_TRY(h->d_masses.ensure(size_t(8) * n_sel));
     MDX_HIP(hipMemcpy(h->d_masses.ptr, masses, size_t(8) * n_sel, hipMemcpyHostToDevice));
-    MDX_TRY(h->d_prev.ensure(size_t(n_sel) * 12));
+    const int64_t row_bytes = int64_t(3) * src.elem();
+    MDX_TRY(h->d_prev.ensure(size_t(n_sel) * row_bytes));
     MDX_TRY(h->d_image.ensure(size_t(n_sel) * 12));
-    const int64_t block = std::max<int64_t>(1, std::min<int64_t>(n_frames, (int64_t(64) << 20) / (12 * n_sel)));
-    MDX_TRY(h->d_f32.ensure(size_t(block) * n_sel * 12));
+    const int64_t block = std::max<int64_t>(1, std::min<int64_t>(n_frames, (int64_t(64) << 20) / (row_bytes * n_sel)));
+    MDX_TRY(h->d_f32.ensure(size_t(block) * n_sel * row_bytes));
     MDX_TRY(h->d_com_x.ensure(size_t(block) * n_sel * 24));
     MDX_TRY(h->d_shift.ensure(size_t(24) * n_frames));
     for (int64_t f0 = 0; f0 < n_frames; f0 += block) {
         const int64_t nf = std::min(block, n_frames - f0);
-        MDX_TRY(src.stage(h, 0, n_sel, f0, nf, h->d_f32.as<float>()));
-        hipLaunchKernelGGL(msd_unwrap_widen_kernel, dim3((unsigned)ceil_div(3 * n_sel, 256)), dim3(256),
-                           0, h->stream, h->d_f32.as<float>(), 3 * n_sel, nf, f0 == 0 ? 1 : 0, unwrap,
-                           dims ? dims[0] : 0.0, dims ? dims[1] : 0.0, dims ? dims[2] : 0.0,
-                           h->d_prev.as<float>(), h->d_image.as<int>(), h->d_com_x.as<double>(),
-                           (const double *)nullptr);
-        hipLaunchKernelGGL(msd_frame_com_kernel, dim3((unsigned)nf), dim3(256), 0, h->stream,
-                           h->d_com_x.as<double>(), n_sel, h->d_masses.as<double>(), 1.0 / total, wrap,
-                           dims ? dims[0] : 1.0, dims ? dims[1] : 1.0, dims ? dims[2] : 1.0,
-                           h->d_shift.as<double>() + 3 * f0);
+        MDX_TRY(src.stage(h, 0, n_sel, f0, nf, h->d_f32.ptr));
+        msd_launch_unwrap(h, src, 3 * n_sel, nf, f0 == 0 ? 1 : 0, unwrap, dims, h->d_com_x.as<double>(),
+                          nullptr);
+        if (molecules) {
+            MDX_TRY(h->d_mol_com.ensure(size_t(nf) * n_mol * 24));
+            hipLaunchKernelGGL(msd_molecule_com_kernel, dim3((unsigned)ceil_div(n_mol * 3, 256), (unsigned)nf),
+                               dim3(256), 0, h->stream, h->d_com_x.as<double>(), n_sel, int64_t(0),
+                               h->d_mol_offsets.as<int64_t>(), h->d_mol_masses.as<double>(),
+                               h->d_mol_total.as<double>(), int64_t(0), n_mol, (const double *)nullptr,
+                               h->d_mol_com.as<double>());
+            hipLaunchKernelGGL(msd_frame_com_kernel, dim3((unsigned)nf), dim3(256), 0, h->stream,
+                               h->d_mol_com.as<double>(), n_mol, h->d_mol_total.as<double>(), 1.0 / h->mol_mass,
+                               wrap, dims ? dims[0] : 1.0, dims ? dims[1] : 1.0, dims ? dims[2] : 1.0,
+                               h->d_shift.as<double>() + 3 * f0);
+        } else {
+            hipLaunchKernelGGL(msd_frame_com_kernel, dim3((unsigned)nf), dim3(256), 0, h->stream,
+                               h->d_com_x.as<double>(), n_sel, h->d_masses.as<double>(), 1.0 / total, wrap,
+                               dims ? dims[0] : 1.0, dims ? dims[1] : 1.0, dims ? dims[2] : 1.0,
+                               h->d_shift.as<double>() + 3 * f0);
+        }
         MDX_HIP(hipGetLastError());
     }
     MDX_HIP(hipMemcpyAsync(out, h->d_shift.ptr, size_t(24) * n_frames, hipMemcpyDeviceToHost, h->stream));
@@ -551,7 +605,7 @@ static int msd_system_com_frames(mdx_msd *h, FrameSource &src, int64_t n_frames,
 // their particles (rows a0 .. a0 + c of the selection): sum_a m_a x_a in row order with separate
 // multiply and add, one division — numpy.bincount(weights=m * x) / bincount(weights=m), the
 // reference's center_of_mass (algorithm/molecule.py:300-306) — then the frame's shift.
-__global__ __launch_bounds__(256) void msd_molecule_com_kernel(
+__global__ void msd_molecule_com_kernel(
     const double *__restrict__ x, int64_t c, int64_t a0, const int64_t *__restrict__ offsets,
     const double *__restrict__ masses, const double *__restrict__ total, int64_t m0, int64_t n_mol,
     const double *__restrict__ shift, double *__restrict__ out)
@@ -609,10 +663,11 @@ static int msd_push_frames(mdx_msd *h, int group, FrameSource &src, int64_t n_se
     }
     MDX_TRY(src.prepare(h, n_sel));
     MDX_TRY(h->d_stage.ensure(size_t(T) * chunk * 24));
-    MDX_TRY(h->d_prev.ensure(size_t(chunk) * 12));
+    const int64_t row_bytes = int64_t(3) * src.elem();
+    MDX_TRY(h->d_prev.ensure(size_t(chunk) * row_bytes));
     MDX_TRY(h->d_image.ensure(size_t(chunk) * 12));
-    const int64_t block = std::max<int64_t>(1, std::min<int64_t>(T, (int64_t(64) << 20) / (12 * chunk)));
-    MDX_TRY(h->d_f32.ensure(size_t(block) * chunk * 12));
+    const int64_t block = std::max<int64_t>(1, std::min<int64_t>(T, (int64_t(64) << 20) / (row_bytes * chunk)));
+    MDX_TRY(h->d_f32.ensure(size_t(block) * chunk * row_bytes));
     if (shift) {
         MDX_TRY(h->d_shift.ensure(size_t(24) * T));
         MDX_HIP(hipMemcpy(h->d_shift.ptr, shift, size_t(24) * T, hipMemcpyHostToDevice));
@@ -627,13 +682,10 @@ static int msd_push_frames(mdx_msd *h, int group, FrameSource &src, int64_t n_se
             continue;
         for (int64_t f0 = 0; f0 < T; f0 += block) {
             const int64_t nf = std::min(block, T - f0);
-            MDX_TRY(src.stage(h, a0, c, f0, nf, h->d_f32.as<float>()));
-            hipLaunchKernelGGL(msd_unwrap_widen_kernel, dim3((unsigned)ceil_div(3 * c, 256)),
-                               dim3(256), 0, h->stream, h->d_f32.as<float>(), 3 * c, nf,
-                               f0 == 0 ? 1 : 0, unwrap, dims ? dims[0] : 0.0, dims ? dims[1] : 0.0,
-                               dims ? dims[2] : 0.0, h->d_prev.as<float>(), h->d_image.as<int>(),
-                               h->d_stage.as<double>() + f0 * c * 3,
-                               shift_rows ? h->d_shift.as<double>() + 3 * f0 : (const double *)nullptr);
+            MDX_TRY(src.stage(h, a0, c, f0, nf, h->d_f32.ptr));
+            msd_launch_unwrap(h, src, 3 * c, nf, f0 == 0 ? 1 : 0, unwrap, dims,
+                              h->d_stage.as<double>() + f0 * c * 3,
+                              shift_rows ? h->d_shift.as<double>() + 3 * f0 : nullptr);
             MDX_HIP(hipGetLastError());
         }
         if (!molecules) {
@@ -861,6 +913,9 @@ int mdx_msd_set_grouping(mdx_msd_t h, int64_t n_molecules, const int64_t *offset
     MDX_HIP(hipMemcpy(h->d_mol_masses.ptr, masses, size_t(8) * n_atoms, hipMemcpyHostToDevice));
     MDX_HIP(hipMemcpy(h->d_mol_total.ptr, total.data(), size_t(8) * n_molecules, hipMemcpyHostToDevice));
     h->mol_offsets.assign(offsets, offsets + n_molecules + 1);
+    h->mol_mass = 0.0;
+    for (double m : total)
+        h->mol_mass += m;
     return MDX_OK;
 }
 
@@ -896,7 +951,21 @@ int mdx_msd_system_com_f32(mdx_msd_t h, const float *pos, int64_t n_frames, int6
     MDX_TRY(set_device(h->dev));
     if (n_frames == 0)
         return MDX_OK;
-    HostFrames src(pos, n_sel);
+    HostFrames<float> src(pos, n_sel);
+    return msd_system_com_frames(h, src, n_frames, n_sel, masses, unwrap, dims, wrap, out);
+}
+
+int mdx_msd_system_com_f64(mdx_msd_t h, const double *pos, int64_t n_frames, int64_t n_sel,
+                           const double *masses, int unwrap, const double *dims, int wrap, double *out)
+{
+    MDX_REQUIRE(h && pos && masses && out, "NULL argument");
+    MDX_REQUIRE(n_frames >= 0 && n_sel > 0, "bad size");
+    MDX_REQUIRE((!unwrap && !wrap) || (dims && dims[0] > 0 && dims[1] > 0 && dims[2] > 0),
+                "unwrapping / wrapping needs positive box dimensions");
+    MDX_TRY(set_device(h->dev));
+    if (n_frames == 0)
+        return MDX_OK;
+    HostFrames<double> src(pos, n_sel);
     return msd_system_com_frames(h, src, n_frames, n_sel, masses, unwrap, dims, wrap, out);
 }
 
@@ -915,7 +984,26 @@ int mdx_msd_push_f32(mdx_msd_t h, int group, const float *pos, int64_t n_frames,
     MDX_TRY(set_device(h->dev));
     if (n_sel == 0)
         return MDX_OK;
-    HostFrames src(pos, n_sel);
+    HostFrames<float> src(pos, n_sel);
+    return msd_push_frames(h, group, src, n_sel, unwrap, dims, zero_dims, shift);
+}
+
+int mdx_msd_push_f64(mdx_msd_t h, int group, const double *pos, int64_t n_frames, int64_t n_sel,
+                     int unwrap, const double *dims, int zero_dims, const double *shift)
+{
+    MDX_REQUIRE(h && pos, "NULL argument");
+    MDX_REQUIRE(group >= 0 && group < h->n_groups, "group %d out of range", group);
+    MDX_REQUIRE(zero_dims >= 0 && zero_dims < 8, "zero_dims is a 3-bit mask");
+    const int64_t T = int64_t(h->n_blocks) * h->t_block;
+    MDX_REQUIRE(n_frames >= T, "%lld frames given, the engine needs %lld", (long long)n_frames,
+                (long long)T);
+    MDX_REQUIRE(!unwrap || (dims && dims[0] > 0 && dims[1] > 0 && dims[2] > 0),
+                "unwrapping needs positive box dimensions");
+    MDX_REQUIRE(n_sel >= 0, "negative particle count");
+    MDX_TRY(set_device(h->dev));
+    if (n_sel == 0)
+        return MDX_OK;
+    HostFrames<double> src(pos, n_sel);
     return msd_push_frames(h, group, src, n_sel, unwrap, dims, zero_dims, shift);
 }
 

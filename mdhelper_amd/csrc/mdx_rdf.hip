@@ -509,6 +509,7 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
         a.maxabs_bits = d_misc;
         a.exact_counter = reinterpret_cast<unsigned long long *>(d_misc + 2);
         a.tilepair_counter = reinterpret_cast<unsigned long long *>(d_misc + 4);
+        a.clock_counter = h->timer.enabled ? reinterpret_cast<unsigned long long *>(d_misc + 8) : nullptr;
         a.t_lo = h->t_lo;
         a.t_hi = h->t_hi;
         a.r0 = h->edges.front();
@@ -1169,6 +1170,18 @@ int mdx_rdf_stats(mdx_rdf_t h, int64_t *launches, double *kernel_ms, int64_t *pa
         MDX_HIP(hipMemcpy(&v, h->d_misc.as<unsigned>() + 2, 8, hipMemcpyDeviceToHost));
         *pairs_exact = (int64_t)v;
     }
+    return MDX_OK;
+}
+
+int mdx_rdf_kernel_clock(mdx_rdf_t h, double *hz)
+{
+    MDX_REQUIRE(h && hz, "NULL argument");
+    MDX_TRY(set_device(h->dev));
+    MDX_HIP(hipStreamSynchronize(h->stream));
+    unsigned long long raw[2] = {0, 0};
+    MDX_HIP(hipMemcpy(raw, h->d_misc.as<unsigned>() + 8, sizeof(raw), hipMemcpyDeviceToHost));
+    // s_memrealtime counts at 100 MHz
+    *hz = raw[1] ? double(raw[0]) / double(raw[1]) * 1.0e8 : 0.0;
     return MDX_OK;
 }
 

@@ -40,6 +40,7 @@ struct CellArgs {
     const unsigned *maxabs_bits;
     unsigned long long *exact_counter;
     unsigned long long *tilepair_counter;   // (64 i) x (CELL_CHUNK j) units actually evaluated
+    unsigned long long *clock_counter;      // timing runs: [0] += engine-clock ticks, [1] += 100 MHz ticks
     double t_lo, t_hi, r0, r1;
     int n1p, n2p;                // padded particle counts (multiples of 128)
     int n_bins, n_hist, n_rep;
@@ -578,6 +579,13 @@ __global__ __launch_bounds__(256, TRI ? 4 : 6) void rdf_cell_pair_kernel(CellArg
     const int frame_l = int(q_xcd) * 8 + int(lin & 7u);
     if (frame_l >= a.n_frames)
         return;
+    // timing runs: every block adds its span in engine-clock ticks (s_memtime) and in ticks of the
+    // constant 100 MHz counter (s_memrealtime); the ratio is the clock this kernel actually ran at
+    long long clk0 = 0, rt0 = 0;
+    if (a.clock_counter && tid == 0) {
+        clk0 = clock64();
+        rt0 = wall_clock64();
+    }
     const int frame = frame_l + a.frame0;
     const int I = int(per_xcd - q_xcd * gridDim.x); // 128-particle i tile = two 64-particle halves
     const int t64_2 = a.n2p / 64;
@@ -946,6 +954,10 @@ __global__ __launch_bounds__(256, TRI ? 4 : 6) void rdf_cell_pair_kernel(CellArg
         if (s_exact) atomicAdd(a.exact_counter, (unsigned long long)s_exact);
         if (s_units) atomicAdd(a.tilepair_counter, (unsigned long long)s_units);
         if (s_general) atomicAdd(a.tilepair_counter + 1, (unsigned long long)s_general);
+        if (a.clock_counter) {
+            atomicAdd(a.clock_counter, (unsigned long long)(clock64() - clk0));
+            atomicAdd(a.clock_counter + 1, (unsigned long long)(wall_clock64() - rt0));
+        }
     }
     if (!GH) {
         for (int b = tid; b < a.n_bins; b += 256) {

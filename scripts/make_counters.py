@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""
+Run ON THE GPU BOX (through gpurun): SQ / memory counters of the bench kernels from separate rocprofv3 PMC
+passes (counters only with --kernel-trace, as MI355X_MICROARCH.md prescribes), reduced to the per-unit
+figures bench.py reads back for its roofline objects:
+
+    gpurun_out/counters/counters.json   ->  copy to profiles/counters.json
+    gpurun_out/counters/*_kernel_stats.csv, *_pmc.csv  -> copy to profiles/
+
+Each entry carries the sha256 of the kernel sources it was measured on (bench.source_digest); bench.py
+ignores an entry whose digest differs from the sources it runs.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (source_digest only; nothing touches the GPU in this process)
+
+OUT = os.path.join(ROOT, "gpurun_out", "counters")
+os.makedirs(OUT, exist_ok=True)
+ENV = dict(os.environ, TMPDIR="/tmp")
+
+
+def run_pmc(tag, counters, bench_args):
+    d = os.path.join(OUT, f"{tag}_{'_'.join(counters)[:40]}")
+    cmd = ["rocprofv3", "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", tag,
+           "--", sys.executable, os.path.join(ROOT, "bench.py"), *bench_args]
+    p = subprocess.run(cmd, cwd="/tmp", env=ENV, capture_output=True, text=True, timeout=900)
+    if p.returncode != 0:
+        sys.stderr.write(p.stderr[-2000:])
+        raise SystemExit(f"{tag}: rocprofv3 failed")
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    res = collections.defaultdict(lambda: collections.defaultdict(float))
+    calls = collections.defaultdict(set)
+    dur = collections.defaultdict(float)
+    for path in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
+        with open(path) as fh:
+            for row in csv.DictReader(fh):
+                res[row["Kernel_Name"]][row["Counter_Name"]] += float(row["Counter_Value"])
+                calls[row["Kernel_Name"]].add(row["Dispatch_Id"])
+    for path in glob.glob(f"{d}/**/*kernel_trace.csv", recursive=True):
+        with open(path) as fh:
+            for row in csv.DictReader(fh):
+                dur[row["Kernel_Name"]] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+    with open(os.path.join(OUT, f"{tag}_{'_'.join(counters)[:40]}_pmc.csv"), "w") as fh:
+        fh.write("kernel,dispatches,duration_ns," + ",".join(counters) + "\n")
+        for k in sorted(res, key=lambda k: -dur[k]):
+            fh.write(f"\"{k[:100]}\",{len(calls[k])},{dur[k]:.0f}," + ",".join(f"{res[k][c]:.0f}" for c in counters) + "\n")
+    return json.loads(line), res, calls, dur
+
+
+def run_stats(tag, bench_args):
+    d = os.path.join(OUT, f"{tag}_stats")
+    cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", tag,
+           "--", sys.executable, os.path.join(ROOT, "bench.py"), *bench_args]
+    p = subprocess.run(cmd, cwd="/tmp", env=ENV, capture_output=True, text=True, timeout=900)
+    if p.returncode != 0:
+        sys.stderr.write(p.stderr[-2000:])
+        raise SystemExit(f"{tag}: rocprofv3 --stats failed")
+    for path in glob.glob(f"{d}/**/*kernel_stats.csv", recursive=True):
+        with open(path) as src, open(os.path.join(OUT, f"{tag}_kernel_stats.csv"), "w") as dst:
+            dst.write(src.read())
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    with open(os.path.join(OUT, f"{tag}_bench_under_rocprof.json"), "w") as fh:
+        fh.write(line + "\n")
+    return json.loads(line)
+
+
+def pick(res, needle):
+    for k in res:
+        if needle in k:
+            return k
+    raise SystemExit(f"no kernel matching {needle}")
+
+
+def rdf_entry(tag, workload, frames):
+    args = ["--workload", workload, "--frames", str(frames), "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+            "--no-extras"]
+    out = {}
+    line, res, calls, dur = run_pmc(tag, ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH"], args)
+    k = pick(res, "rdf_cell_pair_kernel")
+    evals = line["roofline"]["work"]["distance_evaluations_per_sec_kernel"] * line["roofline"]["kernel_ms_per_launch"] \
+        * 1e-3 * len(calls[k])
+    steps = evals / 64.0
+    valu = res[k]["SQ_INSTS_VALU"] / steps
+    out.update(valu_per_step=valu, valu_trans_per_step=1.0, valu_plain_per_step=valu - 1.0,
+               salu_per_step=res[k]["SQ_INSTS_SALU"] / steps, lds_per_step=res[k]["SQ_INSTS_LDS"] / steps,
+               branch_per_step=res[k]["SQ_INSTS_BRANCH"] / steps, steps_per_frame=steps / frames)
+    line, res, calls, dur = run_pmc(tag, ["GRBM_GUI_ACTIVE", "SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES"], args)
+    k = pick(res, "rdf_cell_pair_kernel")
+    out.update(clock_hz=res[k]["GRBM_GUI_ACTIVE"] / 8.0 / dur[k] * 1e9,          # summed over the 8 XCDs
+               waves_per_simd=res[k]["SQ_WAVE_CYCLES"] * 4.0 / (1024.0 * res[k]["GRBM_GUI_ACTIVE"] / 8.0) / 4.0 * 4.0)
+    line, res, calls, dur = run_pmc(tag, ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_LDS",
+                                          "SQ_WAIT_INST_LDS"], args)
+    k = pick(res, "rdf_cell_pair_kernel")
+    out.update(lds_bank_conflict_cycles_per_step=res[k]["SQ_LDS_BANK_CONFLICT"] / steps,
+               lds_idx_active_cycles_per_step=res[k]["SQ_LDS_IDX_ACTIVE"] / steps,
+               lds_wait_quadcycles_per_step=res[k]["SQ_WAIT_INST_LDS"] / steps)
+    fetch = write = 0.0
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        line, res, calls, dur = run_pmc(tag, [ctr], args)
+        k = pick(res, "rdf_cell_pair_kernel")
+        if ctr == "FETCH_SIZE":
+            fetch = res[k][ctr] * 1024.0
+        else:
+            write = res[k][ctr] * 1024.0
+    # gfx950: FETCH_SIZE reports half of a wide coalesced read stream -> doubled; WRITE_SIZE exact
+    out.update(hbm_bytes_per_frame=(2.0 * fetch + write) / frames,
+               traffic_source=f"profiles/r02_{tag}_FETCH_SIZE_pmc.csv + r02_{tag}_WRITE_SIZE_pmc.csv "
+                              f"(separate passes, FETCH doubled per MI355X_MICROARCH.md)",
+               source=f"profiles/r02_{tag}_SQ_INSTS_VALU_SQ_INSTS_SALU_SQ_INSTS_LDS_SQ_INS_pmc.csv, "
+                      f"{frames} frames, scripts/make_counters.py",
+               source_digest=bench.source_digest(*bench.RDF_SOURCES))
+    return out
+
+
+def msd_entry(tag):
+    args = ["--workload", "msd", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    total = 0.0
+    per_kernel = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        line, res, calls, dur = run_pmc(tag, [ctr], args)
+        for k in res:
+            if "msd" in k or "msdfft" in k:
+                # warm-up + timed step: two identical passes
+                v = res[k][ctr] * 1024.0 * (2.0 if ctr == "FETCH_SIZE" else 1.0) / 2.0
+                total += v
+                per_kernel[k[:60] + ":" + ctr] = v
+    return dict(hbm_bytes_per_step=total, per_kernel_bytes_per_step=per_kernel,
+                traffic_source=f"profiles/r02_{tag}_FETCH_SIZE_pmc.csv + r02_{tag}_WRITE_SIZE_pmc.csv (separate passes, "
+                               f"FETCH doubled per MI355X_MICROARCH.md)",
+                source_digest=bench.source_digest(*bench.MSD_SOURCES))
+
+
+def main():
+    which = sys.argv[1:] or ["rdf_c2", "rdf_wide", "msd_c4", "stats"]
+    path = os.path.join(OUT, "counters.json")
+    data = {}
+    if os.path.exists(os.path.join(ROOT, "profiles", "counters.json")):
+        with open(os.path.join(ROOT, "profiles", "counters.json")) as fh:
+            data = json.load(fh)
+    if "rdf_c2" in which:
+        data["rdf_c2"] = rdf_entry("rdf_c2", "rdf", 2000)
+    if "rdf_wide" in which:
+        data["rdf_wide"] = rdf_entry("rdf_wide", "rdf_wide", 400)
+    if "msd_c4" in which:
+        data["msd_c4"] = msd_entry("msd_c4")
+    if "stats" in which:
+        run_stats("rdf_c2", ["--frames", "2000", "--steps", "4", "--no-cpu-baseline", "--no-extras"])
+        run_stats("rdf_wide", ["--workload", "rdf_wide", "--frames", "500", "--steps", "2", "--no-cpu-baseline"])
+        run_stats("msd_c4", ["--workload", "msd", "--steps", "3", "--no-cpu-baseline"])
+        run_stats("sq_c3", ["--workload", "sq", "--steps", "5", "--no-cpu-baseline"])
+    with open(path, "w") as fh:
+        json.dump(data, fh, indent=1, sort_keys=True)
+    print(json.dumps(data, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()

@@ -200,11 +200,15 @@ def test_onsager_center_from_file_on_device(tmp_path, mode):
     assert not np.allclose(plain.results.msd_cross, b.results.msd_cross, rtol=1e-3)
 
 
-@pytest.mark.parametrize("mode", ["residues", "mixed, unwrap", "residues, unwrap, center", "segments, center_atom"])
+@pytest.mark.parametrize("mode", ["residues", "mixed, unwrap", "residues, unwrap, center", "segments, center_atom",
+                                  "residues, unwrap, center_wrap", "mixed, center_wrap",
+                                  "segments, unwrap, center_wrap, float64"])
 def test_onsager_molecule_groupings_from_file_on_device(tmp_path, mode):
     """Onsager(groupings="residues"/"segments") on a trajectory file: the float64 centres of mass of
     the unwrapped particles are formed on the device (mdx_msd_set_grouping); equals the per-frame
-    host analysis (center_of_mass with image flags, transport.py:983-1014)."""
+    host analysis (center_of_mass with image flags, transport.py:983-1014).  center_wrap without
+    center_atom: the system centre of mass of the WRAPPED molecule centres (:1004-1014), per group
+    on the device; float64: in-memory float64 frames through mdx_msd_push_f64."""
     import warnings
     from mdhelper_amd.analysis import Onsager
     rng = np.random.default_rng(91)
@@ -237,7 +241,9 @@ def test_onsager_molecule_groupings_from_file_on_device(tmp_path, mode):
         return [u.atoms[:half], u.atoms[half:n_mol * per]], "residues"
 
     kw = dict(temperature=300, n_blocks=2, verbose=False, unwrap=unwrap, center="center" in mode,
-              center_atom="center_atom" in mode)
+              center_atom="center_atom" in mode, center_wrap="center_wrap" in mode)
+    if "float64" in mode:      # an in-memory float64 trajectory takes the device stages too
+        um = mdhelper_amd.ArrayUniverse(stored.astype(np.float64), dims, **kw_u)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         ga, gra = groups(uf)
