@@ -161,6 +161,14 @@ class Onsager(SerialAnalysisBase):
         (a time correlation needs every lag, so frames cannot); the per-group
         accumulators meet in one all-reduce
 
+    One deliberate difference: with ``unwrap=True`` the reference first makes every fragment of the
+    first analysed frame whole (``make_whole`` through the bond graph, transport.py:936-941) before it
+    stores the starting positions.  Bond topologies are not part of this package's AtomGroup surface,
+    so that step is not taken.  Displacements — hence every MSD of atoms and of molecule centres —
+    are unaffected; only ``center=True, center_wrap=True`` with molecule groupings can see it, and
+    only when a molecule is split across the boundary in the first frame (its wrapped centre then
+    starts from the image the stored coordinates imply).
+
     Results: ``results.pairs``, ``results.times``, ``results.msd_cross``
     ``[N_pairs, N_b, N_t]``, ``results.msd_self`` ``[N_g, N_b, N_t]``, ``results.units``;
     then ``results.L_ij``, ``results.L_ii_self``, ``results.D_i``,

@@ -27,6 +27,7 @@
 #include <rocfft/rocfft.h>
 
 #include <map>
+#include <mutex>
 
 using namespace mdx;
 
@@ -41,11 +42,11 @@ namespace {
 
 int rocfft_ready()
 {
-    static bool done = false;
-    if (!done) {
-        MDX_FFT(rocfft_setup());
-        done = true;
-    }
+    static std::once_flag once;
+    static rocfft_status status = rocfft_status_success;
+    std::call_once(once, [] { status = rocfft_setup(); });
+    if (status != rocfft_status_success)
+        return fail(MDX_ERR_ROCFFT, "rocfft_setup failed with rocfft_status %d", (int)status);
     return MDX_OK;
 }
 

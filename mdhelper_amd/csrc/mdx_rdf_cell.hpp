@@ -939,6 +939,22 @@ __global__ __launch_bounds__(256, TRI ? 4 : 6) void rdf_cell_pair_kernel(CellArg
             }   // images
         }
         __syncthreads();   // the queue is reset by the next round
+        // 32-bit LDS bins hold at most (128 i) x (64 CELL_QCAP j) x weight 2 = 2^24 adds of one round;
+        // with more j tiles than one round the bins are flushed to the 64-bit replicas between
+        // rounds, so no count can wrap however large the second set is (it could, silently,
+        // from ~1.6e7 particles with coarse bins)
+        if (!GH && round0 + CELL_QCAP < t64_2) {
+            for (int b = tid; b < a.n_bins; b += 256) {
+                unsigned long long sum = 0;
+                for (int h = 0; h < a.n_hist; ++h) {
+                    sum += sh[h * cell_hist_stride(a.n_bins) + b];
+                    sh[h * cell_hist_stride(a.n_bins) + b] = 0u;
+                }
+                if (sum)
+                    atomicAdd(out + b, sum);
+            }
+            __syncthreads();
+        }
     }
     if (wv.n_todo) {
         if (GH) cell_flush(hot, a, thr, hg, wv, PO1f, PO2);

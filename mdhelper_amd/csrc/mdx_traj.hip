@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cerrno>
 #include <cmath>
+#include <string>
 #include <thread>
 
 namespace mdx {
@@ -506,7 +507,11 @@ int Trajectory::fill_raw(const int64_t *frames, int64_t n, uint8_t *dst) const
 {
     const int64_t per_frame = 12 * n_atoms;
     const int n_threads = (int)std::max<int64_t>(1, std::min<int64_t>(4, (n * per_frame) >> 22));
+    // Workers only record (status, message): mdx_last_error() is thread-local, so the failing
+    // thread's own fail() would be invisible to the caller; the message is restated on the calling
+    // thread after the join.
     std::vector<int> rcs(n_threads, MDX_OK);
+    std::vector<std::string> msgs((size_t)n_threads);
     auto work = [&](int t) {
         for (int64_t i = t; i < n; i += n_threads) {
             const int64_t at = coord_first + frames[i] * frame_stride;
@@ -520,6 +525,7 @@ int Trajectory::fill_raw(const int64_t *frames, int64_t n, uint8_t *dst) const
             }
             if (rc != MDX_OK) {
                 rcs[t] = rc;
+                msgs[size_t(t)] = mdx_last_error();   // this thread's message
                 return;
             }
         }
@@ -534,9 +540,9 @@ int Trajectory::fill_raw(const int64_t *frames, int64_t n, uint8_t *dst) const
         for (std::thread &th : pool)
             th.join();
     }
-    for (int rc : rcs)
-        if (rc != MDX_OK)   // the message was written by the failing thread; restate it here
-            return fail(rc, "trajectory read failed (short file or I/O error)");
+    for (int t = 0; t < n_threads; ++t)
+        if (rcs[t] != MDX_OK)
+            return fail(rcs[t], "%s", msgs[size_t(t)].empty() ? "trajectory read failed" : msgs[size_t(t)].c_str());
     return MDX_OK;
 }
 
