@@ -26,6 +26,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 
@@ -261,6 +262,56 @@ __device__ __forceinline__ void stockham_stage_mixed(double2 *z, const double2 *
     wave_lds_fence();
 }
 
+// One in-place decimation-in-frequency stage of an M-point transform held by one wave: sub-transforms
+// of length MS, radix RADIX.  Butterfly (block, t) reads z[base + t + r MS/RADIX], forms the
+// RADIX-point transform, multiplies output k by W_MS^(t k) and writes it back to THE SAME slot
+// base + t + k MS/RADIX.  A butterfly touches no slot of another one, so the rounds of a stage need
+// no "all loaded before any is stored": one butterfly's RADIX values are all that is live (20 VGPRs
+// for radix 5 where the Stockham stage above holds 40), and no fence is needed between rounds.
+// After the last stage slot p holds X[digit-reversed p] (dif_slot below).  tw[m] = exp(-2 pi i m / M).
+// FIRST: slots >= M / 2 are structurally zero (the zero padding) and are not read.
+template <int M, int MS, int RADIX, bool FIRST>
+__device__ __forceinline__ void dif_stage(double2 *z, const double2 *tw, int lane)
+{
+    constexpr int T = M / RADIX;            // butterflies
+    constexpr int SUB = MS / RADIX;         // butterflies per sub-transform = slot stride
+    constexpr int ROUNDS = (T + 63) / 64;
+#pragma unroll
+    for (int p = 0; p < ROUNDS; ++p) {
+        const int b = lane + 64 * p;
+        if (T % 64 == 0 || b < T) {
+            const int blk = SUB == 1 ? b : b / SUB, t = SUB == 1 ? 0 : b - blk * SUB;
+            double2 *zz = z + blk * MS + t;
+            double2 v[RADIX];
+#pragma unroll
+            for (int r = 0; r < RADIX; ++r)
+                v[r] = (!FIRST || r < RADIX / 2) ? zz[r * SUB] : make_double2(0.0, 0.0);
+            if (RADIX == 5)
+                dft5(v);
+            else if (RADIX == 4)
+                dft4(v);
+            else
+                dft8(v);
+#pragma unroll
+            for (int k = 0; k < RADIX; ++k) {
+                if (k && SUB > 1)
+                    v[k] = cmul(v[k], tw[t * k * (M / MS)]);
+                zz[k * SUB] = v[k];
+            }
+        }
+    }
+    wave_lds_fence();
+}
+
+// slot of X[k] after the stages (4, 4, 5, 5) of a 400-point dif transform: the digits of
+// k = ka + 4 (kb + 4 (kc + 5 kd)) in reverse significance
+__device__ __forceinline__ int dif_slot_400(int k)
+{
+    const int ka = k & 3, kb = (k >> 2) & 3, kq = k >> 4;
+    const int kd = kq / 5, kc = kq - 5 * kd;
+    return 100 * ka + 25 * kb + 5 * kc + kd;
+}
+
 // In-place forward M-point transform of z[0..M) (LDS) by one wave.  tw: exp(-2 pi i m / M),
 // m < M / 2, in LDS (global twiddle loads would share the vmcnt queue with the streaming loads
 // of the callers and make every transform wait for HBM).
@@ -461,8 +512,10 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols400_fused_kernel(
     const int n_pg = p_pad / PG;
     const int pg0 = sg * SG;
     const int n_q = min(SG, n_pg - pg0);
-    const int n2_count = R2 / int(gridDim.y);
-    const int n2_begin = blockIdx.y * n2_count;
+    // column range of this block: gridDim.y need not divide R2 (it is chosen so that the grid is
+    // close to a whole number of rounds of the chip's 512 block slots)
+    const int n2_begin = int(int64_t(blockIdx.y) * R2 / gridDim.y);
+    const int n2_count = int(int64_t(blockIdx.y + 1) * R2 / gridDim.y) - n2_begin;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < R1; i += THREADS)
         s_h[i] = tw_r1[i];
@@ -569,17 +622,19 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols400_fused_kernel(
             }
         }
         __syncthreads();   // the sums read every pair's rows; the transforms below overwrite them
-        stockham_stage_mixed<R1, 4, 1, true>(zb[wave], s_h, lane, LIVE);
-        stockham_stage_mixed<R1, 4, 4, false>(zb[wave], s_h, lane, R1);
-        stockham_stage_mixed<R1, 5, 16, false>(zb[wave], s_h, lane, R1);
-        stockham_stage_mixed<R1, 5, 80, false>(zb[wave], s_h, lane, R1);
         // next iteration: the following pair group of this column, else the next column's first
-        // (the last iteration reloads itself).  Issued after the transform: during it the 40
-        // registers of a radix-5 stage leave no room for seven rows in flight.
+        // (the last iteration reloads itself).  Issued BEFORE the transform so that the rows are in
+        // flight while the block computes (between its transform and the next staging a block
+        // issues nothing new, and the chip's memory queues ran dry during those phases); the
+        // in-place dif stages below keep one butterfly live at a time, which leaves the registers.
         const int q_n = wrap ? 0 : q + 1;
         const int n2_n = wrap ? min(n2 + 1, n2_begin + n2_count - 1) : n2;
         cur += wrap ? (n2_n - n2) * row_stride - int64_t(n_q - 1) * 16 : 16;
         MDX_FUSED_LOAD(n2_n, q_n, cur)
+        dif_stage<R1, 400, 4, true>(zb[wave], s_h, lane);
+        dif_stage<R1, 100, 4, false>(zb[wave], s_h, lane);
+        dif_stage<R1, 25, 5, false>(zb[wave], s_h, lane);
+        dif_stage<R1, 5, 5, false>(zb[wave], s_h, lane);
         __syncthreads();
         double2 *o = out + (int64_t(pg0 + q) * R2 + n2) * PG;
 #pragma unroll
@@ -590,7 +645,7 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols400_fused_kernel(
             // W_N^(n2 k1) = W_R1^(m / R2) * W_N^(m mod R2), m = n2 k1 < N
             const unsigned m = unsigned(k1) * unsigned(n2);
             const double2 w = cmul(s_h[m / R2], s_n[m & (R2 - 1)]);
-            o[int64_t(64 * ii) * k1_stride] = cmul(zb[p][k1], w);
+            o[int64_t(64 * ii) * k1_stride] = cmul(zb[p][dif_slot_400(k1)], w);
         }
         __syncthreads();
         q = q_n;
@@ -928,12 +983,36 @@ inline int tw_r1_len(int r1) { return r1 == 400 ? 400 : r1 / 2; }
 // slots of the chip (with fewer, a block count that is not a multiple of 512 costs a whole extra
 // round: 800 blocks took as long as 1024); Pfull holds one copy per part.
 constexpr int ROWS_PARTS_MAX = 32;
+constexpr int BLOCK_SLOTS = 512;   // two 512-thread blocks per CU (their LDS) x 256 CUs
+
+// A factor f in [lo, hi] for a grid of base * f equal blocks: the smallest one that gives at least
+// four rounds of the chip's block slots and wastes under 3 % of the last round (a grid of 3.7 rounds
+// takes as long as one of 4; with fewer than ~4 rounds the ramp-up and the tail weigh too much), else
+// the one that wastes least.
+inline int slots_split(int64_t base, int lo, int hi)
+{
+    int best = lo;
+    double best_eff = -1.0;
+    for (int f = lo; f <= hi; ++f) {
+        const int64_t blocks = base * f;
+        const int64_t rounds = (blocks + BLOCK_SLOTS - 1) / BLOCK_SLOTS;
+        const double eff = double(blocks) / double(rounds * BLOCK_SLOTS);
+        if (rounds >= 4 && eff >= 0.97)
+            return f;
+        if (eff * (rounds >= 4 ? 1.0 : 0.9) > best_eff) {
+            best_eff = eff * (rounds >= 4 ? 1.0 : 0.9);
+            best = f;
+        }
+    }
+    return best;
+}
+
 inline int rows_parts(const Shape &sh, int n_blocks)
 {
-    int parts = 1;
-    while (int64_t(sh.r1) * n_blocks * parts < 2048 && parts < ROWS_PARTS_MAX)
-        parts *= 2;
-    return parts;
+    const int64_t base = int64_t(sh.r1) * n_blocks;
+    if (base >= 8 * BLOCK_SLOTS)
+        return 1;
+    return slots_split(base, 1, ROWS_PARTS_MAX);
 }
 
 // Shapes whose pass A carries the per-frame sums (x^2 and the coordinate sums of every frame) itself:
@@ -995,9 +1074,7 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
     } else if (sh.r1 == 400 && part) {
         // per-frame sums fused into pass A: super groups of SG pair groups, >= ~1024 blocks
         const int n_sg = fused_super_groups(p_pad);
-        int fsplit = 4;
-        while (fsplit < sh.r2 / 2 && int64_t(n_sg) * fsplit * n_blocks < 1024)
-            fsplit *= 2;
+        const int fsplit = slots_split(int64_t(n_sg) * n_blocks, 8, 64);
         hipLaunchKernelGGL((msd_fft_cols400_fused_kernel<512>), dim3((unsigned)n_sg, (unsigned)fsplit, (unsigned)n_blocks),
                            dim3(THREADS), 0, stream, pos, n_total, first, n_elem, t_block, zero_dims, p_pad,
                            tw_r1, twN, Y, part);
