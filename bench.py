@@ -729,7 +729,7 @@ def run_extras(args, world):
     import copy
     extra = {}
     plan = (("sq", dict(workload="sq", frames=1000, steps=3, warmup=1)),
-            ("msd", dict(workload="msd", frames=None, steps=3, warmup=1)),
+            ("msd", dict(workload="msd", frames=None, steps=6, warmup=1)),
             ("rdf_wide", dict(workload="rdf_wide", frames=1000, steps=2, warmup=1)))
     for name, over in plan:
         a = copy.copy(args)

@@ -202,6 +202,31 @@ __device__ __forceinline__ void dft5(double2 *a)
     a[3] = csub(m2, u2);
 }
 
+// forward 10-point transform, natural order in and out, decimation in frequency: five radix-2
+// butterflies b_n = a_n + a_{n+5}, c_n = (a_n - a_{n+5}) W_10^n, then X[2m] = dft5(b)[m] and
+// X[2m+1] = dft5(c)[m] — everything in place, ten values live.  HALF: a[5..9] are structurally zero.
+template <bool HALF> __device__ __forceinline__ void dft10(double2 *a)
+{
+    const double c1 = 0.80901699437494742410, s1 = 0.58778525229247312917;   // cos, sin(pi/5)
+    const double c2 = 0.30901699437494742410, s2 = 0.95105651629515357212;   // cos, sin(2 pi/5)
+    const double2 w[5] = {make_double2(1.0, 0.0), make_double2(c1, -s1), make_double2(c2, -s2),
+                          make_double2(-c2, -s2), make_double2(-c1, -s1)};
+    double2 b[5], c[5];
+#pragma unroll
+    for (int n = 0; n < 5; ++n) {
+        b[n] = HALF ? a[n] : cadd(a[n], a[n + 5]);
+        const double2 d = HALF ? a[n] : csub(a[n], a[n + 5]);
+        c[n] = n ? cmul(d, w[n]) : d;
+    }
+    dft5(b);
+    dft5(c);
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+        a[2 * m] = b[m];
+        a[2 * m + 1] = c[m];
+    }
+}
+
 // forward 4-point transform, natural order in and out
 __device__ __forceinline__ void dft4(double2 *a)
 {
@@ -290,6 +315,8 @@ __device__ __forceinline__ void dif_stage(double2 *z, const double2 *tw, int lan
                 dft5(v);
             else if (RADIX == 4)
                 dft4(v);
+            else if (RADIX == 10)
+                dft10<FIRST>(v);
             else
                 dft8(v);
 #pragma unroll
@@ -303,13 +330,13 @@ __device__ __forceinline__ void dif_stage(double2 *z, const double2 *tw, int lan
     wave_lds_fence();
 }
 
-// slot of X[k] after the stages (4, 4, 5, 5) of a 400-point dif transform: the digits of
-// k = ka + 4 (kb + 4 (kc + 5 kd)) in reverse significance
+// slot of X[k] after the stages (10, 10, 4) of a 400-point dif transform: the digits of
+// k = ka + 10 (kb + 10 kc) in reverse significance
 __device__ __forceinline__ int dif_slot_400(int k)
 {
-    const int ka = k & 3, kb = (k >> 2) & 3, kq = k >> 4;
-    const int kd = kq / 5, kc = kq - 5 * kd;
-    return 100 * ka + 25 * kb + 5 * kc + kd;
+    const int q1 = k / 10, ka = k - 10 * q1;
+    const int kc = q1 / 10, kb = q1 - 10 * kc;
+    return 40 * ka + 4 * kb + kc;
 }
 
 // In-place forward M-point transform of z[0..M) (LDS) by one wave.  tw: exp(-2 pi i m / M),
@@ -630,11 +657,18 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols400_fused_kernel(
         const int q_n = wrap ? 0 : q + 1;
         const int n2_n = wrap ? min(n2 + 1, n2_begin + n2_count - 1) : n2;
         cur += wrap ? (n2_n - n2) * row_stride - int64_t(n_q - 1) * 16 : 16;
+#ifndef MDX_LOADS_AFTER
         MDX_FUSED_LOAD(n2_n, q_n, cur)
-        dif_stage<R1, 400, 4, true>(zb[wave], s_h, lane);
-        dif_stage<R1, 100, 4, false>(zb[wave], s_h, lane);
-        dif_stage<R1, 25, 5, false>(zb[wave], s_h, lane);
-        dif_stage<R1, 5, 5, false>(zb[wave], s_h, lane);
+#endif
+        // three stages (10, 10, 4) instead of (4, 4, 5, 5): the transform phase is bound by the LDS
+        // write path (a ds_write_b128 costs 13 cycles of it per wave: in-kernel phase timers show the
+        // slowest wave 59 % of an iteration in here), and a stage fewer is 28 instead of 36 writes
+        dif_stage<R1, 400, 10, true>(zb[wave], s_h, lane);
+        dif_stage<R1, 40, 10, false>(zb[wave], s_h, lane);
+        dif_stage<R1, 4, 4, false>(zb[wave], s_h, lane);
+#ifdef MDX_LOADS_AFTER
+        MDX_FUSED_LOAD(n2_n, q_n, cur)
+#endif
         __syncthreads();
         double2 *o = out + (int64_t(pg0 + q) * R2 + n2) * PG;
 #pragma unroll
