@@ -689,20 +689,23 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols400_fused_kernel(
 #undef MDX_FUSED_OK
 }
 
-// D[b][t] += sum over the super groups (in order) of the partial x^2 sums, traj[b][t][k] likewise;
-// frame t = row * r2 + n2 of block b.  One thread per (n2, row) record of 32 bytes.
+// D[b][t] += sum over the super groups (in order) of the partial x^2 sums, traj[b][t][k] likewise.
+// Records are stored [super group][b][group g][f][4 doubles] with f = column * live + row inside the
+// group's `nc` columns; the frame is t = row * r2 + g * nc + column of block b.  One thread per record.
 __global__ __launch_bounds__(256) void msd_partials_reduce_kernel(const double2 *__restrict__ part,
-                                                                  int n_sg, int r2, int64_t t_block,
+                                                                  int n_sg, int r2, int nc, int live,
+                                                                  int64_t t_block,
                                                                   double *__restrict__ traj,
                                                                   double *__restrict__ D)
 {
     const int64_t idx = int64_t(blockIdx.x) * 256 + threadIdx.x;
     const int b = blockIdx.y;
-    const int64_t per_b = int64_t(r2) * SUMS_ROWS;
+    const int fr = nc * live;
+    const int64_t per_b = int64_t(r2 / nc) * fr;
     if (idx >= per_b)
         return;
-    const int n2 = int(idx / SUMS_ROWS), row = int(idx % SUMS_ROWS);
-    const int64_t t = int64_t(row) * r2 + n2;
+    const int g = int(idx / fr), f = int(idx % fr);
+    const int64_t t = int64_t(f % live) * r2 + int64_t(g) * nc + f / live;
     if (t >= t_block)
         return;
     double d = 0.0, x = 0.0, y = 0.0, z = 0.0;
@@ -714,11 +717,11 @@ __global__ __launch_bounds__(256) void msd_partials_reduce_kernel(const double2 
         y += v.x;
         z += v.y;
     }
-    const int64_t f = int64_t(b) * t_block + t;
-    D[f] += d;
-    traj[3 * f] += x;
-    traj[3 * f + 1] += y;
-    traj[3 * f + 2] += z;
+    const int64_t fo = int64_t(b) * t_block + t;
+    D[fo] += d;
+    traj[3 * fo] += x;
+    traj[3 * fo + 1] += y;
+    traj[3 * fo + 2] += z;
 }
 
 // Pass A for short first factors, R1 = 64 (n_fft = 2^15, 2^16) and R1 = 16 (2^13, 2^14): a wave
@@ -794,6 +797,151 @@ __global__ __launch_bounds__(THREADS, 2) void msd_fft_cols_small_kernel(
         __syncthreads();
     }
 #undef MDX_COLS_SMALL_LOAD
+}
+
+// Pass A for the short first factors with the per-frame sums fused in, as msd_fft_cols400_fused_kernel:
+// a block owns a super group of SG pair groups and a range of column groups; per group of NC columns
+// it runs the pair groups one after the other; while a pair group's rows sit in LDS every wave adds
+// up x^2 and the coordinate sums of the 256 frames of the iteration (R1 / 2 live rows x NC columns);
+// one 32-byte record per frame leaves after the last pair group.  Loads are branch-free (dead
+// entries read a valid dummy address and are zeroed when staged), placeholder stores give the loop
+// entry the back edge's queue of memory operations, and W_N^m comes from two short tables
+// (m = 32 a + b) so that the block's LDS stays below half a CU's with the 8 KB of running sums.
+template <int R1, int R2>
+__global__ __launch_bounds__(THREADS, 4) void msd_fft_cols_small_fused_kernel(
+    const double *__restrict__ pos, int64_t n_total, int64_t first, int64_t n_elem, int64_t t_block,
+    int zero_dims, int p_pad, const double2 *__restrict__ tw_r1, const double2 *__restrict__ twN,
+    double2 *__restrict__ Y, double2 *__restrict__ part)
+{
+    static_assert(R1 == 64 || R1 == 16, "supported first factors");
+    constexpr int NC = 512 / R1, ZS = R1 + 1, LIVE = R1 / 2;
+    constexpr int PER = 8;                         // columns per thread on either side
+    constexpr int FR = LIVE * NC;                  // frames of one iteration: 256
+    static_assert(FR == 256, "frames per iteration");
+    __shared__ double2 zb[PG][NC][ZS];
+    __shared__ double2 s_h[R1 / 2];    // exp(-2 pi i m / R1), m < R1 / 2
+    __shared__ double2 s_na[R2 / 32];  // exp(-2 pi i 32 a / N)
+    __shared__ double2 s_nb[32];       // exp(-2 pi i b / N)
+    __shared__ double2 s_acc[FR][2];   // running (x^2, x, y, z) sums of the iteration's frames
+    const int sg = blockIdx.x, b = blockIdx.z;
+    const int n_pg = p_pad / PG;
+    const int pg0 = sg * SG;
+    const int n_q = min(SG, n_pg - pg0);
+    constexpr int NG = R2 / NC;                    // column groups
+    const int g_begin = int(int64_t(blockIdx.y) * NG / gridDim.y);
+    const int g_count = int(int64_t(blockIdx.y + 1) * NG / gridDim.y) - g_begin;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < R1 / 2; i += THREADS)
+        s_h[i] = tw_r1[i];
+    for (int i = tid; i < R2 / 32; i += THREADS)
+        s_na[i] = twN[32 * i];
+    if (tid < 32)
+        s_nb[tid] = twN[tid];
+
+    // loads: coordinate s of the pair group, live row n1, PER consecutive columns from c_in
+    const int s = tid & 15, n1 = (tid >> 4) % LIVE, c_in = (tid >> 4) / LIVE * PER;
+    const double *base = pos + (int64_t(b) * t_block * n_total + first) * 3;
+    const int64_t row_stride = n_total * 3;
+    double *dst = reinterpret_cast<double *>(&zb[s >> 1][c_in][0]) + (s & 1);
+    // stores: pair p, line k1, PER consecutive columns from c_out
+    const int p = tid & 7, k1 = (tid >> 3) % R1, c_out = (tid >> 3) / R1 * PER;
+    double2 *out = Y + ((int64_t(b) * R1 + k1) * n_pg) * R2 * PG + p;
+
+    // frame (n1 R2 + n2 + c_in + i) of coordinate 16 (pg0 + q) + s; 32-bit liveness tests
+    const int e_lim = int(min<int64_t>(n_elem - int64_t(pg0) * 16 - s, 1 << 20));                    // 16 Q < e_lim
+    const int t_lim = int(min<int64_t>(t_block - int64_t(n1) * R2 - c_in, int64_t(1) << 30));        // N2 + i < t_lim
+#define MDX_SF_OK(N2, Q, I) \
+    (16 * (Q) < e_lim && !((zero_dims >> ((pg0 + (Q) + s) % 3)) & 1) && (N2) + (I) < t_lim)
+    const double *cur = base + (int64_t(n1) * R2 + g_begin * NC + c_in) * row_stride + int64_t(pg0) * 16 + s;
+    double x[PER];
+#define MDX_SF_LOAD(N2, Q, CUR)                                                              \
+    _Pragma("unroll") for (int i = 0; i < PER; ++i)                                          \
+    {                                                                                        \
+        const double *q_ = MDX_SF_OK(N2, Q, i) ? (CUR) + i * row_stride : base;              \
+        x[i] = *q_;                                                                          \
+    }
+    MDX_SF_LOAD(g_begin * NC, 0, cur)
+    {   // placeholder stores into the first iteration's own slots (see the 400-point kernel)
+        double2 *o = out + (int64_t(pg0) * R2 + g_begin * NC + c_out) * PG;
+#pragma unroll
+        for (int i = 0; i < PER; ++i)
+            o[int64_t(i) * PG] = make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+
+    int n2 = g_begin * NC, q = 0;
+    const int n_iter = g_count * n_q;
+    for (int it = 0; it < n_iter; ++it) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i)
+            dst[2 * (i * ZS + n1)] = MDX_SF_OK(n2, q, i) ? x[i] : 0.0;
+        __syncthreads();
+        const bool wrap = q + 1 == n_q;
+        {   // per-frame sums of this pair group: lane pair (2 f, 2 f + 1) owns frame f = 32 wave + lane / 2
+            // = (column f / LIVE, row f % LIVE); the even lane pairs 0..3, the odd one 4..7
+            const int f = 32 * wave + (lane >> 1), half = lane & 1;
+            const int col = f / LIVE, row = f % LIVE;
+            double c0 = 0.0, c1 = 0.0, c2 = 0.0, d = 0.0;
+#pragma unroll
+            for (int k = 0; k < PG / 2; ++k) {
+                const double2 v = zb[4 * half + k][col][row];
+                d = fma(v.x, v.x, fma(v.y, v.y, d));
+                if ((2 * k) % 3 == 0) c0 += v.x; else if ((2 * k) % 3 == 1) c1 += v.x; else c2 += v.x;
+                if ((2 * k + 1) % 3 == 0) c0 += v.y; else if ((2 * k + 1) % 3 == 1) c1 += v.y; else c2 += v.y;
+            }
+            const int rot = (pg0 + q + 2 * half) % 3;
+            double sx = rot == 0 ? c0 : rot == 1 ? c2 : c1;
+            double sy = rot == 0 ? c1 : rot == 1 ? c0 : c2;
+            double sz = rot == 0 ? c2 : rot == 1 ? c1 : c0;
+            d += __shfl_xor(d, 1);
+            sx += __shfl_xor(sx, 1);
+            sy += __shfl_xor(sy, 1);
+            sz += __shfl_xor(sz, 1);
+            if (half == 0) {
+                double2 u = s_acc[f][0], v = s_acc[f][1];
+                if (q == 0)
+                    u = v = make_double2(0.0, 0.0);
+                u.x += d;
+                u.y += sx;
+                v.x += sy;
+                v.y += sz;
+                if (wrap) {
+                    double2 *o = part + (((int64_t(sg) * gridDim.z + b) * NG + n2 / NC) * FR + f) * 2;
+                    o[0] = u;
+                    o[1] = v;
+                } else {
+                    s_acc[f][0] = u;
+                    s_acc[f][1] = v;
+                }
+            }
+        }
+        __syncthreads();   // the sums read every pair's rows; the transforms below overwrite them
+        if (R1 == 64) {
+            stockham_stage_batch<R1, NC, 8, 1, true>(&zb[wave][0][0], ZS, s_h, lane, LIVE);
+            stockham_stage_batch<R1, NC, 8, 8, false>(&zb[wave][0][0], ZS, s_h, lane, R1);
+        } else {
+            stockham_stage_batch<R1, NC, 16, 1, true>(&zb[wave][0][0], ZS, s_h, lane, LIVE);
+        }
+        const int q_n = wrap ? 0 : q + 1;
+        const int n2_n = wrap ? min(n2 + NC, (g_begin + g_count - 1) * NC) : n2;
+        cur += wrap ? (n2_n - n2) * row_stride - int64_t(n_q - 1) * 16 : 16;
+        MDX_SF_LOAD(n2_n, q_n, cur)
+        __syncthreads();
+        double2 *o = out + (int64_t(pg0 + q) * R2 + n2 + c_out) * PG;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            // W_N^(n2 k1) = W_R1^(m / R2) * W_N^(m mod R2), m = n2 k1 < N; the second from two tables
+            const unsigned m = unsigned(k1) * unsigned(n2 + c_out + i);
+            const unsigned ml = m & (R2 - 1);
+            const double2 w = cmul(cmul(tw_at<R1>(s_h, int(m / R2)), s_na[ml >> 5]), s_nb[ml & 31]);
+            o[int64_t(i) * PG] = cmul(zb[p][c_out + i][k1], w);
+        }
+        __syncthreads();
+        q = q_n;
+        n2 = n2_n;
+    }
+#undef MDX_SF_LOAD
+#undef MDX_SF_OK
 }
 
 // Pass B.  grid (k1 < R1, blocks of the trajectory), 512 threads; thread = k2 (and k2 + 512).
@@ -1051,12 +1199,14 @@ inline int rows_parts(const Shape &sh, int n_blocks)
 
 // Shapes whose pass A carries the per-frame sums (x^2 and the coordinate sums of every frame) itself:
 // the caller then skips its own sums kernel and hands `part`, `traj`, `dsq` to launch().
-inline bool fuses_sums(const Shape &sh) { return sh.r1 == 400; }
+inline bool fuses_sums(const Shape &sh) { return sh.r1 == 400 || sh.r1 == 64; }   // (16-point factors: trajectories too short to matter)
 inline int fused_super_groups(int p_pad) { return (p_pad / PG + SG - 1) / SG; }
 // bytes of the partial-sum records of one launch: [super group][block][R2][200 rows][4 doubles]
 inline size_t fused_part_bytes(const Shape &sh, int p_pad, int n_blocks)
 {
-    return size_t(fused_super_groups(p_pad)) * n_blocks * sh.r2 * SUMS_ROWS * 32;
+    // records per block: 400-point factor r2 x 200 rows; short factors (r2 / nc groups) x 256 frames = r2 x r1 / 2
+    const size_t per_b = sh.r1 == 400 ? size_t(sh.r2) * SUMS_ROWS : size_t(sh.r2) * (sh.r1 / 2);
+    return size_t(fused_super_groups(p_pad)) * n_blocks * per_b * 32;
 }
 
 // pass B of shape R1 x R2: the register-staged kernel for 512-point rows, the general one for 1024
@@ -1090,7 +1240,25 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
     hipLaunchKernelGGL((msd_fft_cols_kernel<A, B>), ga, dim3(THREADS), 0, stream, pos, n_total, first, \
                        n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y);                          \
     launch_rows<A, B>(gb, stream, Y, p_pad, tw_r2, Pfull, accumulate)
-    if (sh.r1 <= 64) {
+    if (sh.r1 == 64 && part) {
+        // per-frame sums fused into pass A (short first factors)
+        const int n_sg = fused_super_groups(p_pad);
+        const int nc = 512 / sh.r1, ng = sh.r2 / nc;
+        const int fsplit = std::min(ng, slots_split(int64_t(n_sg) * n_blocks, 1, 64));
+        const dim3 gf((unsigned)n_sg, (unsigned)fsplit, (unsigned)n_blocks);
+#define MDX_MSDFFT_SMALL_FUSED(A, B)                                                                              \
+    hipLaunchKernelGGL((msd_fft_cols_small_fused_kernel<A, B>), gf, dim3(THREADS), 0, stream, pos, n_total, first, \
+                       n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y, part);                                  \
+    hipLaunchKernelGGL(msd_partials_reduce_kernel, dim3((unsigned)((int64_t(B) * (A / 2) + 255) / 256),          \
+                       (unsigned)n_blocks), dim3(256), 0, stream, part, n_sg, B, 512 / A, A / 2, t_block, traj, dsq); \
+    launch_rows<A, B>(gb, stream, Y, p_pad, tw_r2, Pfull, accumulate)
+        if (sh.r2 == 512) {
+            MDX_MSDFFT_SMALL_FUSED(64, 512);
+        } else {
+            MDX_MSDFFT_SMALL_FUSED(64, 1024);
+        }
+#undef MDX_MSDFFT_SMALL_FUSED
+    } else if (sh.r1 <= 64) {
 #define MDX_MSDFFT_SMALL(A, B)                                                                           \
     hipLaunchKernelGGL((msd_fft_cols_small_kernel<A, B>), ga, dim3(THREADS), 0, stream, pos, n_total, first, \
                        n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y);                                \
@@ -1114,7 +1282,7 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
                            tw_r1, twN, Y, part);
         hipLaunchKernelGGL(msd_partials_reduce_kernel,
                            dim3((unsigned)((int64_t(sh.r2) * SUMS_ROWS + 255) / 256), (unsigned)n_blocks), dim3(256), 0,
-                           stream, part, n_sg, sh.r2, t_block, traj, dsq);
+                           stream, part, n_sg, sh.r2, 1, SUMS_ROWS, t_block, traj, dsq);
         hipLaunchKernelGGL((msd_fft_rows512_power_kernel<400>), gb, dim3(THREADS), 0, stream, Y, p_pad,
                            tw_r2, Pfull, accumulate);
     } else if (sh.r1 == 400) {
