@@ -514,7 +514,7 @@ __device__ inline void cell_flush(const CellHot &c, const CellArgs &a, const dou
 template <bool LOWER, bool EXCL, typename Hist>
 __device__ inline void cell_slow_unit(const CellHot &c, const CellArgs &a, const double *sT,
                                       const Hist &hist, const float4 *sJw, int j0, int nj,
-                                      unsigned u_mask, bool tags, bool general, const float *geo,
+                                      unsigned u_mask, bool tags, int general, const float *geo,
                                       const float4 &p0, const float4 &p1, const float4 *po1f,
                                       const float4 *po2f, unsigned i_idx0, unsigned jbase,
                                       unsigned w, CellWave &wv)
@@ -526,11 +526,14 @@ __device__ inline void cell_slow_unit(const CellHot &c, const CellArgs &a, const
                 continue;
             const float4 &p = u ? p1 : p0;
             float fx = q.x - p.x, fy = q.y - p.y, fz = q.z - p.z;
-            if (general) {
-                fx = __fmaf_rn(-rintf(fx * geo[3]), geo[0], fx);
-                fy = __fmaf_rn(-rintf(fy * geo[4]), geo[1], fy);
-                fz = __fmaf_rn(-rintf(fz * geo[5]), geo[2], fz);
-            }
+            // the hot loop's arithmetic to the bit (MDX_CELL_GENERAL): the same pairs must come out
+            // undecided here as there
+            if (general & 1)
+                fx = fminf(fabsf(fx), c.L[0] - fabsf(fx));
+            if (general & 2)
+                fy = fminf(fabsf(fy), c.L[1] - fabsf(fy));
+            if (general & 4)
+                fz = fminf(fabsf(fz), c.L[2] - fabsf(fz));
             float pos;
             bool cand, sure;
             cell_filter<LOWER, 0>(c, fx, fy, fz, 0, 0, pos, cand, sure);
@@ -747,8 +750,9 @@ __global__ __launch_bounds__(256, TRI ? 4 : 6) void rdf_cell_pair_kernel(CellArg
                     // L/2 is rejected by the filter (|sep| >= L/2 >= cut) and its true image
                     // component is L - |sep| >= L - reach: when that exceeds the cut it is out
                     // of range under the contract too, so the shifted value is harmless.
+                    // (per dimension: bit k of `general` = this component needs the per-pair search)
                     const float halfL = 0.4999f * Lk;
-                    general |= !(reach < halfL) && !(cut < halfL && reach < Lk - cut - 1e-4f * Lk);
+                    general |= int(!(reach < halfL) && !(cut < halfL && reach < Lk - cut - 1e-4f * Lk)) << k;
                 }
                 code |= unsigned(J) | (unsigned(general) << 28);
                 }
@@ -792,17 +796,20 @@ __global__ __launch_bounds__(256, TRI ? 4 : 6) void rdf_cell_pair_kernel(CellArg
                 sy = -(ib * s_geo[35] + ic * s_geo[38]);
                 sz = -(ic * s_geo[39]);
             } else {
-                gen = int(code >> 28) & 1;
+                gen = int(code >> 28) & 7;
                 sx = float(int((code >> 22) & 3u) - 1) * s_geo[0];
                 sy = float(int((code >> 24) & 3u) - 1) * s_geo[1];
                 sz = float(int((code >> 26) & 3u) - 1) * s_geo[2];
             }
+            // a component that needs no search carries the tile pair's image shift; one that does stays
+            // as wrapped (|difference| < L) and the loop below folds it
             float4 pj = pj_raw;
-            if (!gen) {
+            if (!(gen & 1))
                 pj.x -= sx;
+            if (!(gen & 2))
                 pj.y -= sy;
+            if (!(gen & 4))
                 pj.z -= sz;
-            }
             // second-level cull: lane l tests (j chunk l>>1) x (i half l&1) — 2 CELL_NCHUNK tests
             constexpr unsigned long long SUB_ALL =
                 CELL_NCHUNK == 32 ? ~0ull : ((1ull << (2 * (CELL_NCHUNK & 31))) - 1ull);
@@ -902,34 +909,52 @@ __global__ __launch_bounds__(256, TRI ? 4 : 6) void rdf_cell_pair_kernel(CellArg
                         const int s = __builtin_ctzll(rem) >> 1;
                         const unsigned bits = unsigned(rem >> (2 * s)) & 3u;
                         rem &= ~(3ull << (2 * s));
-                        if (GH) cell_slow_unit<LOWER, EXCL>(hot, a, thr, hg, sJw, CELL_CHUNK * s, CELL_CHUNK, bits, tags, false, s_geo, p0, p1, PO1f, PO2, i_idx0, jbase, w, wv);
-                        else cell_slow_unit<LOWER, EXCL>(hot, a, thr, hl, sJw, CELL_CHUNK * s, CELL_CHUNK, bits, tags, false, s_geo, p0, p1, PO1f, PO2, i_idx0, jbase, w, wv);
+                        if (GH) cell_slow_unit<LOWER, EXCL>(hot, a, thr, hg, sJw, CELL_CHUNK * s, CELL_CHUNK, bits, tags, 0, s_geo, p0, p1, PO1f, PO2, i_idx0, jbase, w, wv);
+                        else cell_slow_unit<LOWER, EXCL>(hot, a, thr, hl, sJw, CELL_CHUNK * s, CELL_CHUNK, bits, tags, 0, s_geo, p0, p1, PO1f, PO2, i_idx0, jbase, w, wv);
                     }
                 }
             } else {
-                // tile pair that straddles half a box: per-pair image search (float32), rare
+                // Tile pair that straddles half a box in the components of `gen`: those components take the
+                // per-pair minimum image, as a magnitude (only the square is used): with both coordinates
+                // wrapped, |f| < L and the image's magnitude is min(|f|, L - |f|) — two instructions where
+                // f - L rint(f / L) takes three; one more rounding of at most 2^-25 L, inside the 4 * 2^-24 L
+                // the bound delta of DESIGN.md §4.2 sets aside for the filter's own arithmetic.  The other
+                // components were shifted with the tile.  One loop per set of components (7), so that a
+                // tile pair straddling in x alone — the common case — pays for x alone.
                 n_units += 2 * CELL_NCHUNK;
                 n_general += 2 * CELL_NCHUNK;
                 const unsigned mark = wv.n_todo;
-#pragma unroll 2
-                for (int jj = 0; jj < 64; ++jj) {
-                    float4 q = sJw[jj];
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const float4 &p = u ? p1 : p0;
-                        float fx = q.x - p.x, fy = q.y - p.y, fz = q.z - p.z;
-                        fx = __fmaf_rn(-rintf(fx * s_geo[3]), s_geo[0], fx);
-                        fy = __fmaf_rn(-rintf(fy * s_geo[4]), s_geo[1], fy);
-                        fz = __fmaf_rn(-rintf(fz * s_geo[5]), s_geo[2], fz);
-                        if (GH) cell_step<LOWER, EXCL ? 1 : 0, MODE>(hot, a, hg, fx, fy, fz, __float_as_int(p.w), __float_as_int(q.w), i_base0 + 64u * u, jbase + jj, w, wv);
-                        else cell_step<LOWER, EXCL ? 1 : 0, MODE>(hot, a, hl, fx, fy, fz, __float_as_int(p.w), __float_as_int(q.w), i_base0 + 64u * u, jbase + jj, w, wv);
-                    }
+#define MDX_CELL_GENERAL(GM)                                                                       \
+    _Pragma("unroll 2") for (int jj = 0; jj < 64; ++jj)                                            \
+    {                                                                                              \
+        float4 q = sJw[jj];                                                                        \
+        asm volatile("" ::"v"(q.w)); /* whole 16-byte read (ds_read_b96 costs twice the cycles) */ \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u)                                              \
+        {                                                                                          \
+            const float4 &p = u ? p1 : p0;                                                         \
+            float fx = q.x - p.x, fy = q.y - p.y, fz = q.z - p.z;                                  \
+            if ((GM) & 1) fx = fminf(fabsf(fx), hot.L[0] - fabsf(fx));                             \
+            if ((GM) & 2) fy = fminf(fabsf(fy), hot.L[1] - fabsf(fy));                             \
+            if ((GM) & 4) fz = fminf(fabsf(fz), hot.L[2] - fabsf(fz));                             \
+            if (GH) cell_step<LOWER, EXCL ? 1 : 0, MODE>(hot, a, hg, fx, fy, fz, __float_as_int(p.w), __float_as_int(q.w), i_base0 + 64u * u, jbase + jj, w, wv); \
+            else cell_step<LOWER, EXCL ? 1 : 0, MODE>(hot, a, hl, fx, fy, fz, __float_as_int(p.w), __float_as_int(q.w), i_base0 + 64u * u, jbase + jj, w, wv); \
+        }                                                                                          \
+    }
+                switch (gen) {
+                case 1: MDX_CELL_GENERAL(1) break;
+                case 2: MDX_CELL_GENERAL(2) break;
+                case 3: MDX_CELL_GENERAL(3) break;
+                case 4: MDX_CELL_GENERAL(4) break;
+                case 5: MDX_CELL_GENERAL(5) break;
+                case 6: MDX_CELL_GENERAL(6) break;
+                default: MDX_CELL_GENERAL(7) break;
                 }
+#undef MDX_CELL_GENERAL
                 if (__builtin_expect(wv.overflow != 0u, 0)) {
                     wv.overflow = 0u;
                     wv.n_todo = mark;
-                    if (GH) cell_slow_unit<LOWER, EXCL>(hot, a, thr, hg, sJw, 0, 64, 3u, true, true, s_geo, p0, p1, PO1f, PO2, i_idx0, jbase, w, wv);
-                    else cell_slow_unit<LOWER, EXCL>(hot, a, thr, hl, sJw, 0, 64, 3u, true, true, s_geo, p0, p1, PO1f, PO2, i_idx0, jbase, w, wv);
+                    if (GH) cell_slow_unit<LOWER, EXCL>(hot, a, thr, hg, sJw, 0, 64, 3u, true, gen, s_geo, p0, p1, PO1f, PO2, i_idx0, jbase, w, wv);
+                    else cell_slow_unit<LOWER, EXCL>(hot, a, thr, hl, sJw, 0, 64, 3u, true, gen, s_geo, p0, p1, PO1f, PO2, i_idx0, jbase, w, wv);
                 }
             }
             if (wv.n_todo >= 64u) {   // enough undecided pairs for a full-width exact pass

@@ -8,11 +8,14 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #define REP16(x) x x x x x x x x x x x x x x x x
+typedef float v2f __attribute__((ext_vector_type(2)));
 template <int MODE>
 __global__ void kern(float *out, long long *clk, int iters)
 {
     float a0 = threadIdx.x, a1 = 1.f, a2 = 2.f, a3 = 3.f, a4 = 4.f, a5 = 5.f, a6 = 6.f, a7 = 7.f;
     float b = 1.0001f, c = 0.5f;
+    v2f p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, p4 = p0 + 1.f, p5 = p1 + 1.f, p6 = p2 + 1.f, p7 = p3 + 1.f;
+    v2f pb = {b, b}, pc = {c, c};
     unsigned s0 = blockIdx.x, s1 = 1, s2 = 2, s3 = 3;
     const long long t0 = clock64(), w0 = wall_clock64();
     for (int i = 0; i < iters; ++i) {
@@ -44,6 +47,18 @@ __global__ void kern(float *out, long long *clk, int iters)
                                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7),
                                  "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3)
                                : "v"(b), "v"(c) : "vcc", "scc");)
+        } else if (MODE == 5) {   // 8 independent v_pk_fma_f32 (two f32 per lane each)
+            REP16(asm volatile("v_pk_fma_f32 %0, %0, %8, %9\n v_pk_fma_f32 %1, %1, %8, %9\n v_pk_fma_f32 %2, %2, %8, %9\n v_pk_fma_f32 %3, %3, %8, %9\n"
+                               "v_pk_fma_f32 %4, %4, %8, %9\n v_pk_fma_f32 %5, %5, %8, %9\n v_pk_fma_f32 %6, %6, %8, %9\n v_pk_fma_f32 %7, %7, %8, %9\n"
+                               : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pb), "v"(pc));)
+        } else if (MODE == 6) {   // 4 v_pk_add_f32 + 4 v_pk_mul_f32
+            REP16(asm volatile("v_pk_add_f32 %0, %0, %8\n v_pk_mul_f32 %1, %1, %9\n v_pk_add_f32 %2, %2, %8\n v_pk_mul_f32 %3, %3, %9\n"
+                               "v_pk_add_f32 %4, %4, %8\n v_pk_mul_f32 %5, %5, %9\n v_pk_add_f32 %6, %6, %8\n v_pk_mul_f32 %7, %7, %9\n"
+                               : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pb), "v"(pc));)
+        } else if (MODE == 7) {   // 4 v_sub_u32 + 4 v_cvt_f32_i32 (fixed-point minimum image)
+            REP16(asm volatile("v_sub_u32 %0, %0, %8\n v_cvt_f32_i32 %1, %0\n v_sub_u32 %2, %2, %8\n v_cvt_f32_i32 %3, %2\n"
+                               "v_sub_u32 %4, %4, %8\n v_cvt_f32_i32 %5, %4\n v_sub_u32 %6, %6, %8\n v_cvt_f32_i32 %7, %6\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));)
         }
     }
     const long long t1 = clock64(), w1 = wall_clock64();
@@ -51,7 +66,8 @@ __global__ void kern(float *out, long long *clk, int iters)
         clk[0] = t1 - t0;
         clk[1] = w1 - w0;
     }
-    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + float(s0 + s1 + s2 + s3);
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + float(s0 + s1 + s2 + s3) +
+        (p0 + p1 + p2 + p3 + p4 + p5 + p6 + p7).x + (p0 + p1 + p2 + p3 + p4 + p5 + p6 + p7).y;
 }
 template <int MODE> void run(const char *name, int n_valu, int n_salu)
 {
@@ -86,5 +102,8 @@ int main()
     run<2>("8 v_fma_f32 + 8 SALU", 8, 8);
     run<3>("hot step 13 VALU", 13, 0);
     run<4>("hot step 13 VALU+10 SALU", 13, 10);
+    run<5>("8 v_pk_fma_f32", 8, 0);
+    run<6>("4 pk_add + 4 pk_mul f32", 8, 0);
+    run<7>("4 v_sub_u32+4 cvt_f32_i32", 8, 0);
     return 0;
 }

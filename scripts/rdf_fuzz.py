@@ -39,6 +39,8 @@ while time.time() < t_end:
         pos = (rng.integers(-3, 40, (F, n1 + n2, 3)) * 0.5 + rng.normal(0, 1e-3, (F, n1 + n2, 3)))
     pos = pos.astype(np.float32)
     r_hi = float(rng.uniform(0.5, 0.5 * float(L.min()) * (0.8 if tri else 1.0)))
+    if not tri and rng.random() < 0.3:   # up to half the cell: tile pairs that straddle L/2 (per-pair image fold)
+        r_hi = 0.5 * float(L.min()) * float(rng.choice([1.0, 0.999, rng.uniform(0.8, 1.0)]))
     r_lo = float(rng.choice([0.0, 0.0, rng.uniform(0, r_hi * 0.5)]))
     n_bins = int(rng.choice([1, 2, 7, 50, 201, 777, 3000]))
     excl = None
@@ -50,7 +52,7 @@ while time.time() < t_end:
     for f in range(F):
         want += c_radial_histogram(p1[f], p1[f] if same else p2[f], n_bins, (r_lo, r_hi), box, exclusion=excl)
     edges = np.linspace(r_lo, r_hi, n_bins + 1)
-    for algo in ("auto", "filter"):
+    for algo in ("auto", "filter", "cell"):
         eng = _core.RdfEngine(edges, excl, algo=algo)
         eng.accumulate(p1, p2, np.tile(box, (F, 1)))
         got = eng.counts()
