@@ -117,6 +117,32 @@ def test_rdf_half_box_separations(algo):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("exclusion", [None, (2, 2)])
+@pytest.mark.parametrize("dims", [(40.0, 40.0, 40.0), (30.0, 75.0, 120.0), (110.0, 31.0, 34.0), (64.0, 100.0, 33.0)])
+def test_rdf_cell_tile_pairs_straddling_half_a_box(dims, exclusion):
+    """Ranges up to half the shortest edge: tile pairs whose separation reaches L/2 in some components
+    take the per-pair image fold in exactly those components (mdx_rdf_cell.hpp, MDX_CELL_GENERAL); the
+    elongated cells make every subset of components occur (long edges never straddle)."""
+    rng = np.random.default_rng(31)
+    box = np.array([*dims, 90, 90, 90], dtype=np.float32)
+    pos = (rng.random((6000, 3)) * box[:3]).astype(np.float32)
+    pos[:300] -= box[:3] * np.array([1, 2, -1], dtype=np.float32)      # unwrapped images
+    other = (rng.random((1500, 3)) * box[:3]).astype(np.float32)
+    half = 0.5 * float(min(dims))
+    for rng_range, nb in [((0.0, half), 201), ((0.0, 0.97 * half), 64), ((0.3 * half, half), 50)]:
+        want = c_radial_histogram(pos, pos, nb, rng_range, box, exclusion=exclusion)
+        eng = _core.RdfEngine(_edges(nb, rng_range), exclusion, algo="cell", timing=True)
+        eng.accumulate(pos, None, box)
+        got = eng.counts()
+        st = eng.stats()
+        eng.close()
+        assert np.array_equal(got, want), (rng_range, nb)
+        assert st["cell_units_general"] > 0, "no tile pair took the per-pair image path"
+    want = c_radial_histogram(pos, other, 120, (0.0, half), box, exclusion=exclusion)
+    got = _gpu_hist(pos, other, 120, (0.0, half), box, exclusion, "cell")
+    assert np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("exclusion", [None, (1, 1), (4, 4)])
 def test_rdf_cell_culling_regime(exclusion):
     """Enough particles and a short range: tiles are culled and take the shifted fast path."""
