@@ -114,7 +114,7 @@ def rdf_entry(tag, workload, frames):
     out.update(hbm_bytes_per_frame=(2.0 * fetch + write) / frames,
                traffic_source=f"profiles/r02_{tag}_FETCH_SIZE_pmc.csv + r02_{tag}_WRITE_SIZE_pmc.csv "
                               f"(separate passes, FETCH doubled per MI355X_MICROARCH.md)",
-               source=f"profiles/r02_{tag}_SQ_INSTS_VALU_SQ_INSTS_SALU_SQ_INSTS_LDS_SQ_INS_pmc.csv, "
+               source=f"profiles/r02_{tag}_SQ_INSTS_VALU_SQ_INSTS_SALU_SQ_INSTS_LDS_pmc.csv, "
                       f"{frames} frames, scripts/make_counters.py",
                source_digest=bench.source_digest(*bench.RDF_SOURCES))
     return out
