@@ -59,6 +59,19 @@ constexpr int CELL_TODO = 128;    // per-wave list of pairs waiting for the exac
 // index n_bins instead of letting it alias the next histogram's bin 0.
 __host__ __device__ constexpr int cell_hist_stride(int n_bins) { return n_bins + 1; }
 
+// LDS histogram of the pair kernel: n_bins + 1 bins x R interleaved replicas, word (bin * R + lane % R).
+// One wave instruction is served in two groups of 32 lanes on 32 banks; with the replicas interleaved two
+// lanes of a group meet on a bank only when lane % R agrees AND the bins agree modulo 32 / R — at R = 8 the
+// ~8-17 adding lanes of a step hardly ever do, where per-wave histograms (bank = bin % 32) made them queue
+// 2-3 deep.  (LDS executes one wave instruction at a time: histograms private to a wave bought nothing.)
+struct HistLdsRep {
+    unsigned *h;   // replica of this lane: base + lane % R
+    int sh;        // log2 R
+    __device__ inline void add(int k, unsigned w) const { atomicAdd(h + (k << sh), w); }
+};
+__device__ inline int cell_hist_shift(const HistLdsRep &h) { return h.sh; }
+template <typename Hist> __device__ inline int cell_hist_shift(const Hist &) { return 0; }
+
 struct CellGrid {
     int nc[3];
     float Lf[3];
@@ -420,42 +433,43 @@ __device__ inline void cell_step(const CellHot &c, const CellArgs &a, const Hist
         // it, the sure lanes are what is left, and EXEC is restored once — two scalar instructions.
         // EXEC is all ones here: every call site sits in wave-uniform control flow of full waves.
         const unsigned hbase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned *)hist.h;
+        const int hshift = cell_hist_shift(hist) + 2;   // byte offset of a bin = bin << (2 + log2 R)
         unsigned tmp;
         if (LOWER && TAGS)
             asm volatile("v_cmpx_gt_f32_e32 %[hi], %[r2]\n\tv_cmpx_le_f32_e32 %[lo], %[r2]\n\tv_cmpx_ne_u32_e32 %[ti], %[tj]\n\t"
                          "v_cmp_le_f32_e64 %[mt], %[sw], %[t]\n\tv_cvt_i32_f32_e32 %[tmp], %[pos]\n\t"
-                         "s_andn2_b64 exec, exec, %[mt]\n\tv_lshl_add_u32 %[tmp], %[tmp], 2, %[hb]\n\t"
+                         "s_andn2_b64 exec, exec, %[mt]\n\tv_lshl_add_u32 %[tmp], %[tmp], %[sh], %[hb]\n\t"
                          "ds_add_u32 %[tmp], %[w]\n\ts_mov_b64 exec, -1"
                          : [mt] "=&s"(m_todo), [tmp] "=&v"(tmp)
                          : [hi] "s"(c.cand_hi), [lo] "s"(c.cand_lo), [r2] "v"(r2), [sw] "s"(c.sure_w), [t] "v"(t),
-                           [pos] "v"(pos), [hb] "v"(hbase), [w] "v"(w), [ti] "v"(tag_i), [tj] "v"(tag_j)
+                           [pos] "v"(pos), [hb] "v"(hbase), [w] "v"(w), [sh] "s"(hshift), [ti] "v"(tag_i), [tj] "v"(tag_j)
                          : "memory");
         else if (LOWER)
             asm volatile("v_cmpx_gt_f32_e32 %[hi], %[r2]\n\tv_cmpx_le_f32_e32 %[lo], %[r2]\n\t"
                          "v_cmp_le_f32_e64 %[mt], %[sw], %[t]\n\tv_cvt_i32_f32_e32 %[tmp], %[pos]\n\t"
-                         "s_andn2_b64 exec, exec, %[mt]\n\tv_lshl_add_u32 %[tmp], %[tmp], 2, %[hb]\n\t"
+                         "s_andn2_b64 exec, exec, %[mt]\n\tv_lshl_add_u32 %[tmp], %[tmp], %[sh], %[hb]\n\t"
                          "ds_add_u32 %[tmp], %[w]\n\ts_mov_b64 exec, -1"
                          : [mt] "=&s"(m_todo), [tmp] "=&v"(tmp)
                          : [hi] "s"(c.cand_hi), [lo] "s"(c.cand_lo), [r2] "v"(r2), [sw] "s"(c.sure_w), [t] "v"(t),
-                           [pos] "v"(pos), [hb] "v"(hbase), [w] "v"(w)
+                           [pos] "v"(pos), [hb] "v"(hbase), [w] "v"(w), [sh] "s"(hshift)
                          : "memory");
         else if (TAGS)
             asm volatile("v_cmpx_gt_f32_e32 %[hi], %[r2]\n\tv_cmpx_ne_u32_e32 %[ti], %[tj]\n\t"
                          "v_cmp_le_f32_e64 %[mt], %[sw], %[t]\n\tv_cvt_i32_f32_e32 %[tmp], %[pos]\n\t"
-                         "s_andn2_b64 exec, exec, %[mt]\n\tv_lshl_add_u32 %[tmp], %[tmp], 2, %[hb]\n\t"
+                         "s_andn2_b64 exec, exec, %[mt]\n\tv_lshl_add_u32 %[tmp], %[tmp], %[sh], %[hb]\n\t"
                          "ds_add_u32 %[tmp], %[w]\n\ts_mov_b64 exec, -1"
                          : [mt] "=&s"(m_todo), [tmp] "=&v"(tmp)
                          : [hi] "s"(c.cand_hi), [r2] "v"(r2), [sw] "s"(c.sure_w), [t] "v"(t), [pos] "v"(pos),
-                           [hb] "v"(hbase), [w] "v"(w), [ti] "v"(tag_i), [tj] "v"(tag_j)
+                           [hb] "v"(hbase), [w] "v"(w), [sh] "s"(hshift), [ti] "v"(tag_i), [tj] "v"(tag_j)
                          : "memory");
         else
             asm volatile("v_cmpx_gt_f32_e32 %[hi], %[r2]\n\t"
                          "v_cmp_le_f32_e64 %[mt], %[sw], %[t]\n\tv_cvt_i32_f32_e32 %[tmp], %[pos]\n\t"
-                         "s_andn2_b64 exec, exec, %[mt]\n\tv_lshl_add_u32 %[tmp], %[tmp], 2, %[hb]\n\t"
+                         "s_andn2_b64 exec, exec, %[mt]\n\tv_lshl_add_u32 %[tmp], %[tmp], %[sh], %[hb]\n\t"
                          "ds_add_u32 %[tmp], %[w]\n\ts_mov_b64 exec, -1"
                          : [mt] "=&s"(m_todo), [tmp] "=&v"(tmp)
                          : [hi] "s"(c.cand_hi), [r2] "v"(r2), [sw] "s"(c.sure_w), [t] "v"(t), [pos] "v"(pos),
-                           [hb] "v"(hbase), [w] "v"(w)
+                           [hb] "v"(hbase), [w] "v"(w), [sh] "s"(hshift)
                          : "memory");
     }
     // An undecided pair is not evaluated here, a lane or two at a time with fp64 temporaries in the
@@ -563,7 +577,7 @@ __global__ __launch_bounds__(256, TRI ? 4 : 6) void rdf_cell_pair_kernel(CellArg
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float4 *sJ = reinterpret_cast<float4 *>(smem_raw);                        // [4 waves][64]
     double *sT = reinterpret_cast<double *>(smem_raw + sizeof(float4) * 256); // [n_bins+1]
-    unsigned *sh = reinterpret_cast<unsigned *>(sT + (a.n_bins + 1));         // [n_hist][n_bins + 1]
+    unsigned *sh = reinterpret_cast<unsigned *>(sT + (a.n_bins + 1));         // [n_bins + 1][n_hist replicas]
     __shared__ unsigned s_exact, s_units, s_general, s_qn, s_qnext;
     __shared__ unsigned sQ[CELL_QCAP];
     __shared__ uint2 s_todo[4][CELL_TODO];
@@ -673,9 +687,10 @@ __global__ __launch_bounds__(256, TRI ? 4 : 6) void rdf_cell_pair_kernel(CellArg
     }
     hot.tri = TRI ? s_geo + 31 : nullptr;
     const double *thr = GH ? a.thresh : sT;
-    // per-wave histograms of n_bins + 1 slots: the extra slot absorbs a (proven impossible,
-    // DESIGN.md §4.2) index n_bins instead of letting it alias the next histogram's bin 0
-    HistLds hl{sh + (GH ? 0 : (wave % a.n_hist) * cell_hist_stride(a.n_bins))};
+    // n_bins + 1 bins of n_hist (a power of two) interleaved replicas: the extra bin absorbs a (proven
+    // impossible) index n_bins
+    const int rep_log = __builtin_amdgcn_readfirstlane(31 - __clz(a.n_hist));
+    HistLdsRep hl{sh + (GH ? 0 : (lane & (a.n_hist - 1))), GH ? 0 : rep_log};
     HistGlobal hg{out};
 
     const float4 *PW1 = a.pw1 + int64_t(frame) * a.n1p + int64_t(I) * 128;
@@ -972,8 +987,8 @@ __global__ __launch_bounds__(256, TRI ? 4 : 6) void rdf_cell_pair_kernel(CellArg
             for (int b = tid; b < a.n_bins; b += 256) {
                 unsigned long long sum = 0;
                 for (int h = 0; h < a.n_hist; ++h) {
-                    sum += sh[h * cell_hist_stride(a.n_bins) + b];
-                    sh[h * cell_hist_stride(a.n_bins) + b] = 0u;
+                    sum += sh[b * a.n_hist + h];
+                    sh[b * a.n_hist + h] = 0u;
                 }
                 if (sum)
                     atomicAdd(out + b, sum);
@@ -1004,7 +1019,7 @@ __global__ __launch_bounds__(256, TRI ? 4 : 6) void rdf_cell_pair_kernel(CellArg
         for (int b = tid; b < a.n_bins; b += 256) {
             unsigned long long s = 0;
             for (int h = 0; h < a.n_hist; ++h)
-                s += sh[h * cell_hist_stride(a.n_bins) + b];
+                s += sh[b * a.n_hist + h];
             if (s)
                 atomicAdd(out + b, s);
         }
