@@ -60,6 +60,7 @@ struct StreamTimer {
     bool enabled = false;
     hipStream_t stream = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> limbo;   // dropped before they fired (reset on a busy stream)
     std::vector<hipEvent_t> pool;
     double total_ms = 0.0;
     int64_t launches = 0;

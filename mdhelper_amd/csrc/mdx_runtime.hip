@@ -87,12 +87,29 @@ void StreamTimer::end(hipEvent_t start)
 
 void StreamTimer::collect()
 {
+    // pairs dropped by reset() while their events were still in flight: recycle them once they have fired
+    // (an event recorded again before it has fired gave elapsed times that spanned two uses)
+    for (size_t i = 0; i < limbo.size();) {
+        if (hipEventQuery(limbo[i].second) == hipSuccess) {
+            pool.push_back(limbo[i].first);
+            pool.push_back(limbo[i].second);
+            limbo[i] = limbo.back();
+            limbo.pop_back();
+        } else {
+            (void)hipGetLastError();
+            ++i;
+        }
+    }
     for (auto &p : pending) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess)
+        if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
             total_ms += ms;
-        pool.push_back(p.first);
-        pool.push_back(p.second);
+            pool.push_back(p.first);
+            pool.push_back(p.second);
+        } else {
+            (void)hipGetLastError();
+            limbo.push_back(p);
+        }
     }
     pending.clear();
 }
@@ -107,6 +124,11 @@ void StreamTimer::reset()
 void StreamTimer::destroy()
 {
     collect();
+    for (auto &p : limbo) {
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    limbo.clear();
     for (auto ev : pool)
         (void)hipEventDestroy(ev);
     pool.clear();
