@@ -191,7 +191,8 @@ __global__ __launch_bounds__(256) void rdf_tile_kernel(RdfArgs a)
             atomicAdd(&s_exact, n_exact);
         __syncthreads();
         if (tid == 0 && s_exact)
-            atomicAdd(a.exact_counter, (unsigned long long)s_exact);
+            atomicAdd(a.exact_counter + rdf_stat_offset(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)),
+                      (unsigned long long)s_exact);
     }
     if (!GH) {
         for (int b = tid; b < a.n_bins; b += 256) {
@@ -362,6 +363,7 @@ struct mdx_rdf {
     int algo = MDX_RDF_ALGO_AUTO;
     int n_rep = 32;
     DeviceBuffer d_thresh, d_counts, d_total, d_pack1, d_pack2, d_misc, d_tri;
+    DeviceBuffer d_stats;   // RDF_STAT_SHARDS x RDF_STAT_STRIDE 64-bit words (mdx_rdf_device.hpp)
     // optional centre-of-mass stage per set: incoming rows are particles grouped into molecules
     MoleculeStage grouping[2];
     // drop_axis (2-D mode, structure.py:761-770): coordinate zeroed, box length -> max(lx, ly, lz)
@@ -512,9 +514,9 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
         a.thresh = h->d_thresh.as<double>();
         a.counts = h->d_counts.as<unsigned long long>();
         a.maxabs_bits = d_misc;
-        a.exact_counter = reinterpret_cast<unsigned long long *>(d_misc + 2);
-        a.tilepair_counter = reinterpret_cast<unsigned long long *>(d_misc + 4);
-        a.clock_counter = h->timer.enabled ? reinterpret_cast<unsigned long long *>(d_misc + 8) : nullptr;
+        a.exact_counter = h->d_stats.as<unsigned long long>();
+        a.tilepair_counter = a.exact_counter + 1;
+        a.clock_counter = h->timer.enabled ? a.exact_counter + 3 : nullptr;
         a.t_lo = h->t_lo;
         a.t_hi = h->t_hi;
         a.r0 = h->edges.front();
@@ -608,7 +610,7 @@ static int accumulate_ortho(mdx_rdf *h, const float *d_pos1, int64_t n1, const f
         a.counts = h->d_counts.as<unsigned long long>();
         a.n_rep = h->n_rep;
         a.maxabs_bits = d_misc;
-        a.exact_counter = reinterpret_cast<unsigned long long *>(d_misc + 2);
+        a.exact_counter = h->d_stats.as<unsigned long long>();
         MDX_TRY(launch_tiles(h, a, algo, ipt, d_boxes != nullptr, excl, nf));
         const int64_t tile_pairs = self ? int64_t(a.nt1) * (a.nt1 + 1) / 2 : int64_t(a.nt1) * a.nt2;
         h->pairs_bruteforce += nf * tile_pairs * T * T;
@@ -964,6 +966,7 @@ int mdx_rdf_create(mdx_rdf_t *out, int dev, int n_bins, const double *edges, int
         if ((rc = h->d_counts.ensure(sizeof(uint64_t) * size_t(h->n_rep) * n_bins)) != MDX_OK) break;
         if ((rc = h->d_total.ensure(sizeof(uint64_t) * n_bins)) != MDX_OK) break;
         if ((rc = h->d_misc.ensure(64)) != MDX_OK) break;
+        if ((rc = h->d_stats.ensure(RDF_STAT_BYTES)) != MDX_OK) break;
         if (hipMemcpy(h->d_thresh.ptr, h->thresh.data(), sizeof(double) * (n_bins + 1),
                       hipMemcpyHostToDevice) != hipSuccess) {
             rc = fail(MDX_ERR_HIP, "threshold upload failed");
@@ -989,7 +992,7 @@ int mdx_rdf_destroy(mdx_rdf_t h)
     h->pipe.destroy();
     for (DeviceBuffer *b : {&h->d_thresh, &h->d_counts, &h->d_total, &h->d_pack1, &h->d_pack2,
                             &h->d_stage1[0], &h->d_stage2[0], &h->d_boxes[0], &h->d_stage1[1],
-                            &h->d_stage2[1], &h->d_boxes[1], &h->d_index[0], &h->d_index[1], &h->d_tri, &h->d_misc, &h->d_pw1,
+                            &h->d_stage2[1], &h->d_boxes[1], &h->d_index[0], &h->d_index[1], &h->d_tri, &h->d_misc, &h->d_stats, &h->d_pw1,
                             &h->d_po1, &h->d_bb1, &h->d_pw2, &h->d_po2, &h->d_bb2, &h->d_bb16_1,
                             &h->d_bb16_2, &h->d_drop[0], &h->d_drop[1], &h->d_drop_box})
         b->release();
@@ -1009,6 +1012,7 @@ int mdx_rdf_reset(mdx_rdf_t h)
     MDX_HIP(hipMemsetAsync(h->d_counts.ptr, 0, sizeof(uint64_t) * size_t(h->n_rep) * h->n_bins,
                            h->stream));
     MDX_HIP(hipMemsetAsync(h->d_misc.ptr, 0, 64, h->stream));
+    MDX_HIP(hipMemsetAsync(h->d_stats.ptr, 0, RDF_STAT_BYTES, h->stream));
     MDX_HIP(hipStreamSynchronize(h->stream));
     h->timer.reset();
     h->pairs_evaluated = 0;
@@ -1120,6 +1124,21 @@ int mdx_rdf_accumulate_traj(mdx_rdf_t h, mdx_traj_t traj, const int64_t *frames,
         });
 }
 
+// Sum of the statistics shards after the stream has drained: [0] exact pairs, [1] units, [2] general units,
+// [3] engine-clock ticks, [4] 100 MHz ticks.
+static int read_stats(mdx_rdf *h, unsigned long long out[5])
+{
+    MDX_HIP(hipStreamSynchronize(h->stream));
+    std::vector<unsigned long long> raw(size_t(RDF_STAT_SHARDS) * RDF_STAT_STRIDE);
+    MDX_HIP(hipMemcpy(raw.data(), h->d_stats.ptr, RDF_STAT_BYTES, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 5; ++k)
+        out[k] = 0;
+    for (unsigned sh = 0; sh < RDF_STAT_SHARDS; ++sh)
+        for (int k = 0; k < 5; ++k)
+            out[k] += raw[size_t(sh) * RDF_STAT_STRIDE + k];
+    return MDX_OK;
+}
+
 int mdx_rdf_synchronize(mdx_rdf_t h)
 {
     MDX_REQUIRE(h, "NULL handle");
@@ -1158,10 +1177,9 @@ int mdx_rdf_stats(mdx_rdf_t h, int64_t *launches, double *kernel_ms, int64_t *pa
 {
     if (pairs_computed && h) {
         // distance evaluations actually executed: brute-force tiles + culled cell tiles
-        unsigned long long tp = 0;
-        if (set_device(h->dev) == MDX_OK && hipStreamSynchronize(h->stream) == hipSuccess &&
-            hipMemcpy(&tp, h->d_misc.as<unsigned>() + 4, 8, hipMemcpyDeviceToHost) == hipSuccess)
-            *pairs_computed = h->pairs_bruteforce + (int64_t)tp * 64 * CELL_CHUNK;
+        unsigned long long st[5];
+        if (set_device(h->dev) == MDX_OK && read_stats(h, st) == MDX_OK)
+            *pairs_computed = h->pairs_bruteforce + (int64_t)st[1] * 64 * CELL_CHUNK;
     }
     MDX_REQUIRE(h, "NULL handle");
     MDX_TRY(set_device(h->dev));
@@ -1171,9 +1189,9 @@ int mdx_rdf_stats(mdx_rdf_t h, int64_t *launches, double *kernel_ms, int64_t *pa
     if (kernel_ms) *kernel_ms = h->timer.total_ms;
     if (pairs_evaluated) *pairs_evaluated = h->pairs_evaluated;
     if (pairs_exact) {
-        unsigned long long v = 0;
-        MDX_HIP(hipMemcpy(&v, h->d_misc.as<unsigned>() + 2, 8, hipMemcpyDeviceToHost));
-        *pairs_exact = (int64_t)v;
+        unsigned long long st[5];
+        MDX_TRY(read_stats(h, st));
+        *pairs_exact = (int64_t)st[0];
     }
     return MDX_OK;
 }
@@ -1182,11 +1200,10 @@ int mdx_rdf_kernel_clock(mdx_rdf_t h, double *hz)
 {
     MDX_REQUIRE(h && hz, "NULL argument");
     MDX_TRY(set_device(h->dev));
-    MDX_HIP(hipStreamSynchronize(h->stream));
-    unsigned long long raw[2] = {0, 0};
-    MDX_HIP(hipMemcpy(raw, h->d_misc.as<unsigned>() + 8, sizeof(raw), hipMemcpyDeviceToHost));
+    unsigned long long st[5];
+    MDX_TRY(read_stats(h, st));
     // s_memrealtime counts at 100 MHz
-    *hz = raw[1] ? double(raw[0]) / double(raw[1]) * 1.0e8 : 0.0;
+    *hz = st[4] ? double(st[3]) / double(st[4]) * 1.0e8 : 0.0;
     return MDX_OK;
 }
 
@@ -1194,9 +1211,8 @@ int mdx_rdf_debug_counters(mdx_rdf_t h, int64_t out[4])
 {
     MDX_REQUIRE(h && out, "NULL argument");
     MDX_TRY(set_device(h->dev));
-    MDX_HIP(hipStreamSynchronize(h->stream));
-    unsigned long long raw[3] = {0, 0, 0};
-    MDX_HIP(hipMemcpy(raw, h->d_misc.as<unsigned>() + 2, sizeof(raw), hipMemcpyDeviceToHost));
+    unsigned long long raw[5];
+    MDX_TRY(read_stats(h, raw));
     out[0] = (int64_t)raw[0];   // pairs re-evaluated exactly
     out[1] = (int64_t)raw[1];   // (64 i) x (16 j) units evaluated by the cell kernel
     out[2] = (int64_t)raw[2];   // ... of which on the per-pair image-search path

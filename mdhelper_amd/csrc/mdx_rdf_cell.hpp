@@ -38,9 +38,10 @@ struct CellArgs {
     const double *thresh;        // [n_bins+1]
     unsigned long long *counts;  // [n_rep][n_bins]
     const unsigned *maxabs_bits;
-    unsigned long long *exact_counter;
-    unsigned long long *tilepair_counter;   // (64 i) x (CELL_CHUNK j) units actually evaluated
-    unsigned long long *clock_counter;      // timing runs: [0] += engine-clock ticks, [1] += 100 MHz ticks
+    // words of the statistics shards (rdf_stat_offset; mdx_rdf_device.hpp)
+    unsigned long long *exact_counter;      // word 0
+    unsigned long long *tilepair_counter;   // words 1, 2: (64 i) x (CELL_CHUNK j) units evaluated, of which general
+    unsigned long long *clock_counter;      // words 3, 4 (timing runs): engine-clock ticks, 100 MHz ticks
     double t_lo, t_hi, r0, r1;
     int n1p, n2p;                // padded particle counts (multiples of 128)
     int n_bins, n_hist, n_rep;
@@ -1007,12 +1008,13 @@ __global__ __launch_bounds__(256, TRI ? 4 : 6) void rdf_cell_pair_kernel(CellArg
     }
     __syncthreads();
     if (tid == 0) {
-        if (s_exact) atomicAdd(a.exact_counter, (unsigned long long)s_exact);
-        if (s_units) atomicAdd(a.tilepair_counter, (unsigned long long)s_units);
-        if (s_general) atomicAdd(a.tilepair_counter + 1, (unsigned long long)s_general);
+        const unsigned so = rdf_stat_offset(lin);
+        if (s_exact) atomicAdd(a.exact_counter + so, (unsigned long long)s_exact);
+        if (s_units) atomicAdd(a.tilepair_counter + so, (unsigned long long)s_units);
+        if (s_general) atomicAdd(a.tilepair_counter + so + 1, (unsigned long long)s_general);
         if (a.clock_counter) {
-            atomicAdd(a.clock_counter, (unsigned long long)(clock64() - clk0));
-            atomicAdd(a.clock_counter + 1, (unsigned long long)(wall_clock64() - rt0));
+            atomicAdd(a.clock_counter + so, (unsigned long long)(clock64() - clk0));
+            atomicAdd(a.clock_counter + so + 1, (unsigned long long)(wall_clock64() - rt0));
         }
     }
     if (!GH) {

@@ -17,6 +17,19 @@
 
 #include <cstdint>
 
+// Statistics counters (pairs sent to the exact arithmetic, units evaluated, clock ticks) are kept in
+// RDF_STAT_SHARDS shards of 16 words, one 128-byte line each; a block adds to the shard of its linear id.
+// One shared set of counters cost a third of the pair kernel's time and hid every other change: a launch of
+// 1 000 frames retires 256 000 blocks, each with up to five atomics on ONE line, and same-line device
+// atomics complete one per ~24 ns (12.5 ms per launch measured with empty blocks).
+constexpr unsigned RDF_STAT_SHARDS = 512;
+constexpr unsigned RDF_STAT_STRIDE = 16;   // 64-bit words per shard
+constexpr size_t RDF_STAT_BYTES = size_t(RDF_STAT_SHARDS) * RDF_STAT_STRIDE * 8;
+__device__ inline unsigned rdf_stat_offset(unsigned linear_block)
+{
+    return (linear_block & (RDF_STAT_SHARDS - 1u)) * RDF_STAT_STRIDE;
+}
+
 struct RdfArgs {
     const float4 *p1;            // [frames][n1p]  packed xyz + exclusion tag
     const float4 *p2;            // [frames][n2p]
@@ -24,7 +37,7 @@ struct RdfArgs {
     const double *thresh;        // [n_bins+1]  T(edge_k) in the squared-distance domain
     unsigned long long *counts;  // [n_rep][n_bins]
     const unsigned *maxabs_bits; // max |coordinate| of the batch (float bits)
-    unsigned long long *exact_counter;
+    unsigned long long *exact_counter;   // word 0 of the shards (rdf_stat_offset)
     double t_lo, t_hi;           // in range  <=>  t_lo <= rsq < t_hi
     double r0, r1;
     int n1p, n2p, nt1, nt2;
