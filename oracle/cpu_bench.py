@@ -63,6 +63,34 @@ def time_rdf_numpy(frame, dims, n_bins, rng, exclusion, rows: int, workers: int 
     return counts, workers * rows * n, max(p["seconds"] for p in parts)
 
 
+def time_rdf_kdtree(frame, dims, n_bins, rng, exclusion, rows: int):
+    """
+    The neighbour-search route an installed reference takes at this size: ``capped_distance`` switches from
+    brute force to a periodic k-d tree / cell grid for large inputs (MDAnalysis.lib.distances, methods
+    'pkdtree' / 'nsgrid'; reference src/mdhelper/analysis/structure.py:93-96 passes ``max_cutoff`` = the
+    range end).  Neither MDAnalysis nor its grid is here; scipy's ``cKDTree(boxsize=...)`` is the same
+    algorithm family on one core: pairs within the range end of ``rows`` query rows against the tree of all
+    particles, then ``numpy.histogram``.  float64 distances from float32-wrapped coordinates: counts can
+    differ from the contract's by a pair on a bin edge, so equality with the C restatement is reported, not
+    required.  Returns (counts, ordered pairs covered, seconds including the tree build).
+    """
+    from scipy.spatial import cKDTree
+    n = frame.shape[0]
+    rows = max(1, min(rows, n))
+    L = np.asarray(dims[:3], dtype=np.float64)
+    t0 = time.perf_counter()
+    x = np.mod(frame.astype(np.float64), L)
+    x[x >= L] = 0.0                              # mod can return L itself for tiny negative inputs
+    tree = cKDTree(x, boxsize=L)
+    sub = cKDTree(x[:rows], boxsize=L)
+    sd = sub.sparse_distance_matrix(tree, float(rng[1]), output_type="ndarray")
+    keep = np.ones(sd.shape[0], dtype=bool)
+    if exclusion:
+        keep = (sd["i"] // exclusion[0]) != (sd["j"] // exclusion[1])
+    counts, _ = np.histogram(sd["v"][keep], bins=n_bins, range=rng)
+    return counts.astype(np.int64), rows * n, time.perf_counter() - t0
+
+
 if __name__ == "__main__":
     import json
     import sys

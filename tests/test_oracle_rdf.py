@@ -118,3 +118,18 @@ def test_ideal_gas_rdf_is_one():
     frames = (rng.random((4, 1500, 3)) * L).astype(np.float32)
     res = orf.rdf_run_ref(frames, [L, L, L, 90, 90, 90], n_bins=30, range=(0.0, 12.0), exclusion=(1, 1))
     assert np.allclose(res["rdf"][8:], 1.0, atol=0.06)
+
+
+def test_kdtree_baseline_counts_the_same_pairs_up_to_bin_edges():
+    """bench.py's cpu_baseline_celllist leg (scipy periodic k-d tree + numpy.histogram) against the C restatement."""
+    from oracle import cpu_bench
+    from oracle.cbind import c_radial_histogram
+    rng = np.random.default_rng(12)
+    L = np.array([31.0, 35.5, 40.25], dtype=np.float32)
+    box = np.array([*L, 90, 90, 90], dtype=np.float32)
+    x = (rng.random((3000, 3)) * L - 5.0).astype(np.float32)        # partly outside the cell
+    counts, pairs, seconds = cpu_bench.time_rdf_kdtree(x, box, 120, (0.0, 12.0), (1, 1), 1000)
+    want = c_radial_histogram(x[:1000], x, 120, (0.0, 12.0), box, exclusion=(1, 1))
+    assert pairs == 1000 * 3000 and seconds > 0
+    assert abs(int(counts.sum()) - int(want.sum())) <= 2
+    assert np.abs(counts - want).sum() <= 1e-5 * want.sum() + 4
