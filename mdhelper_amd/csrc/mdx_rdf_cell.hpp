@@ -485,7 +485,7 @@ __device__ inline void cell_step(const CellHot &c, const CellArgs &a, const Hist
                     (unsigned)(m_todo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_todo, 0u));
                 // i index = (wave-uniform base of the half tile) + lane, formed only here
                 wv.todo[wv.n_todo + rank] =
-                    make_uint2(i_base + (threadIdx.x & 63u), j_idx | ((w - 1u) << 31));
+                    make_uint2(i_base + (threadIdx.x & 63u), j_idx);   // j_idx carries the weight flag (bit 31)
             }
             wv.n_todo += cnt;
         } else {
@@ -872,7 +872,9 @@ __global__ __launch_bounds__(256, TRI ? 4 : 6) void rdf_cell_pair_kernel(CellArg
             const bool diag = a.self && Jt <= 2 * I + 1;
             unsigned w = (a.self && !diag) ? 2u : 1u;
             asm volatile("" : "+v"(w));   // the add's data operand: one VGPR per tile, not a v_mov per step
-            const unsigned jbase = unsigned(Jt) * 64u;
+            // bit 31 of every j index handed on = (weight - 1): formed here on the scalar unit, once per tile
+            // (derived from `w`, which is pinned in a vector register, it was a v_or per chunk)
+            const unsigned jbase = unsigned(Jt) * 64u | ((a.self && !diag) ? 0x80000000u : 0u);
             // exclusion tags can only collide inside the diagonal tiles when exclusion == (1, 1)
             const bool tags = EXCL && (a.tags_everywhere || diag);
             if (!gen) {
