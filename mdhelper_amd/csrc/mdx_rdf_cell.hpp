@@ -203,6 +203,9 @@ __global__ __launch_bounds__(SORT_THREADS) void rdf_cell_sort_kernel(
     __syncthreads();
 
     float m = 0.0f;
+    // (unrolled: the loads of four particles are in flight before the first is counted; a block is one
+    // frame and nothing else hides their latency)
+#pragma unroll 4
     for (int a = tid; a < n; a += SORT_THREADS) {
         float x = P[3 * a], y = P[3 * a + 1], z = P[3 * a + 2];
         int cx, cy, cz;
@@ -219,13 +222,23 @@ __global__ __launch_bounds__(SORT_THREADS) void rdf_cell_sort_kernel(
         m = fmaxf(m, am == am ? am : __int_as_float(0x7f800000));
     }
     {
+        // one atomicMax per block, not per wave: device atomics on one address complete one per ~24 ns, and
+        // sixteen per frame were a third of this kernel
         unsigned bits = __float_as_uint(m);
         for (int off = 32; off > 0; off >>= 1)
             bits = max(bits, (unsigned)__shfl_xor((int)bits, off));
-        if ((tid & 63) == 0 && bits)
-            atomicMax(maxabs_bits, bits);
+        if ((tid & 63) == 0)
+            part[tid >> 6] = bits;
     }
     __syncthreads();
+    if (tid == 0) {
+        unsigned bits = 0u;
+        for (int w = 0; w < SORT_THREADS / 64; ++w)
+            bits = max(bits, part[w]);
+        if (bits)
+            atomicMax(maxabs_bits, bits);
+    }
+    __syncthreads();   // part[] is reused by the scan
 
     // exclusive scan of cnt[0..ncell): each thread owns a contiguous run
     const int per = (ncell + SORT_THREADS - 1) / SORT_THREADS;
@@ -250,6 +263,7 @@ __global__ __launch_bounds__(SORT_THREADS) void rdf_cell_sort_kernel(
     __syncthreads();
 
     // scatter: the cursor of a cell hands out its slots
+#pragma unroll 4
     for (int a = tid; a < n; a += SORT_THREADS) {
         float x = P[3 * a], y = P[3 * a + 1], z = P[3 * a + 2];
         int cx, cy, cz;
@@ -280,6 +294,7 @@ __global__ __launch_bounds__(SORT_THREADS) void rdf_cell_sort_kernel(
     const int n_tiles = n_pad / 64;
     float4 *BB = bb + int64_t(frame) * n_tiles * 2;
     float4 *BB16 = bb16 + int64_t(frame) * n_tiles * 2 * CELL_NCHUNK;
+#pragma unroll 2
     for (int t = wave; t < n_tiles; t += SORT_THREADS / 64) {
         float4 v = PW[t * 64 + lane];
         const float inf = __int_as_float(0x7f800000);
