@@ -528,7 +528,7 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols400_fused_kernel(
     double2 *__restrict__ Y, double2 *__restrict__ part)
 {
     constexpr int R1 = 400, ZS = R1 + 1, LIVE = R1 / 2;
-    constexpr int LOADS = (LIVE + 31) / 32;     // 7 row rounds
+    constexpr int LOADS = (LIVE + 63) / 64;     // 4 row rounds of 64 rows (a lane loads a PAIR: 16 bytes)
     constexpr int OUTS = (R1 + 63) / 64;        // 7 line rounds
     static_assert(LIVE == SUMS_ROWS, "row count of the partial sums");
     __shared__ double2 zb[PG][ZS];
@@ -549,11 +549,13 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols400_fused_kernel(
     for (int i = tid; i < R2; i += THREADS)
         s_n[i] = twN[i];
 
-    // loads: coordinate s of the pair group, rows row0 + 32 i
-    const int s = tid & 15, row0 = tid >> 4;
+    // loads: pair lp of the pair group (coordinates s, s + 1 = one complex value), rows row0 + 64 i.  16 bytes per
+    // lane: 8-byte-per-lane loads run at 0.54-0.70 of the 16-byte rate (MI355X_MICROARCH.md), and the pair is what
+    // gets staged anyway
+    const int lp = tid & 7, s = 2 * lp, row0 = tid >> 3;
     const double *base = pos + (int64_t(b) * t_block * n_total + first) * 3;
     const int64_t row_stride = n_total * 3;
-    const int64_t istr = int64_t(32) * R2 * row_stride;       // rows row0 + 32 i -> + i * istr
+    const int64_t istr = int64_t(64) * R2 * row_stride;       // rows row0 + 64 i -> + i * istr
     // stores: pair p of line kbase + 64 i
     const int p = tid & 7, kbase = tid >> 3;
     const int64_t k1_stride = int64_t(n_pg) * R2 * PG;
@@ -561,24 +563,37 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols400_fused_kernel(
 
     // rows of the current iteration: coordinate e = 16 (pg0 + q) + s, column n2
     const double *cur = base + (int64_t(row0) * R2 + n2_begin) * row_stride + int64_t(pg0) * 16 + s;
-    double x[LOADS];
-    // entry i of (column N2, pair group pg0 + Q) is a live value (else it is staged as zero): the
-    // coordinate lies in the chunk and its dimension is kept, the row exists (row0 + 32 i < 200) and
-    // its frame (row0 + 32 i) R2 + N2 lies in the block.  32-bit tests against two per-thread limits.
-    const int e_lim = int(min<int64_t>(n_elem - int64_t(pg0) * 16 - s, 1 << 20));      // 16 Q < e_lim
-    const int t_lim = int(min<int64_t>(t_block - int64_t(row0) * R2, int64_t(1) << 30));   // 32 i R2 + N2 < t_lim
-    const int i_lim = row0 < LIVE - 32 * (LOADS - 1) ? LOADS : LOADS - 1;                 // i < i_lim
-#define MDX_FUSED_OK(N2, Q, I)                                                               \
-    (16 * (Q) < e_lim && !((zero_dims >> ((pg0 + (Q) + s) % 3)) & 1) && (I) < i_lim &&       \
-     32 * R2 * (I) + (N2) < t_lim)
-    // issue the loads of (column N2, pair group pg0 + Q) from CUR; dead entries read `base`
+    struct alignas(8) Pair { double x, y; };   // two consecutive coordinates; the address is 8-byte aligned
+    Pair x[LOADS];
+    // entry i of (column N2, pair group pg0 + Q) holds live values (else zeros are staged): the coordinates lie
+    // in the chunk (the second of a pair may not: the chunk has 3 c coordinates) and their dimensions are kept,
+    // the row exists (row0 + 64 i < 200) and its frame (row0 + 64 i) R2 + N2 lies in the block.  32-bit tests
+    // against per-thread limits.
+    const int e_lim = int(min<int64_t>(n_elem - int64_t(pg0) * 16 - s, 1 << 20));      // 16 Q (+ 1) < e_lim
+    const int t_lim = int(min<int64_t>(t_block - int64_t(row0) * R2, int64_t(1) << 30));   // 64 i R2 + N2 < t_lim
+    const int i_lim = row0 < LIVE - 64 * (LOADS - 1) ? LOADS : LOADS - 1;                 // i < i_lim
+#define MDX_FUSED_ROW(N2, I) ((I) < i_lim && 64 * R2 * (I) + (N2) < t_lim)
+#define MDX_FUSED_OK0(N2, Q, I)                                                              \
+    (16 * (Q) < e_lim && !((zero_dims >> ((pg0 + (Q) + s) % 3)) & 1) && MDX_FUSED_ROW(N2, I))
+#define MDX_FUSED_OK1(N2, Q, I)                                                              \
+    (16 * (Q) + 1 < e_lim && !((zero_dims >> ((pg0 + (Q) + s + 1) % 3)) & 1) && MDX_FUSED_ROW(N2, I))
+    // issue the loads of (column N2, pair group pg0 + Q) from CUR; dead rows read `base`; a pair whose second
+    // coordinate lies past the chunk is read one coordinate earlier (its first coordinate arrives in .y), so
+    // that no load reaches past the chunk's last coordinate
 #define MDX_FUSED_LOAD(N2, Q, CUR)                                                          \
     _Pragma("unroll") for (int i = 0; i < LOADS; ++i)                                       \
     {                                                                                       \
-        const double *q_ = MDX_FUSED_OK(N2, Q, i) ? (CUR) + i * istr : base;                \
-        x[i] = *q_;                                                                         \
+        const bool row_ = 16 * (Q) < e_lim && MDX_FUSED_ROW(N2, i);                         \
+        const double *q_ = row_ ? (CUR) + i * istr - (16 * (Q) + 1 < e_lim ? 0 : 1) : base; \
+        x[i] = *reinterpret_cast<const Pair *>(q_);                                         \
     }
     MDX_FUSED_LOAD(n2_begin, 0, cur)
+    // the first rows are waited for here, once: the loop is then entered with no load pending and seven stores in
+    // flight, and re-entered with four loads FOLLOWED BY seven stores, and the wait at its top is vmcnt(7 + ...)
+    // on both paths (left to itself the compiler sank one of these loads below the placeholder stores)
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i)
+        asm volatile("" ::"v"(x[i].x), "v"(x[i].y) : "memory");
     // Seven placeholder stores into the first iteration's own output slots (overwritten there): the
     // loop is then entered with the same queue of memory operations as it is re-entered with — seven
     // loads followed by seven stores — and the compiler's wait for the loads at the top of the loop
@@ -597,11 +612,15 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols400_fused_kernel(
     const int n_iter = n2_count * n_q;
     for (int it = 0; it < n_iter; ++it) {
         {
-            double *dst = reinterpret_cast<double *>(&zb[s >> 1][0]) + (s & 1);
+            const bool shifted = !(16 * q + 1 < e_lim);   // the pair was read one coordinate earlier
 #pragma unroll
-            for (int i = 0; i < LOADS; ++i)
-                if (row0 + 32 * i < LIVE)
-                    dst[2 * (row0 + 32 * i)] = MDX_FUSED_OK(n2, q, i) ? x[i] : 0.0;
+            for (int i = 0; i < LOADS; ++i) {
+                // (rows 200..255 of the last round receive zeros: the first stage does not read rows >= 200
+                // and overwrites them; no branch here, or the compiler drains vmcnt at its join)
+                const double v0 = shifted ? x[i].y : x[i].x;
+                zb[lp][row0 + 64 * i] = make_double2(MDX_FUSED_OK0(n2, q, i) ? v0 : 0.0,
+                                                     MDX_FUSED_OK1(n2, q, i) ? x[i].y : 0.0);
+            }
         }
         __syncthreads();
         const bool wrap = q + 1 == n_q;
@@ -639,9 +658,13 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols400_fused_kernel(
                 v.x += sy;
                 v.y += sz;
                 if (wrap) {
-                    double2 *o = part + (((int64_t(sg) * gridDim.z + b) * R2 + n2) * LIVE + row) * 2;
-                    o[0] = u;
-                    o[1] = v;
+                    // wave-uniform 64-bit base + a 32-bit lane offset (a per-lane 64-bit index was spilled, and
+                    // its scratch reload drains vmcnt)
+                    double2 *o = part + ((int64_t(sg) * gridDim.z + b) * R2 + n2) * (2 * LIVE);
+                    int r2_ = int(threadIdx.x) & ~1;   // 2 row (row = tid / 2), formed here: a copy kept across
+                    asm volatile("" : "+v"(r2_));      // the loop was spilled, and its reload drains vmcnt
+                    o[r2_] = u;
+                    o[r2_ + 1] = v;
                 } else {
                     s_acc[row][0] = u;
                     s_acc[row][1] = v;
@@ -686,7 +709,9 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols400_fused_kernel(
         n2 = n2_n;
     }
 #undef MDX_FUSED_LOAD
-#undef MDX_FUSED_OK
+#undef MDX_FUSED_OK0
+#undef MDX_FUSED_OK1
+#undef MDX_FUSED_ROW
 }
 
 // D[b][t] += sum over the super groups (in order) of the partial x^2 sums, traj[b][t][k] likewise.
