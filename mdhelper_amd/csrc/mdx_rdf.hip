@@ -374,6 +374,10 @@ struct mdx_rdf {
     StagePipeline pipe;
     DeviceBuffer d_pw1, d_po1, d_bb1, d_pw2, d_po2, d_bb2;   // cell path: sorted copies + tile boxes
     DeviceBuffer d_bb16_1, d_bb16_2;                         // boxes of the CELL_CHUNK-particle chunks
+    // cell path: the sort of slab k + 1 runs on its own stream beside the pair kernel of slab k (two sets of the
+    // sorted copies); events hand the sets back and forth
+    hipStream_t sort_stream = nullptr;
+    hipEvent_t ev_inputs = nullptr, ev_sorted[2] = {nullptr, nullptr}, ev_paired[2] = {nullptr, nullptr};
     StreamTimer timer;
     int64_t pairs_evaluated = 0;    // ordered pair space covered: frames * n1 * n2
     int64_t pairs_bruteforce = 0;   // distance evaluations executed by the brute-force tiles
@@ -442,17 +446,36 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
     // (two-particle chunks take their boxes from the staged rows: no chunk-box array)
     constexpr int64_t CHUNK_BOX_BYTES = CELL_CHUNK >= 4 ? 32 / CELL_CHUNK : 0;
     const int64_t per_frame = (32 + 1 + CHUNK_BOX_BYTES) * (n1p + (self ? 0 : n2p));
-    int64_t slab = std::max<int64_t>(1, (int64_t(1) << 30) / per_frame);
+    // (MDX_RDF_SLAB_BYTES: test hook, so that small inputs run through several slabs and both sets)
+    const char *slab_env = getenv("MDX_RDF_SLAB_BYTES");
+    const int64_t slab_bytes = slab_env ? std::max<int64_t>(1, atoll(slab_env)) : (int64_t(1) << 30);
+    int64_t slab = std::max<int64_t>(1, slab_bytes / per_frame);
     slab = std::min<int64_t>(std::min<int64_t>(slab, 32768), n_frames);
-    MDX_TRY(h->d_pw1.ensure(size_t(16) * n1p * slab));
-    MDX_TRY(h->d_po1.ensure(size_t(16) * n1p * slab));
-    MDX_TRY(h->d_bb1.ensure(size_t(32) * (n1p / 64) * slab));
-    MDX_TRY(h->d_bb16_1.ensure(CELL_CHUNK >= 4 ? size_t(32) * (n1p / CELL_CHUNK) * slab : 256));
+    // two sets of the sorted copies when there is more than one slab: the sort of the next slab runs beside
+    // the pair kernel of this one (MDX_RDF_NO_OVERLAP=1: one set, one stream).  Sizes in float4 elements.
+    const bool no_overlap = getenv("MDX_RDF_NO_OVERLAP") != nullptr;
+    const int n_sets = (!no_overlap && slab < n_frames) ? 2 : 1;
+    const size_t e_p1 = size_t(n1p) * slab, e_b1 = size_t(n1p / 64) * 2 * slab;
+    const size_t e_c1 = CELL_CHUNK >= 4 ? size_t(n1p / CELL_CHUNK) * 2 * slab : 16;
+    const size_t e_p2 = size_t(n2p) * slab, e_b2 = size_t(n2p / 64) * 2 * slab;
+    const size_t e_c2 = CELL_CHUNK >= 4 ? size_t(n2p / CELL_CHUNK) * 2 * slab : 16;
+    MDX_TRY(h->d_pw1.ensure(16 * e_p1 * n_sets));
+    MDX_TRY(h->d_po1.ensure(16 * e_p1 * n_sets));
+    MDX_TRY(h->d_bb1.ensure(16 * e_b1 * n_sets));
+    MDX_TRY(h->d_bb16_1.ensure(16 * e_c1 * n_sets));
     if (!self) {
-        MDX_TRY(h->d_bb16_2.ensure(CELL_CHUNK >= 4 ? size_t(32) * (n2p / CELL_CHUNK) * slab : 256));
-        MDX_TRY(h->d_pw2.ensure(size_t(16) * n2p * slab));
-        MDX_TRY(h->d_po2.ensure(size_t(16) * n2p * slab));
-        MDX_TRY(h->d_bb2.ensure(size_t(32) * (n2p / 64) * slab));
+        MDX_TRY(h->d_bb16_2.ensure(16 * e_c2 * n_sets));
+        MDX_TRY(h->d_pw2.ensure(16 * e_p2 * n_sets));
+        MDX_TRY(h->d_po2.ensure(16 * e_p2 * n_sets));
+        MDX_TRY(h->d_bb2.ensure(16 * e_b2 * n_sets));
+    }
+    if (n_sets == 2 && !h->sort_stream) {
+        MDX_HIP(hipStreamCreateWithFlags(&h->sort_stream, hipStreamNonBlocking));
+        MDX_HIP(hipEventCreateWithFlags(&h->ev_inputs, hipEventDisableTiming));
+        for (int b = 0; b < 2; ++b) {
+            MDX_HIP(hipEventCreateWithFlags(&h->ev_sorted[b], hipEventDisableTiming));
+            MDX_HIP(hipEventCreateWithFlags(&h->ev_paired[b], hipEventDisableTiming));
+        }
     }
     unsigned *d_misc = h->d_misc.as<unsigned>();
     if (!tri)
@@ -485,29 +508,48 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
     else MDX_CELL_PICK(false, false);
 #undef MDX_CELL_PICK
 
-    for (int64_t f0 = 0; f0 < n_frames; f0 += slab) {
+    hipStream_t s_sort = n_sets == 2 ? h->sort_stream : h->stream;
+    if (n_sets == 2) {
+        // whatever produced the inputs was queued on h->stream (and so were the pair kernels of an earlier
+        // call, which read the sets)
+        MDX_HIP(hipEventRecord(h->ev_inputs, h->stream));
+        MDX_HIP(hipStreamWaitEvent(s_sort, h->ev_inputs, 0));
+    }
+    int64_t k_slab = 0;
+    for (int64_t f0 = 0; f0 < n_frames; f0 += slab, ++k_slab) {
         const int64_t nf = std::min(slab, n_frames - f0);
+        const int set = n_sets == 2 ? int(k_slab & 1) : 0;
+        float4 *pw1 = h->d_pw1.as<float4>() + set * e_p1, *po1 = h->d_po1.as<float4>() + set * e_p1;
+        float4 *bb1 = h->d_bb1.as<float4>() + set * e_b1, *bc1 = h->d_bb16_1.as<float4>() + set * e_c1;
+        float4 *pw2 = self ? pw1 : h->d_pw2.as<float4>() + set * e_p2;
+        float4 *po2 = self ? po1 : h->d_po2.as<float4>() + set * e_p2;
+        float4 *bb2 = self ? bb1 : h->d_bb2.as<float4>() + set * e_b2;
+        float4 *bc2 = self ? bc1 : h->d_bb16_2.as<float4>() + set * e_c2;
         {
+            if (n_sets == 2 && k_slab >= 2)   // the pair kernel that read this set two slabs ago
+                MDX_HIP(hipStreamWaitEvent(s_sort, h->ev_paired[set], 0));
             auto sort = tri ? rdf_cell_sort_kernel<true> : rdf_cell_sort_kernel<false>;
             const float *cells = tri ? d_tri + f0 * 9 : d_boxes + f0 * 6;
-            hipLaunchKernelGGL(sort, dim3((unsigned)nf), dim3(SORT_THREADS), 0, h->stream,
+            hipLaunchKernelGGL(sort, dim3((unsigned)nf), dim3(SORT_THREADS), 0, s_sort,
                                d_pos1 + f0 * n1 * 3, cells, (int)n1, (int)n1p, excl ? h->excl1 : 0,
-                               h->d_pw1.as<float4>(), h->d_po1.as<float4>(), h->d_bb1.as<float4>(),
-                               h->d_bb16_1.as<float4>(), d_misc);
+                               pw1, po1, bb1, bc1, d_misc);
             if (!self)
-                hipLaunchKernelGGL(sort, dim3((unsigned)nf), dim3(SORT_THREADS), 0, h->stream,
+                hipLaunchKernelGGL(sort, dim3((unsigned)nf), dim3(SORT_THREADS), 0, s_sort,
                                    d_pos2 + f0 * n2 * 3, cells, (int)n2, (int)n2p,
-                                   excl ? h->excl2 : 0, h->d_pw2.as<float4>(), h->d_po2.as<float4>(),
-                                   h->d_bb2.as<float4>(), h->d_bb16_2.as<float4>(), d_misc);
+                                   excl ? h->excl2 : 0, pw2, po2, bb2, bc2, d_misc);
+            if (n_sets == 2) {
+                MDX_HIP(hipEventRecord(h->ev_sorted[set], s_sort));
+                MDX_HIP(hipStreamWaitEvent(h->stream, h->ev_sorted[set], 0));
+            }
         }
         CellArgs a{};
-        a.pw1 = h->d_pw1.as<float4>();
-        a.po1 = h->d_po1.as<float4>();
-        a.bb1 = h->d_bb1.as<float4>();
-        a.pw2 = self ? a.pw1 : h->d_pw2.as<float4>();
-        a.po2 = self ? a.po1 : h->d_po2.as<float4>();
-        a.bb2 = self ? a.bb1 : h->d_bb2.as<float4>();
-        a.bb16_2 = self ? h->d_bb16_1.as<float4>() : h->d_bb16_2.as<float4>();
+        a.pw1 = pw1;
+        a.po1 = po1;
+        a.bb1 = bb1;
+        a.pw2 = pw2;
+        a.po2 = po2;
+        a.bb2 = bb2;
+        a.bb16_2 = bc2;
         a.tags_everywhere = (self && h->excl1 == 1 && h->excl2 == 1) ? 0 : 1;
         a.boxes = tri ? nullptr : d_boxes + f0 * 6;
         a.tri = tri ? d_tri + f0 * 9 : nullptr;
@@ -535,6 +577,8 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
             hipLaunchKernelGGL(kern, grid, dim3(256), lds, h->stream, a);
         }
         h->timer.end(ev);
+        if (n_sets == 2)
+            MDX_HIP(hipEventRecord(h->ev_paired[set], h->stream));
         MDX_HIP(hipGetLastError());
     }
     h->pairs_evaluated += n_frames * n1 * n2;
@@ -998,6 +1042,15 @@ int mdx_rdf_destroy(mdx_rdf_t h)
         b->release();
     h->grouping[0].release();
     h->grouping[1].release();
+    if (h->sort_stream) {
+        (void)hipStreamSynchronize(h->sort_stream);
+        (void)hipStreamDestroy(h->sort_stream);
+        (void)hipEventDestroy(h->ev_inputs);
+        for (int b = 0; b < 2; ++b) {
+            (void)hipEventDestroy(h->ev_sorted[b]);
+            (void)hipEventDestroy(h->ev_paired[b]);
+        }
+    }
     if (h->stream)
         (void)hipStreamDestroy(h->stream);
     delete h;

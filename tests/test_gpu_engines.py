@@ -143,6 +143,31 @@ def test_rdf_cell_tile_pairs_straddling_half_a_box(dims, exclusion):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("overlap", [True, False])
+def test_rdf_cell_many_slabs_sort_beside_pair_kernel(overlap, monkeypatch):
+    """Frames beyond one slab of sorted copies: the sort of slab k + 1 runs on its own stream beside the pair
+    kernel of slab k, on the other of two sets (mdx_rdf.hip::accumulate_cell).  MDX_RDF_SLAB_BYTES shrinks the slab
+    so that 23 frames take eight slabs; two groups, changing boxes, two accumulate calls on one engine."""
+    monkeypatch.setenv("MDX_RDF_SLAB_BYTES", str(3 * 33 * (3072 + 1024)))     # three frames per slab
+    if not overlap:
+        monkeypatch.setenv("MDX_RDF_NO_OVERLAP", "1")
+    rng = np.random.default_rng(41)
+    F, n1, n2 = 23, 3000, 1000
+    Ls = (36 + 4 * rng.random((F, 3))).astype(np.float32)
+    boxes = np.concatenate([Ls, np.full((F, 3), 90, np.float32)], axis=1)
+    a = (rng.random((F, n1, 3)) * Ls[:, None, :]).astype(np.float32)
+    b = (rng.random((F, n2, 3)) * Ls[:, None, :]).astype(np.float32)
+    want = np.zeros(90, dtype=np.int64)
+    for f in range(F):
+        want += c_radial_histogram(a[f], b[f], 90, (0.5, 11.0), boxes[f])
+    eng = _core.RdfEngine(_edges(90, (0.5, 11.0)), None, algo="cell")
+    eng.accumulate(a[:14], b[:14], boxes[:14])
+    eng.accumulate(a[14:], b[14:], boxes[14:])
+    got = eng.counts()
+    eng.close()
+    assert np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("exclusion", [None, (1, 1), (4, 4)])
 def test_rdf_cell_culling_regime(exclusion):
     """Enough particles and a short range: tiles are culled and take the shifted fast path."""
