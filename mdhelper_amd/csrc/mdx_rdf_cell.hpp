@@ -812,7 +812,9 @@ __global__ __launch_bounds__(256, TRI ? 4 : 6) void rdf_cell_pair_kernel(CellArg
             e = __builtin_amdgcn_readfirstlane(e);
             if (e >= nq)
                 break;
-            const unsigned code = sQ[e];
+            // (wave-uniform, but read from LDS: pinned into a scalar register, or the tile index and every j index
+            // derived from it live in vector registers and cost a VALU instruction per turn of the loops below)
+            const unsigned code = __builtin_amdgcn_readfirstlane(sQ[e]);
             const int Jt = int(code & 0x3fffffu);
             const float4 pj_raw = PW2[int64_t(Jt) * 64 + lane];
             // orthorhombic: one pass with the tile pair's image; triclinic: one pass per
@@ -954,15 +956,22 @@ __global__ __launch_bounds__(256, TRI ? 4 : 6) void rdf_cell_pair_kernel(CellArg
         asm volatile("" ::"v"(q.w));   /* whole 16-byte read */                                    \
         BODY                                                                                       \
     }
+// two adjacent rows per turn: both reads issued before the first wait
+#define MDX_CELL_ROW2_LOOP(TG, MASK, BODY)                                                         \
+    for (unsigned long long rem = (MASK); rem;) {                                                  \
+        const int r = __builtin_ctzll(rem);                                                        \
+        asm("s_bitset0_b64 %0, %1" : "+s"(rem) : "s"(r));                                          \
+        const float4 q = sJw[r], q1 = sJw[r + 1];                                                  \
+        asm volatile("" ::"v"(q.w), "v"(q1.w));                                                    \
+        BODY                                                                                       \
+    }
 #define MDX_CELL_UNITS_ROWS(TG)                                                                    \
     {                                                                                              \
         const unsigned long long both = sub & sub1;                                                \
         /* rows (2 k, 2 k + 1) that both survived against both halves: two reads, four steps per turn */ \
         const unsigned long long pairs = both & (both >> 1) & 0x5555555555555555ull;               \
         const unsigned long long paired = pairs | (pairs << 1);                                    \
-        MDX_CELL_ROW_LOOP(TG, pairs,                                                               \
-                          const float4 q1 = sJw[r + 1];                                            \
-                          asm volatile("" ::"v"(q1.w));                                            \
+        MDX_CELL_ROW2_LOOP(TG, pairs,                                                              \
                           MDX_CELL_HALF(TG, p0, i_base0, q, jbase + unsigned(r))                   \
                           MDX_CELL_HALF(TG, p0, i_base0, q1, jbase + unsigned(r) + 1u)             \
                           MDX_CELL_HALF(TG, p1, i_base0 + 64u, q, jbase + unsigned(r))             \
@@ -974,14 +983,10 @@ __global__ __launch_bounds__(256, TRI ? 4 : 6) void rdf_cell_pair_kernel(CellArg
         const unsigned long long only0 = sub & ~sub1, only1 = sub1 & ~sub;                         \
         const unsigned long long pairs0 = only0 & (only0 >> 1) & 0x5555555555555555ull;            \
         const unsigned long long pairs1 = only1 & (only1 >> 1) & 0x5555555555555555ull;            \
-        MDX_CELL_ROW_LOOP(TG, pairs0,                                                              \
-                          const float4 q1 = sJw[r + 1];                                            \
-                          asm volatile("" ::"v"(q1.w));                                            \
+        MDX_CELL_ROW2_LOOP(TG, pairs0,                                                             \
                           MDX_CELL_HALF(TG, p0, i_base0, q, jbase + unsigned(r))                   \
                           MDX_CELL_HALF(TG, p0, i_base0, q1, jbase + unsigned(r) + 1u))            \
-        MDX_CELL_ROW_LOOP(TG, pairs1,                                                              \
-                          const float4 q1 = sJw[r + 1];                                            \
-                          asm volatile("" ::"v"(q1.w));                                            \
+        MDX_CELL_ROW2_LOOP(TG, pairs1,                                                             \
                           MDX_CELL_HALF(TG, p1, i_base0 + 64u, q, jbase + unsigned(r))             \
                           MDX_CELL_HALF(TG, p1, i_base0 + 64u, q1, jbase + unsigned(r) + 1u))      \
         MDX_CELL_ROW_LOOP(TG, only0 & ~(pairs0 | (pairs0 << 1)),                                   \
@@ -1003,6 +1008,7 @@ __global__ __launch_bounds__(256, TRI ? 4 : 6) void rdf_cell_pair_kernel(CellArg
 #undef MDX_CELL_UNITS
 #undef MDX_CELL_UNITS_ROWS
 #undef MDX_CELL_ROW_LOOP
+#undef MDX_CELL_ROW2_LOOP
 #undef MDX_CELL_UNITS_CHUNKS
 #undef MDX_CELL_HALF
                 if (__builtin_expect(wv.overflow != 0u, 0)) {
