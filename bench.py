@@ -746,7 +746,7 @@ def run_extras(args, world):
     extra = {}
     plan = (("sq", dict(workload="sq", frames=1000, steps=3, warmup=1)),
             ("msd", dict(workload="msd", frames=None, steps=6, warmup=1)),
-            ("rdf_wide", dict(workload="rdf_wide", frames=1000, steps=2, warmup=1)))
+            ("rdf_wide", dict(workload="rdf_wide", frames=1000, steps=3, warmup=1)))
     for name, over in plan:
         a = copy.copy(args)
         a.atoms, a.blocks, a.algo, a.host_path, a.traj_file, a.shard_fixed = None, 1, "auto", False, False, False
