@@ -852,20 +852,19 @@ __global__ __launch_bounds__(256, TRI ? 4 : 6) void rdf_cell_pair_kernel(CellArg
             if (!gen) {
                 float sg2 = __int_as_float(0x7f800000);
                 if (CELL_CHUNK == 1) {
-                    // NaN padding rows fail both comparisons (the gap is formed without fmax's NaN filter first)
+                    // (fmaxf drops a NaN: the NaN padding rows are taken out by a test of their own)
                     float g0 = 0.f, g1 = 0.f;
                     const float pc[3] = {pj.x, pj.y, pj.z};
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
-                        const float d0 = fabsf(pc[k] - s_geo[14 + k]) - s_geo[20 + k];
-                        const float d1 = fabsf(pc[k] - s_geo[17 + k]) - s_geo[23 + k];
-                        const float a0 = d0 > 0.f ? d0 : (d0 == d0 ? 0.f : d0);
-                        const float a1 = d1 > 0.f ? d1 : (d1 == d1 ? 0.f : d1);
+                        const float a0 = fmaxf(0.f, fabsf(pc[k] - s_geo[14 + k]) - s_geo[20 + k]);
+                        const float a1 = fmaxf(0.f, fabsf(pc[k] - s_geo[17 + k]) - s_geo[23 + k]);
                         g0 = __fmaf_rn(a0, a0, g0);
                         g1 = __fmaf_rn(a1, a1, g1);
                     }
-                    sub1 = __ballot(g1 <= s_geo[7]);
-                    sg2 = g0;
+                    const bool real_row = pj.x == pj.x;
+                    sub1 = __ballot(real_row && g1 <= s_geo[7]);
+                    sg2 = real_row ? g0 : __int_as_float(0x7f800000);
                 } else if (CELL_CHUNK == 2) {
                     // chunk = lane pair: its box comes from the staged rows themselves (one
                     // cross-lane exchange), no box array; NaN padding drops out of fmin / fmax,
