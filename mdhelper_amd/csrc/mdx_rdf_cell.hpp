@@ -87,15 +87,16 @@ struct CellGrid {
             invLd[k] = 1.0 / Ld[k];
             vol *= Ld[k];
         }
-        // Columns of cross-section a x a along z, a^3 = the volume of 64 particles, cut into layers of ~8
-        // particles: sorted column by column and layer by layer, 64 consecutive particles are a slab of a column
+        // Columns of cross-section a x a along z, a^3 = the volume of 64 particles, cut into layers of ~4
+        // particles (a / 16 thick; with ~8 per layer 1 % slower, with ~2 the sort costs what the boxes gain):
+        // sorted column by column and layer by layer, 64 consecutive particles are a slab of a column
         // about `a` thick — a box of a x a x a wherever the 64 begin.  (With cubic cells in 2x2x2 bricks a group of 64
         // that straddled two bricks was two bricks long: mean extents 8.4 x 9.1 x 15.0 A at C2, now 8.5 x 9.2 x 8.8;
         // the volume within the cutoff of such a box, which is what the pair kernel evaluates, is 16 % smaller.)
         const double a = cbrt(64.0 * vol / (double)max(n, 1));
         nc[0] = min(max((int)rint(Ld[0] / a), 1), 64);
         nc[1] = min(max((int)rint(Ld[1] / a), 1), 64);
-        nc[2] = max((int)rint(8.0 * Ld[2] / a), 1);
+        nc[2] = max((int)rint(16.0 * Ld[2] / a), 1);
         while (nc[0] * nc[1] * nc[2] > CELL_MAX)   // thicker layers until the table fits
             nc[2] = (nc[2] + 1) / 2;
     }
