@@ -483,11 +483,11 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
                            0, h->stream, d_boxes, n_frames, d_misc + 1);
 
     // LDS of the pair kernel: 4 wave slabs + thresholds + the histogram in n_hist interleaved replicas
-    // (HistLdsRep): 8 while six blocks of a CU still fit (the kernel's static LDS is ~9 KB), fewer for
+    // (HistLdsRep): 8 while seven blocks of a CU still fit (the kernel's static LDS is 8.4 KB), fewer for
     // long bin tables
     size_t base = sizeof(float4) * 256 + sizeof(double) * (h->n_bins + 1);
     const size_t lds_budget = 64 * 1024;
-    const size_t lds_six_blocks = 17 * 1024;
+    const size_t lds_six_blocks = 13 * 1024;   // seven blocks of a CU: (160 KB / 7) - 8.4 KB static
     int n_hist = 8;
     while (n_hist > 4 && base + size_t(n_hist) * cell_hist_stride(h->n_bins) * 4 > lds_six_blocks)
         n_hist >>= 1;

@@ -583,7 +583,9 @@ __device__ inline void cell_slow_unit(const CellHot &c, const CellArgs &a, const
 }
 
 template <bool EXCL, bool LOWER, int MODE, bool TRI = false>
-__global__ __launch_bounds__(256, TRI ? 4 : 6) void rdf_cell_pair_kernel(CellArgs a)
+// (seven waves per SIMD: 72 VGPRs with 12 more bytes of scratch in the prologue than at six and 80 — +4 % at C2(i);
+// eight do not fit the LDS of seven blocks and lose to their spills)
+__global__ __launch_bounds__(256, TRI ? 4 : 7) void rdf_cell_pair_kernel(CellArgs a)
 {
     constexpr bool GH = MODE == 1;
     extern __shared__ __align__(16) unsigned char smem_raw[];
