@@ -741,6 +741,20 @@ int Trajectory::stage_async(int device, hipStream_t stream, const int64_t *frame
         }
         MDX_HIP(hipGetLastError());
     }
+    // The pinned buffers' hand-over events do not outlive this call unfinished: the stream belongs to the
+    // caller's engine, and the next call may come from another engine after this one (and its stream) is gone —
+    // an event that still refers to a destroyed stream made a later launch fail now and then ("operation not
+    // permitted on an event last recorded in a capturing stream").  Fresh events per stream (ensure_pipeline).
+    for (int b = 0; b < 2; ++b)
+        if (pinned_busy[b]) {
+            MDX_HIP(hipEventSynchronize(ev_free[b]));
+            pinned_busy[b] = false;
+        }
+    for (int b = 0; b < 2; ++b)
+        if (ev_free[b]) {
+            MDX_HIP(hipEventDestroy(ev_free[b]));
+            ev_free[b] = nullptr;
+        }
     return MDX_OK;
 }
 
