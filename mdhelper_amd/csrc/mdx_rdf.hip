@@ -455,18 +455,23 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
     // the pair kernel of this one (MDX_RDF_NO_OVERLAP=1: one set, one stream).  Sizes in float4 elements.
     const bool no_overlap = getenv("MDX_RDF_NO_OVERLAP") != nullptr;
     const int n_sets = (!no_overlap && slab < n_frames) ? 2 : 1;
+    // exclusion 0 or 1: a particle's tag is its row, and the exact path reads the frames as they came in —
+    // no sorted copy of the original coordinates (half of the sort kernel's scattered stores)
+    const bool lazy_orig = !tri && h->excl1 <= 1 && h->excl2 <= 1 && !getenv("MDX_RDF_SORTED_ORIGINALS");
     const size_t e_p1 = size_t(n1p) * slab, e_b1 = size_t(n1p / 64) * 2 * slab;
     const size_t e_c1 = CELL_CHUNK >= 4 ? size_t(n1p / CELL_CHUNK) * 2 * slab : 16;
     const size_t e_p2 = size_t(n2p) * slab, e_b2 = size_t(n2p / 64) * 2 * slab;
     const size_t e_c2 = CELL_CHUNK >= 4 ? size_t(n2p / CELL_CHUNK) * 2 * slab : 16;
     MDX_TRY(h->d_pw1.ensure(16 * e_p1 * n_sets));
-    MDX_TRY(h->d_po1.ensure(16 * e_p1 * n_sets));
+    if (!lazy_orig)
+        MDX_TRY(h->d_po1.ensure(16 * e_p1 * n_sets));
     MDX_TRY(h->d_bb1.ensure(16 * e_b1 * n_sets));
     MDX_TRY(h->d_bb16_1.ensure(16 * e_c1 * n_sets));
     if (!self) {
         MDX_TRY(h->d_bb16_2.ensure(16 * e_c2 * n_sets));
         MDX_TRY(h->d_pw2.ensure(16 * e_p2 * n_sets));
-        MDX_TRY(h->d_po2.ensure(16 * e_p2 * n_sets));
+        if (!lazy_orig)
+            MDX_TRY(h->d_po2.ensure(16 * e_p2 * n_sets));
         MDX_TRY(h->d_bb2.ensure(16 * e_b2 * n_sets));
     }
     if (n_sets == 2 && !h->sort_stream) {
@@ -519,10 +524,11 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
     for (int64_t f0 = 0; f0 < n_frames; f0 += slab, ++k_slab) {
         const int64_t nf = std::min(slab, n_frames - f0);
         const int set = n_sets == 2 ? int(k_slab & 1) : 0;
-        float4 *pw1 = h->d_pw1.as<float4>() + set * e_p1, *po1 = h->d_po1.as<float4>() + set * e_p1;
+        float4 *pw1 = h->d_pw1.as<float4>() + set * e_p1;
+        float4 *po1 = lazy_orig ? nullptr : h->d_po1.as<float4>() + set * e_p1;
         float4 *bb1 = h->d_bb1.as<float4>() + set * e_b1, *bc1 = h->d_bb16_1.as<float4>() + set * e_c1;
         float4 *pw2 = self ? pw1 : h->d_pw2.as<float4>() + set * e_p2;
-        float4 *po2 = self ? po1 : h->d_po2.as<float4>() + set * e_p2;
+        float4 *po2 = self ? po1 : (lazy_orig ? nullptr : h->d_po2.as<float4>() + set * e_p2);
         float4 *bb2 = self ? bb1 : h->d_bb2.as<float4>() + set * e_b2;
         float4 *bc2 = self ? bc1 : h->d_bb16_2.as<float4>() + set * e_c2;
         {
@@ -550,6 +556,10 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
         a.po2 = po2;
         a.bb2 = bb2;
         a.bb16_2 = bc2;
+        a.in1 = lazy_orig ? d_pos1 + f0 * n1 * 3 : nullptr;
+        a.in2 = lazy_orig ? d_pos2 + f0 * n2 * 3 : nullptr;
+        a.n1_in = (int)n1;
+        a.n2_in = (int)n2;
         a.tags_everywhere = (self && h->excl1 == 1 && h->excl2 == 1) ? 0 : 1;
         a.boxes = tri ? nullptr : d_boxes + f0 * 6;
         a.tri = tri ? d_tri + f0 * 9 : nullptr;
@@ -1281,8 +1291,10 @@ int mdx_rdf_debug_sorted(mdx_rdf_t h, int64_t frame, int64_t n_pad, float *pw, f
     MDX_REQUIRE(h->d_pw1.bytes >= size_t(16) * n_pad * (frame + 1), "frame outside the last slab");
     MDX_HIP(hipMemcpy(pw, h->d_pw1.as<float4>() + frame * n_pad, size_t(16) * n_pad,
                       hipMemcpyDeviceToHost));
-    MDX_HIP(hipMemcpy(po, h->d_po1.as<float4>() + frame * n_pad, size_t(16) * n_pad,
-                      hipMemcpyDeviceToHost));
+    // (exclusion 0 or 1: the sorted originals are not materialised; the wrapped copies are returned twice)
+    const bool have_po = h->d_po1.bytes >= size_t(16) * n_pad * (frame + 1);
+    MDX_HIP(hipMemcpy(po, (have_po ? h->d_po1.as<float4>() : h->d_pw1.as<float4>()) + frame * n_pad,
+                      size_t(16) * n_pad, hipMemcpyDeviceToHost));
     return MDX_OK;
 }
 

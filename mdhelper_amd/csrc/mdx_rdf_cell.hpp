@@ -33,6 +33,10 @@ struct CellArgs {
     const float4 *pw1, *po1, *bb1;
     const float4 *pw2, *po2, *bb2;
     const float4 *bb16_2;        // boxes of the CELL_CHUNK-particle chunks of the j side
+    // po1 / po2 == nullptr: the sorted originals are not materialised; a particle's tag IS its index in the
+    // set (exclusion 0 or 1) and the exact path reads in1 / in2 = the frames as they came in, [frame][n][3]
+    const float *in1, *in2;
+    int n1_in, n2_in;
     const float *boxes;          // [frames][6] (orthorhombic frames)
     const float *tri;            // [frames][9] cell matrices (triclinic kernel variant)
     const double *thresh;        // [n_bins+1]
@@ -274,12 +278,14 @@ __global__ __launch_bounds__(SORT_THREADS) void rdf_cell_sort_kernel(
         unsigned slot = atomicAdd(&cnt[g.key(cx, cy, cz)], 1u);
         float tag = __int_as_float(excl > 0 ? int(int64_t(a) / excl) : a);
         PW[slot] = make_float4(wx, wy, wz, tag);
-        PO[slot] = make_float4(x, y, z, tag);
+        if (po)
+            PO[slot] = make_float4(x, y, z, tag);
     }
     const float qnan = __int_as_float(0x7fc00000);
     for (int a = n + tid; a < n_pad; a += SORT_THREADS) {
         PW[a] = make_float4(qnan, qnan, qnan, __int_as_float(-1));
-        PO[a] = make_float4(qnan, qnan, qnan, __int_as_float(-1));
+        if (po)
+            PO[a] = make_float4(qnan, qnan, qnan, __int_as_float(-1));
     }
     __threadfence_block();
     __syncthreads();
@@ -346,15 +352,32 @@ __device__ inline double rdf_rsq_contract_tri(const float *Bf, const float4 &pi,
 
 template <typename Hist>
 __device__ inline void cell_pair_exact(const PairCtx<true> &c, const CellArgs &a,
-                                             const double *sT, const Hist &hist, const float4 *po_i,
-                                             const float4 *po_j, unsigned w,
+                                             const double *sT, const Hist &hist, const float4 &po_i,
+                                             const float4 &po_j, unsigned w,
                                              const float *tri = nullptr)
 {
-    double rsq = tri ? rdf_rsq_contract_tri(tri, *po_i, *po_j)
-                     : rdf_rsq_contract<true>(c, *po_i, *po_j);
+    double rsq = tri ? rdf_rsq_contract_tri(tri, po_i, po_j)
+                     : rdf_rsq_contract<true>(c, po_i, po_j);
     if ((rsq >= a.t_lo) && (rsq < a.t_hi))
         hist.add(rdf_bin_exact(rsq, sT, a.n_bins, c.r0f, c.inv_wf), w);
 }
+
+// Original (unwrapped) coordinates of sorted particle `idx` of a frame, for the exact path: the sorted copy where
+// it exists, else the incoming row named by the particle's tag (CellArgs::in1).  Half the scattered stores of the
+// sort kernel — two thirds of its time — were this copy, read by ~10^-3 of the evaluations.
+struct CellOrig {
+    const float4 *po;   // sorted originals of the frame, or nullptr
+    const float4 *pw;   // sorted wrapped copies of the frame (.w = tag = row index when po is nullptr)
+    const float *in;    // the frame as it came in, [n][3]
+    __device__ inline float4 at(unsigned idx) const
+    {
+        if (po)
+            return po[idx];
+        const float tag = pw[idx].w;
+        const float *r = in + 3 * (int64_t)__float_as_int(tag);
+        return make_float4(r[0], r[1], r[2], tag);
+    }
+};
 
 // wave-uniform float constants of the hot loop, forced into SGPRs
 struct CellHot {
@@ -510,8 +533,8 @@ __device__ inline void cell_step(const CellHot &c, const CellArgs &a, const Hist
 // Exact arithmetic for the listed pairs, 64 at a time, one per lane (the list is wave-private).
 template <typename Hist>
 __device__ inline void cell_flush(const CellHot &c, const CellArgs &a, const double *sT,
-                                  const Hist &hist, CellWave &wv, const float4 *po1f,
-                                  const float4 *po2f)
+                                  const Hist &hist, CellWave &wv, const CellOrig &po1f,
+                                  const CellOrig &po2f)
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -522,7 +545,7 @@ __device__ inline void cell_flush(const CellHot &c, const CellArgs &a, const dou
     for (unsigned e0 = 0; e0 < wv.n_todo; e0 += 64u) {
         if (e0 + lane < wv.n_todo) {
             const uint2 e = wv.todo[e0 + lane];
-            cell_pair_exact(cx, a, sT, hist, po1f + e.x, po2f + (e.y & 0x7fffffffu),
+            cell_pair_exact(cx, a, sT, hist, po1f.at(e.x), po2f.at(e.y & 0x7fffffffu),
                             (e.y >> 31) + 1u, c.tri);
         }
     }
@@ -541,8 +564,8 @@ template <bool LOWER, bool EXCL, typename Hist>
 __device__ inline void cell_slow_unit(const CellHot &c, const CellArgs &a, const double *sT,
                                       const Hist &hist, const float4 *sJw, int j0, int nj,
                                       unsigned u_mask, bool tags, int general, const float *geo,
-                                      const float4 &p0, const float4 &p1, const float4 *po1f,
-                                      const float4 *po2f, unsigned i_idx0, unsigned jbase,
+                                      const float4 &p0, const float4 &p1, const CellOrig &po1f,
+                                      const CellOrig &po2f, unsigned i_idx0, unsigned jbase,
                                       unsigned w, CellWave &wv)
 {
     for (int jj = j0; jj < j0 + nj; ++jj) {
@@ -708,11 +731,14 @@ __global__ __launch_bounds__(256, TRI ? 4 : 7) void rdf_cell_pair_kernel(CellArg
     HistGlobal hg{out};
 
     const float4 *PW1 = a.pw1 + int64_t(frame) * a.n1p + int64_t(I) * 128;
-    const float4 *PO1f = a.po1 + int64_t(frame) * a.n1p;     // this frame's original coordinates
+    // this frame's original coordinates
+    const CellOrig PO1f{a.po1 ? a.po1 + int64_t(frame) * a.n1p : nullptr, a.pw1 + int64_t(frame) * a.n1p,
+                        a.in1 ? a.in1 + int64_t(frame) * a.n1_in * 3 : nullptr};
     const unsigned i_base0 = unsigned(I) * 128u;   // wave-uniform; + lane = this lane's i index
     const unsigned i_idx0 = i_base0 + unsigned(lane);
     const float4 *PW2 = a.pw2 + int64_t(frame) * a.n2p;
-    const float4 *PO2 = a.po2 + int64_t(frame) * a.n2p;
+    const CellOrig PO2{a.po2 ? a.po2 + int64_t(frame) * a.n2p : nullptr, a.pw2 + int64_t(frame) * a.n2p,
+                       a.in2 ? a.in2 + int64_t(frame) * a.n2_in * 3 : nullptr};
     const float4 *BB2 = a.bb2 + int64_t(frame) * t64_2 * 2;
     const float4 *BB16 = a.bb16_2 + int64_t(frame) * t64_2 * 2 * CELL_NCHUNK;
     const float4 p0 = PW1[lane], p1 = PW1[64 + lane];
