@@ -59,11 +59,14 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="rdf", choices=["rdf", "rdf_wide", "sq", "msd", "isf"])
+    ap.add_argument("--workload", default="rdf", choices=["rdf", "rdf_wide", "sq", "msd", "isf", "ingest"])
     ap.add_argument("--frames", type=int, default=None, help="frames per step per GPU")
     ap.add_argument("--atoms", type=int, default=None)
     ap.add_argument("--algo", default="auto", choices=["auto", "exact", "filter", "cell"])
     ap.add_argument("--blocks", type=int, default=1, help="msd: n_blocks (C4 is quoted for 1 and 8)")
+    ap.add_argument("--n-points", type=int, default=8,
+                    help="sq: grid points per axis (8 -> the 512 wavevectors of C3; 32 -> the reference's "
+                         "default StructureFactor grid of 32 768, structure.py:1324, 1376-1381)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="rdf at N=1: skip the short C3 / C4 / C2(ii) legs embedded under 'extra'")
@@ -202,6 +205,61 @@ def profiled(key, *sources):
     return entry
 
 
+def max_rel_deviation(got, ref, floor=1e-9):
+    """Largest element-wise relative deviation over the entries whose reference magnitude exceeds
+    ``floor`` x the largest one (entries that are pure round-off — lag 0 of an MSD — are left out):
+    max |got - ref| / |ref|, not a norm over the array."""
+    got, ref = np.asarray(got), np.asarray(ref)
+    mag = np.abs(ref)
+    keep = mag > floor * mag.max()
+    return float((np.abs(got - ref)[keep] / mag[keep]).max())
+
+
+def write_amber_netcdf_fast(path, positions, box):
+    """AMBER NetCDF (64-bit-offset container, the reference's own, openmm/file.py:49-52) of
+    float32[F, N, 3] frames with one cell for all of them: the header comes from scipy.io.netcdf_file
+    (an independent NetCDF-3 writer) with one record, the F records are then written as one
+    big-endian structured array — scipy's own per-record writes take minutes at bench sizes.
+    tests/test_traj_io.py reads such a file back through scipy."""
+    from scipy.io import netcdf_file
+    F, N, _ = positions.shape
+    with netcdf_file(path, "w", version=2) as nc:
+        nc.Conventions = "AMBER"
+        nc.ConventionVersion = "1.0"
+        nc.createDimension("frame", None)
+        nc.createDimension("spatial", 3)
+        nc.createDimension("atom", N)
+        nc.createDimension("cell_spatial", 3)
+        nc.createDimension("cell_angular", 3)
+        v_t = nc.createVariable("time", "f", ("frame",))
+        v_x = nc.createVariable("coordinates", "f", ("frame", "atom", "spatial"))
+        v_l = nc.createVariable("cell_lengths", "d", ("frame", "cell_spatial"))
+        v_a = nc.createVariable("cell_angles", "d", ("frame", "cell_angular"))
+        v_t[0] = 0.0
+        v_x[0] = positions[0]
+        v_l[0] = box[:3]
+        v_a[0] = box[3:]
+    # record variables are laid out in definition order, each padded to 4 bytes; the file ends
+    # with its single record
+    rec = np.dtype([("time", ">f4"), ("coordinates", ">f4", (N, 3)), ("cell_lengths", ">f8", (3,)),
+                    ("cell_angles", ">f8", (3,))])
+    first = os.path.getsize(path) - rec.itemsize
+    with open(path, "r+b") as fh:
+        fh.seek(4)
+        fh.write(int(F).to_bytes(4, "big"))          # numrecs
+        fh.seek(first)
+        step = max(1, (256 << 20) // rec.itemsize)
+        for f0 in range(0, F, step):
+            n = min(step, F - f0)
+            block = np.empty(n, dtype=rec)
+            block["time"] = np.arange(f0, f0 + n)
+            block["coordinates"] = positions[f0:f0 + n]
+            block["cell_lengths"] = box[:3]
+            block["cell_angles"] = box[3:]
+            block.tofile(fh)
+        fh.truncate()
+
+
 RDF_SOURCES = ("mdx_rdf.hip", "mdx_rdf_cell.hpp", "mdx_rdf_device.hpp")
 MSD_SOURCES = ("mdx_msd.hip", "mdx_msd_fft.hpp")
 SQ_SOURCES = ("mdx_sq.hip", "mdx_sq_device.hpp")
@@ -231,27 +289,11 @@ def bench_rdf(args, world, wide=False):
     traj_file = None
     if args.traj_file:
         import tempfile
-        from scipy.io import netcdf_file
         from mdhelper_amd.io import TrajectoryFile
         h_traj = traj.to_host()
         tmp = tempfile.NamedTemporaryFile(suffix=".nc", delete=False)
         tmp.close()
-        with netcdf_file(tmp.name, "w", version=2) as nc:
-            nc.Conventions = "AMBER"
-            nc.createDimension("frame", None)
-            nc.createDimension("spatial", 3)
-            nc.createDimension("atom", N)
-            nc.createDimension("cell_spatial", 3)
-            nc.createDimension("cell_angular", 3)
-            v_t = nc.createVariable("time", "f", ("frame",))
-            v_x = nc.createVariable("coordinates", "f", ("frame", "atom", "spatial"))
-            v_l = nc.createVariable("cell_lengths", "d", ("frame", "cell_spatial"))
-            v_a = nc.createVariable("cell_angles", "d", ("frame", "cell_angular"))
-            for f in range(F):
-                v_t[f] = f
-                v_x[f] = h_traj[f]
-                v_l[f] = box[:3]
-                v_a[f] = box[3:]
+        write_amber_netcdf_fast(tmp.name, h_traj, box)
         del h_traj
         traj_file = TrajectoryFile(tmp.name)
         my_frames = np.arange(lo, hi)
@@ -299,6 +341,8 @@ def bench_rdf(args, world, wide=False):
     alg_bytes_per_launch = args.steps * F_mine * (12 * N + 24) / launches
     achieved = alg_bytes_per_launch * launches / kernel_s / 1e9 if kernel_s > 0 else 0.0
     steps64 = st["pairs_computed"] / 64.0          # hot-loop trips: 64 distance evaluations each
+    # this rank's own share of the reduced counts (weak scaling: every rank bins the same amount)
+    binned_mine = binned / (1 if args.shard_fixed else world.world) * (F_mine / max(F, 1) if args.shard_fixed else 1.0)
     celled = args.algo in ("auto", "cell")
     # VALU / SALU / LDS instructions per hot-loop trip and the engine clock under this kernel come from
     # SQ counters of a separate rocprofv3 pass over the SAME sources (scripts/profile_counters.sh ->
@@ -310,7 +354,14 @@ def bench_rdf(args, world, wide=False):
         clk = clock or ctr.get("clock_hz") or CLOCK_HZ
         cyc_per_step = ctr["valu_plain_per_step"] * VALU_CYCLES + ctr["valu_trans_per_step"] * VALU_TRANS_CYCLES
         issue = steps64 / kernel_s * cyc_per_step            # SIMD issue cycles consumed per second
+        # useful work beside the utilisation: the hot step's own 13 instructions (12 plain + v_sqrt_f32 =
+        # 28 issue cycles per 64 distance evaluations), counted once per evaluation that was made and
+        # once per evaluation that ended in a bin
+        useful = steps64 / kernel_s * (12 * VALU_CYCLES + VALU_TRANS_CYCLES)
+        binned_share = min(1.0, binned_mine / max(st["pairs_computed"], 1))
         valu = {"achieved": issue / 1e9, "peak": SIMDS * clk / 1e9, "frac": issue / (SIMDS * clk),
+                "frac_evaluations": useful / (SIMDS * clk),
+                "frac_binned": useful * binned_share / (SIMDS * clk),
                 "frac_at_nominal_clock": issue / (SIMDS * CLOCK_HZ),
                 "clock_hz": clk, "clock_source": "s_memtime / s_memrealtime inside this run's kernel"
                 if clock else "profiles/counters.json",
@@ -332,13 +383,17 @@ def bench_rdf(args, world, wide=False):
         "bound": "valu", "unit": "G SIMD issue cycles/s",
         "achieved": valu["achieved"] if valu else None, "peak": valu["peak"] if valu else SIMDS * CLOCK_HZ / 1e9,
         "frac": valu["frac"] if valu else None,
+        "frac_evaluations": valu["frac_evaluations"] if valu else None,
+        "frac_binned": valu["frac_binned"] if valu else None,
         "traffic": hbm["traffic"],
         "kernel": "rdf_cell_pair_kernel" if celled else "rdf_tile_kernel",
         "kernel_ms_per_launch": st["kernel_ms"] / launches,
         "definition": "hot-loop trips/s (64 distance evaluations each, counted by the kernel) x VALU issue "
                       "cycles per trip (SQ_INSTS_VALU per trip from profiles/, 2 cycles per wave64 VALU "
                       "instruction on a SIMD-32, 4 for v_sqrt_f32: MI355X_MICROARCH.md) / (1024 SIMDs x "
-                      "engine clock measured inside the kernel)",
+                      "engine clock measured inside the kernel); frac_evaluations / frac_binned: the same with "
+                      "the hot step's own 13 instructions (28 cycles) per 64 evaluations made / binned — "
+                      "useful work instead of issue-slot utilisation; traffic: sort + pair kernels",
         "valu": valu,
         "hbm": hbm,
         "work": {
@@ -472,8 +527,8 @@ def bench_sq(args, world):
     N = args.atoms or 32768
     F = args.frames or 1000
     L = 68.94
-    # 512 grid wavevectors, numpy.meshgrid's default 'xy' order (structure.py:1379-1381)
-    grid = 2 * np.pi * np.arange(8) / L
+    # n_points^3 grid wavevectors (512 at C3), numpy.meshgrid's default 'xy' order (structure.py:1379-1381)
+    grid = 2 * np.pi * np.arange(args.n_points) / L
     q = np.stack(np.meshgrid(grid, grid, grid), -1).reshape(-1, 3)
     sizes = [N // 2, N - N // 2]
     pairs = ((0, 0), (0, 1), (1, 1))               # mode="partial" (structure.py:1459-1464)
@@ -519,7 +574,9 @@ def bench_sq(args, world):
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong" if args.shard_fixed else "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"C3 partial S(q) {N} atoms, {len(q)} wavevectors, 2 groups, {F} frames"
+        "config": {"workload": ("C3" if len(q) == 512 else f"n_points={args.n_points} (reference default grid)"
+                                if args.n_points == 32 else f"n_points={args.n_points}")
+                               + f" partial S(q) {N} atoms, {len(q)} wavevectors, 2 groups, {F} frames"
                                + ("/job/step (fixed set, sharded)" if args.shard_fixed else "/GPU/step")},
         "frames_per_sec": frames_total / dt,
         "per_rank_frames_per_sec": world.gather(args.steps * F_mine / own),
@@ -540,17 +597,21 @@ def bench_sq(args, world):
     }
     if world.rank == 0 and world.world == 1 and not args.no_cpu_baseline:
         from oracle import fourier as of
-        n_f = 2
-        sample = traj.to_host(0, n_f).astype(np.float64)
+        # bounded sample: whole frames at C3, the first atoms of one frame for larger wavevector sets
+        n_f = 2 if len(q) <= 512 else 1
+        n_s = N if len(q) <= 512 else max(256, min(N, int(6e7 // len(q))))
+        sample = traj.to_host(0, n_f)[:, :n_s].astype(np.float64)
         t0 = time.perf_counter()
         refs = [of.fourier_sum_ref(q, sample[f]) for f in range(n_f)]
         t_cpu = time.perf_counter() - t0
         got = _core.fourier_sum_device(q, sample[0], dev=dev)
-        err = float(np.abs(got - refs[0]).max() / np.abs(refs[0]).max())
-        out["cpu_baseline"] = {"value": n_f * float(N) * len(q) / t_cpu, "unit": "evals/s", "cores": 1,
-                               "kind": "port", "sample": f"{n_f} bench frames, numpy exp(1j q.r) in q-chunks "
-                                                         f"(oracle/fourier.py; accelerated.py:81-122), {t_cpu:.1f} s",
-                               "gpu_max_rel_deviation_on_sample": err}
+        out["cpu_baseline"] = {"value": n_f * float(n_s) * len(q) / t_cpu, "unit": "evals/s", "cores": 1,
+                               "kind": "port", "sample": f"{n_f} bench frame(s) x {n_s} atoms, numpy exp(1j q.r) in "
+                                                         f"q-chunks (oracle/fourier.py; accelerated.py:81-122), "
+                                                         f"{t_cpu:.1f} s",
+                               "gpu_max_rel_deviation_on_sample": max_rel_deviation(got, refs[0]),
+                               "deviation_metric": "max over wavevectors of |got - ref| / |ref| (element-wise; "
+                                                   "entries below 1e-9 of the largest left out)"}
     eng.close()
     traj.free()
     return out
@@ -624,8 +685,13 @@ def bench_isf(args, world):
         gc, gi = small.result()
         small.close()
         norm = n_s * np.arange(f_s, f_s - lags_s, -1)[:, None, None]
-        err = max(float(np.abs(gc / norm - ref["cisf"]).max() / np.abs(ref["cisf"]).max()),
-                  float(np.abs(gi / norm - ref["iisf"]).max() / np.abs(ref["iisf"]).max()))
+        # element-wise on the incoherent part (positive, O(1) after normalisation); the coherent part
+        # passes through zero, so its deviation is taken against the geometric mean of the two
+        # self terms' scale, i.e. the lag-0 coherent value of the same wavevector
+        err_i = max_rel_deviation(gi / norm, ref["iisf"], floor=1e-6)
+        scale_c = np.maximum(np.abs(ref["cisf"][0:1]).max(axis=1, keepdims=True), 1e-30)
+        err_c = float((np.abs(gc / norm - ref["cisf"]) / scale_c).max())
+        err = max(err_i, err_c)
         terms = float(n_s) * len(q) * (f_s + sum(min(f + 1, lags_s) for f in range(f_s)))
         out["cpu_baseline"] = {"value": terms / t_cpu, "unit": "evals/s", "cores": 1, "kind": "port",
                                "sample": f"{f_s} frames x {n_s} atoms x {lags_s} lags, numpy restatement "
@@ -727,15 +793,124 @@ def bench_msd(args, world):
         got = chk.result()[0][0, 0]
         chk.close()
         small.free()
-        err = float(np.abs(got - ref).max() / np.abs(ref).max())
+        err = max_rel_deviation(got[1:], ref[1:], floor=0.0)     # every lag but 0 (pure round-off there)
         out["cpu_baseline"] = {"value": n_s * float(T) / t_cpu, "unit": "atom-frames/s", "cores": 1,
                                "kind": "port",
                                "sample": f"{n_s} particles x {T} frames, scipy-FFT msd_fft restatement "
                                          f"(oracle/correlation.py; correlation.py:461-668), {t_cpu:.1f} s",
-                               "gpu_max_rel_deviation_on_sample": err}
+                               "gpu_max_rel_deviation_on_sample": err,
+                               "deviation_metric": "max over lags 1..T-1 of |got - ref| / |ref| (element-wise)"}
     eng.close()
     traj.free()
     return out
+
+
+def bench_rdf_ingest(args, world, resident_fps):
+    """
+    The drop-in path at the kernel's rate (N = 1 only; never the headline value): the same C2(i)
+    analysis fed the ways a user of the reference feeds it, each leg with frames/s and its ratio
+    to the HBM-resident figure of this run.
+
+    rdf_host          mdx_rdf_accumulate on pageable host memory (what ``ts.positions`` is): library
+                      threads copy into the pinned ring, DMA to HBM, kernels overlapped
+    rdf_host_pinned   the same buffer page-locked through mdx_host_register (DMA reads it in place)
+    rdf_file          mdx_rdf_accumulate_traj on an AMBER NetCDF file in the page cache
+    file_to_hbm       the ingest alone (mdx_traj_load_device: pread -> pinned -> HBM -> byte swap), no analysis
+    rdf_class_memory  RadialDistributionFunction(u.atoms, exclusion=(1, 1)).run() on an in-memory universe
+                      (reference base.py:539-584, structure.py:750-791), engine creation and result included
+    rdf_class_file    the same on a FileUniverse over the NetCDF file
+    """
+    import tempfile
+    import mdhelper_amd
+    from mdhelper_amd import _core, _lib
+    from mdhelper_amd.analysis import RadialDistributionFunction
+    from mdhelper_amd.io import FileUniverse, TrajectoryFile
+    dev = world.dev
+    N, F, L = 32768, 3000, 68.94
+    box = np.array([L, L, L, 90, 90, 90], dtype=np.float32)
+    edges = np.linspace(0.0, 15.0, 202)
+    d_traj = _core.synth_random_walk(F, N, box[:3], 0.3, seed=2, dev=dev)
+    h_traj = d_traj.to_host()
+    d_traj.free()
+    h_boxes = np.tile(box, (F, 1))
+    tmp = tempfile.NamedTemporaryFile(suffix=".nc", delete=False)
+    tmp.close()
+    t0 = time.perf_counter()
+    write_amber_netcdf_fast(tmp.name, h_traj, box)
+    t_write = time.perf_counter() - t0
+    gb = F * 12.0 * N / 1e9
+    legs = {"frames": F, "atoms": N, "coordinate_bytes_per_frame": 12 * N,
+            "resident_frames_per_sec": resident_fps,
+            "io_threads": int(os.environ.get("MDX_IO_THREADS", "8")),
+            "file": f"AMBER NetCDF (CDF-2), {os.path.getsize(tmp.name) / 1e9:.2f} GB, written in {t_write:.1f} s, "
+                    f"read from the page cache"}
+
+    def timed(fn, reps=2):
+        fn()                                   # warm-up: allocations, pinned ring, page cache
+        _core.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        _core.synchronize(dev)
+        return (time.perf_counter() - t0) / reps
+
+    def leg(name, seconds, counts=None, **more):
+        legs[name] = {"frames_per_sec": F / seconds, "GB_per_sec": gb / seconds,
+                      "ratio_to_resident": F / seconds / resident_fps, **more}
+        if counts is not None:
+            legs[name]["result_digest"] = hashlib.sha256(
+                np.ascontiguousarray(counts, dtype=np.int64).tobytes()).hexdigest()[:16]
+
+    try:
+        eng = _core.RdfEngine(edges, (1, 1), dev=dev)
+
+        def host():
+            eng.reset()
+            eng.accumulate(h_traj, None, h_boxes)
+            eng.synchronize()
+        leg("rdf_host", timed(host), eng.counts())
+        _lib.check(_lib.lib().mdx_host_register(dev, h_traj.ctypes.data, h_traj.nbytes))
+        try:
+            leg("rdf_host_pinned", timed(host), eng.counts())
+        finally:
+            _lib.check(_lib.lib().mdx_host_unregister(dev, h_traj.ctypes.data))
+        tf = TrajectoryFile(tmp.name)
+        frames = np.arange(F)
+
+        def from_file():
+            eng.reset()
+            eng.accumulate_traj(tf, frames, h_boxes)
+            eng.synchronize()
+        leg("rdf_file", timed(from_file), eng.counts())
+        eng.close()
+        d_out = _core.DeviceArray((F, N, 3), np.float32, dev)
+        leg("file_to_hbm", timed(lambda: tf.load_device(frames, d_out.ptr, dev=dev)),
+            note="ingest alone, analysis kernels off")
+        d_out.free()
+        tf.close()
+
+        res = {}
+        u = mdhelper_amd.ArrayUniverse(h_traj, box)
+
+        def cls_mem():
+            res["m"] = RadialDistributionFunction(u.atoms, exclusion=(1, 1), verbose=False, device=dev).run()
+        leg("rdf_class_memory", timed(cls_mem), res["m"].results.counts)
+        fu = FileUniverse(tmp.name)
+
+        def cls_file():
+            res["f"] = RadialDistributionFunction(fu.atoms, exclusion=(1, 1), verbose=False, device=dev).run()
+        leg("rdf_class_file", timed(cls_file), res["f"].results.counts)
+        fu.trajectory.file.close()
+        digests = {legs[k]["result_digest"] for k in legs if isinstance(legs[k], dict) and "result_digest" in legs[k]}
+        legs["all_legs_same_counts"] = len(digests) == 1
+        # what one host has to deliver for the 8 ranks of C2 / C5 at this kernel rate
+        legs["host_demand_8_ranks_GB_per_sec"] = {
+            "C2": 8 * resident_fps * 12.0 * N / 1e9,
+            "note": "coordinates only; pageable memory costs one extra host copy (read + write) per byte, "
+                    "pinned or registered memory and files in the page cache one read"}
+    finally:
+        os.unlink(tmp.name)
+    return legs
 
 
 def run_extras(args, world):
@@ -767,6 +942,16 @@ def run_extras(args, world):
     return extra
 
 
+def run_ingest(args, world, resident_fps):
+    t0 = time.perf_counter()
+    try:
+        out = bench_rdf_ingest(args, world, resident_fps)
+        out["leg_wall_s"] = time.perf_counter() - t0
+        return out
+    except Exception as exc:
+        return {"error": f"{type(exc).__name__}: {exc}"}
+
+
 def launch_ranks(args):
     """``python bench.py --gpus N`` outside any launcher: start N fresh ranks of this script (one per
     GPU) from this process, which never touches the GPU, and relay rank 0's line."""
@@ -787,8 +972,19 @@ def launch_ranks(args):
     return rc
 
 
+def product_library():
+    """bench.py measures the product library and nothing else: MDX_LIBRARY (mdhelper_amd/_lib.py) may
+    not point at a stand-in."""
+    from mdhelper_amd import _lib
+    want = os.path.join(ROOT, "mdhelper_amd", "libmdx.so")
+    if os.path.realpath(str(_lib.LIB_PATH)) != os.path.realpath(want):
+        raise SystemExit(f"bench.py: MDX_LIBRARY points at {_lib.LIB_PATH}; the bench runs {want} only")
+    return os.path.relpath(want, ROOT)
+
+
 def main():
     args = parse()
+    library = product_library()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
     # Libraries underneath (RCCL) print banners on stdout; keep stdout clean for the
@@ -797,7 +993,12 @@ def main():
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
     world = World(args)
-    if args.workload in ("rdf", "rdf_wide"):
+    if args.workload == "ingest":
+        # the host-buffer / file / operator-surface legs on their own, behind a short resident run
+        args.frames, args.no_cpu_baseline = args.frames or 3000, True
+        out = bench_rdf(args, world)
+        out["extra"] = {"ingest": run_ingest(args, world, out["frames_per_sec"])}
+    elif args.workload in ("rdf", "rdf_wide"):
         out = bench_rdf(args, world, wide=args.workload == "rdf_wide")
     elif args.workload == "sq":
         out = bench_sq(args, world)
@@ -808,6 +1009,8 @@ def main():
     plain = not (args.host_path or args.traj_file or args.shard_fixed or args.atoms or args.algo != "auto")
     if args.workload == "rdf" and world.world == 1 and plain and not args.no_extras:
         out["extra"] = run_extras(args, world)
+        out["extra"]["ingest"] = run_ingest(args, world, out["frames_per_sec"])
+    out["library"] = library
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)
     os.close(saved_stdout)

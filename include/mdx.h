@@ -58,6 +58,13 @@ int mdx_memcpy_h2d(int dev, void *dst, const void *src, size_t bytes);
 int mdx_memcpy_d2h(int dev, void *dst, const void *src, size_t bytes);
 int mdx_memset(int dev, void *dst, int value, size_t bytes);
 int mdx_device_synchronize(int dev);
+/* Page-lock a caller buffer (e.g. the float32[n_frames][n][3] array an MDAnalysis memory reader
+ * holds — what `universe.trajectory[frame].positions` views, reference structure.py:753,796) so
+ * that the host-buffer entry points below hand it to the DMA engine where it lies, without the
+ * staging copy through the library's own pinned ring.  Optional: unregistered memory works, one
+ * host copy slower.  The caller unregisters before freeing the buffer. */
+int mdx_host_register(int dev, void *ptr, size_t bytes);
+int mdx_host_unregister(int dev, void *ptr);
 
 /* Synthetic wrapped Gaussian random walk, generated in HBM (bench / tests):
  * frame 0 uniform in [0, L)^3, then x += sigma * N(0,1) wrapped into the box;
@@ -150,7 +157,8 @@ int mdx_rdf_debug_counters(mdx_rdf_t h, int64_t out[4]);
  * ticks; 0 when no such kernel has run. */
 int mdx_rdf_kernel_clock(mdx_rdf_t h, double *hz);
 /* Cell path: the sorted copies (wrapped and original float4 rows, n_pad rows) of one frame of
- * the most recent slab — for debugging the tile logic on the host. */
+ * the most recent slab — for debugging the tile logic on the host.  With exclusion 0 or 1 the
+ * sorted originals are not materialised: pw is filled and MDX_ERR_STATE returned. */
 int mdx_rdf_debug_sorted(mdx_rdf_t h, int64_t frame, int64_t n_pad, float *pw, float *po);
 
 /* Function-level drop-in for structure.radial_histogram (structure.py:32-104):

@@ -43,6 +43,8 @@ _SIGNATURES = {
     "mdx_memcpy_d2h": (c_int, [c_int, _vp, _vp, c_size_t]),
     "mdx_memset": (c_int, [c_int, _vp, c_int, c_size_t]),
     "mdx_device_synchronize": (c_int, [c_int]),
+    "mdx_host_register": (c_int, [c_int, _vp, c_size_t]),
+    "mdx_host_unregister": (c_int, [c_int, _vp]),
     "mdx_synth_random_walk": (c_int, [c_int, _vp, c_int64, c_int64, POINTER(c_float), c_float, c_uint64, c_int]),
     "mdx_synth_random_walk_f64": (c_int, [c_int, _vp, c_int64, c_int64, POINTER(c_float), c_float, c_uint64]),
     # collectives

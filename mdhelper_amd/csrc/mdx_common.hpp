@@ -7,7 +7,12 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mdx.h"
@@ -66,12 +71,65 @@ struct StreamTimer {
     int64_t launches = 0;
     hipEvent_t begin();
     void end(hipEvent_t start);
-    void collect();            // call after the stream has been synchronised
-    void reset();
+    void collect();            // waits for the end event of every bracket still pending, then adds it up
+    void reset();              // drops what is pending (recycled once fired) and zeroes the totals
     void destroy();
 };
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Persistent host threads for the copies that feed pinned staging memory (memcpy out of caller
+// buffers, pread out of the page cache).  parallel_for(n, fn) runs fn(0) ... fn(n-1), the caller
+// taking part; tasks are claimed from one counter, so uneven tasks balance.
+struct HostWorkers {
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    const std::function<void(int)> *job = nullptr;
+    std::atomic<int> next{0};
+    int n_tasks = 0, active = 0;
+    uint64_t generation = 0;
+    bool stopping = false;
+    int size() const { return int(threads.size()) + 1; }
+    void start(int n_threads);          // idempotent; n_threads counts the caller
+    void parallel_for(int n, const std::function<void(int)> &fn);
+    void stop();
+    ~HostWorkers() { stop(); }
+private:
+    void loop();
+};
+
+// Pinned staging ring between host memory (caller buffers, the page cache) and HBM.  It owns its
+// stream, and every event it owns is only ever recorded on that stream: no event can outlive the
+// stream it was last recorded on.  (HIP keeps a raw pointer to that stream inside the event and
+// reads its capture state in hipEventSynchronize / hipStreamWaitEvent; after the stream is
+// destroyed that is a read of freed memory, which now and then looks like "capture active" and
+// comes back as hipErrorCapturedEvent: "operation not permitted on an event last recorded in a
+// capturing stream".  That was the intermittent failure of round 2, commit 5575fea.)
+// Copies stay in flight across calls; a buffer is waited for only when it is needed again.
+struct HostStager {
+    static constexpr int NBUF = 3;
+    int dev = -1;
+    hipStream_t io = nullptr;
+    void *pinned[NBUF] = {nullptr, nullptr, nullptr};
+    size_t pinned_bytes = 0;
+    hipEvent_t ev_sent[NBUF] = {nullptr, nullptr, nullptr};   // behind the last copy out of pinned[b]
+    bool in_flight[NBUF] = {false, false, false};
+    hipEvent_t ev_batch = nullptr;      // behind everything queued on io so far (consumers wait on it)
+    int64_t turn = 0;
+    HostWorkers workers;
+
+    int ensure(int device, size_t chunk_bytes);
+    int after(hipStream_t producer);                 // io waits for what `producer` holds so far
+    int acquire(int *b, void **host);                // next pinned buffer, its last copy finished
+    int send(int b, void *d_dst, size_t bytes);      // pinned[b] -> HBM on io
+    int finish(hipStream_t consumer);                // consumer waits for everything queued on io
+    // d_dst[0, bytes) <- src: directly when src is pinned / registered memory, else in chunks
+    // through the ring with the workers copying; the data is ordered before later work on `consumer`
+    int upload(int device, hipStream_t consumer, void *d_dst, const void *src, size_t bytes);
+    int drain();                                     // host waits for every pinned buffer
+    void destroy();
+};
 
 // Double-buffered staging between a producer on a copy stream and the kernels on a handle's
 // compute stream: the fill of slab k+1 overlaps the kernels of slab k.  A buffer is refilled
@@ -80,6 +138,7 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // still be in flight on the compute stream.
 struct StagePipeline {
     hipStream_t copy_stream = nullptr;
+    HostStager stager;                  // host buffers -> HBM for the fills that start in host memory
     hipEvent_t ev_filled[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
     bool busy[2] = {false, false};
     int ensure();

@@ -364,6 +364,12 @@ struct mdx_rdf {
     int n_rep = 32;
     DeviceBuffer d_thresh, d_counts, d_total, d_pack1, d_pack2, d_misc, d_tri;
     DeviceBuffer d_stats;   // RDF_STAT_SHARDS x RDF_STAT_STRIDE 64-bit words (mdx_rdf_device.hpp)
+    DeviceBuffer d_work;    // work counters of the persistent pair kernel (one line per XCD)
+    // what mdx_rdf_debug_sorted needs to find the most recent slab: its set of sorted copies, whether the
+    // sorted originals were materialised, its frame count
+    size_t last_offset = 0;   // float4 elements from the start of d_pw1 / d_po1 to the slab
+    int64_t last_frames = 0, last_n_pad = 0;
+    bool last_lazy = false;
     // optional centre-of-mass stage per set: incoming rows are particles grouped into molecules
     MoleculeStage grouping[2];
     // drop_axis (2-D mode, structure.py:761-770): coordinate zeroed, box length -> max(lx, ly, lz)
@@ -512,6 +518,12 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
     else if (lower) MDX_CELL_PICK(false, true);
     else MDX_CELL_PICK(false, false);
 #undef MDX_CELL_PICK
+    // resident blocks per XCD (32 CUs each) of this kernel at this LDS size
+    int per_cu = 0;
+    MDX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), 256, lds));
+    hipDeviceProp_t prop;
+    MDX_HIP(hipGetDeviceProperties(&prop, h->dev));
+    const int64_t blocks_per_xcd = std::max<int64_t>(1, int64_t(std::max(per_cu, 1)) * prop.multiProcessorCount / 8);
 
     hipStream_t s_sort = n_sets == 2 ? h->sort_stream : h->stream;
     if (n_sets == 2) {
@@ -531,6 +543,16 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
         float4 *po2 = self ? po1 : (lazy_orig ? nullptr : h->d_po2.as<float4>() + set * e_p2);
         float4 *bb2 = self ? bb1 : h->d_bb2.as<float4>() + set * e_b2;
         float4 *bc2 = self ? bc1 : h->d_bb16_2.as<float4>() + set * e_c2;
+        // The batch's largest |coordinate| (the filter's error bound grows with it) is folded by the sort.
+        // With two sets each has a word of its own: the sort of slab k + 1 runs beside the pair kernel of
+        // slab k, and on one shared word the blocks of that kernel would see the bound move under them —
+        // harmless for the counts (it only grows), but the exact-path statistics would differ from run to
+        // run.  A set's word covers every slab sorted into that set since the last reset: conservative.
+        unsigned *d_maxabs = d_misc + (n_sets == 2 ? 4 + set : 0);
+        h->last_offset = set * e_p1;
+        h->last_frames = nf;
+        h->last_n_pad = n1p;
+        h->last_lazy = lazy_orig;
         {
             if (n_sets == 2 && k_slab >= 2)   // the pair kernel that read this set two slabs ago
                 MDX_HIP(hipStreamWaitEvent(s_sort, h->ev_paired[set], 0));
@@ -538,11 +560,11 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
             const float *cells = tri ? d_tri + f0 * 9 : d_boxes + f0 * 6;
             hipLaunchKernelGGL(sort, dim3((unsigned)nf), dim3(SORT_THREADS), 0, s_sort,
                                d_pos1 + f0 * n1 * 3, cells, (int)n1, (int)n1p, excl ? h->excl1 : 0,
-                               pw1, po1, bb1, bc1, d_misc);
+                               pw1, po1, bb1, bc1, d_maxabs);
             if (!self)
                 hipLaunchKernelGGL(sort, dim3((unsigned)nf), dim3(SORT_THREADS), 0, s_sort,
                                    d_pos2 + f0 * n2 * 3, cells, (int)n2, (int)n2p,
-                                   excl ? h->excl2 : 0, pw2, po2, bb2, bc2, d_misc);
+                                   excl ? h->excl2 : 0, pw2, po2, bb2, bc2, d_maxabs);
             if (n_sets == 2) {
                 MDX_HIP(hipEventRecord(h->ev_sorted[set], s_sort));
                 MDX_HIP(hipStreamWaitEvent(h->stream, h->ev_sorted[set], 0));
@@ -565,7 +587,7 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
         a.tri = tri ? d_tri + f0 * 9 : nullptr;
         a.thresh = h->d_thresh.as<double>();
         a.counts = h->d_counts.as<unsigned long long>();
-        a.maxabs_bits = d_misc;
+        a.maxabs_bits = d_maxabs;
         a.exact_counter = h->d_stats.as<unsigned long long>();
         a.tilepair_counter = a.exact_counter + 1;
         a.clock_counter = h->timer.enabled ? a.exact_counter + 3 : nullptr;
@@ -579,12 +601,20 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
         a.n_hist = n_hist;
         a.n_rep = h->n_rep;
         a.self = self ? 1 : 0;
+        // persistent blocks: what the chip holds at once (blocks per CU from the kernel's own occupancy), a
+        // multiple of 8 so that every XCD gets the same number; fewer when there is less work than that
+        a.work = h->d_work.as<unsigned>();
+        const int64_t tiles = n1p / 128;
         hipEvent_t ev = h->timer.begin();
-        for (int64_t g0 = 0; g0 < nf; g0 += 32768) {
+        // (frames per launch: the item index is 32 bits wide)
+        const int64_t launch_frames = std::max<int64_t>(8, std::min<int64_t>(32768, ((int64_t(1) << 30) / tiles) * 8));
+        for (int64_t g0 = 0; g0 < nf; g0 += launch_frames) {
             a.frame0 = (int)g0;
-            a.n_frames = (int)std::min<int64_t>(32768, nf - g0);
-            dim3 grid((unsigned)(n1p / 128), (unsigned)(ceil_div(a.n_frames, 8) * 8));
-            hipLaunchKernelGGL(kern, grid, dim3(256), lds, h->stream, a);
+            a.n_frames = (int)std::min<int64_t>(launch_frames, nf - g0);
+            const int64_t items_per_xcd = ceil_div(a.n_frames, 8) * tiles;
+            const unsigned grid = 8u * (unsigned)std::min<int64_t>(blocks_per_xcd, items_per_xcd);
+            MDX_HIP(hipMemsetAsync(h->d_work.ptr, 0, CELL_WORK_BYTES, h->stream));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, h->stream, a);
         }
         h->timer.end(ev);
         if (n_sets == 2)
@@ -1021,6 +1051,7 @@ int mdx_rdf_create(mdx_rdf_t *out, int dev, int n_bins, const double *edges, int
         if ((rc = h->d_total.ensure(sizeof(uint64_t) * n_bins)) != MDX_OK) break;
         if ((rc = h->d_misc.ensure(64)) != MDX_OK) break;
         if ((rc = h->d_stats.ensure(RDF_STAT_BYTES)) != MDX_OK) break;
+        if ((rc = h->d_work.ensure(CELL_WORK_BYTES)) != MDX_OK) break;
         if (hipMemcpy(h->d_thresh.ptr, h->thresh.data(), sizeof(double) * (n_bins + 1),
                       hipMemcpyHostToDevice) != hipSuccess) {
             rc = fail(MDX_ERR_HIP, "threshold upload failed");
@@ -1046,7 +1077,7 @@ int mdx_rdf_destroy(mdx_rdf_t h)
     h->pipe.destroy();
     for (DeviceBuffer *b : {&h->d_thresh, &h->d_counts, &h->d_total, &h->d_pack1, &h->d_pack2,
                             &h->d_stage1[0], &h->d_stage2[0], &h->d_boxes[0], &h->d_stage1[1],
-                            &h->d_stage2[1], &h->d_boxes[1], &h->d_index[0], &h->d_index[1], &h->d_tri, &h->d_misc, &h->d_stats, &h->d_pw1,
+                            &h->d_stage2[1], &h->d_boxes[1], &h->d_index[0], &h->d_index[1], &h->d_tri, &h->d_misc, &h->d_stats, &h->d_work, &h->d_pw1,
                             &h->d_po1, &h->d_bb1, &h->d_pw2, &h->d_po2, &h->d_bb2, &h->d_bb16_1,
                             &h->d_bb16_2, &h->d_drop[0], &h->d_drop[1], &h->d_drop_box})
         b->release();
@@ -1128,12 +1159,13 @@ int mdx_rdf_accumulate(mdx_rdf_t h, const float *pos1, int64_t n1, const float *
     return accumulate_pipelined(
         h, n1, n2, same, boxes, n_frames, 12 * std::max(n1, n2),
         [&](int b, int64_t f0, int64_t nf) -> int {
-            MDX_HIP(hipMemcpyAsync(h->d_stage1[b].ptr, pos1 + f0 * n1 * 3, size_t(12) * n1 * nf,
-                                   hipMemcpyHostToDevice, h->pipe.copy_stream));
+            // caller memory -> pinned ring (host threads) -> HBM; pinned / registered caller
+            // memory is read by the DMA engine where it lies
+            MDX_TRY(h->pipe.stager.upload(h->dev, h->pipe.copy_stream, h->d_stage1[b].ptr,
+                                          pos1 + f0 * n1 * 3, size_t(12) * n1 * nf));
             if (!same)
-                MDX_HIP(hipMemcpyAsync(h->d_stage2[b].ptr, pos2 + f0 * n2 * 3,
-                                       size_t(12) * n2 * nf, hipMemcpyHostToDevice,
-                                       h->pipe.copy_stream));
+                MDX_TRY(h->pipe.stager.upload(h->dev, h->pipe.copy_stream, h->d_stage2[b].ptr,
+                                              pos2 + f0 * n2 * 3, size_t(12) * n2 * nf));
             return MDX_OK;
         });
 }
@@ -1288,13 +1320,20 @@ int mdx_rdf_debug_sorted(mdx_rdf_t h, int64_t frame, int64_t n_pad, float *pw, f
     MDX_REQUIRE(h && pw && po, "NULL argument");
     MDX_TRY(set_device(h->dev));
     MDX_HIP(hipStreamSynchronize(h->stream));
-    MDX_REQUIRE(h->d_pw1.bytes >= size_t(16) * n_pad * (frame + 1), "frame outside the last slab");
-    MDX_HIP(hipMemcpy(pw, h->d_pw1.as<float4>() + frame * n_pad, size_t(16) * n_pad,
+    MDX_REQUIRE(h->last_frames > 0, "no slab has gone through the cell-sorted path yet");
+    MDX_REQUIRE(frame >= 0 && frame < h->last_frames, "frame %lld outside the last slab (%lld frames)",
+                (long long)frame, (long long)h->last_frames);
+    MDX_REQUIRE(n_pad == h->last_n_pad, "n_pad is %lld for the last slab", (long long)h->last_n_pad);
+    // the slab's own set of sorted copies (two sets alternate when the sort runs beside the pair kernel)
+    MDX_HIP(hipMemcpy(pw, h->d_pw1.as<float4>() + h->last_offset + frame * n_pad, size_t(16) * n_pad,
                       hipMemcpyDeviceToHost));
-    // (exclusion 0 or 1: the sorted originals are not materialised; the wrapped copies are returned twice)
-    const bool have_po = h->d_po1.bytes >= size_t(16) * n_pad * (frame + 1);
-    MDX_HIP(hipMemcpy(po, (have_po ? h->d_po1.as<float4>() : h->d_pw1.as<float4>()) + frame * n_pad,
-                      size_t(16) * n_pad, hipMemcpyDeviceToHost));
+    if (h->last_lazy)
+        // exclusion 0 or 1: no sorted copy of the original coordinates exists (the exact path reads the
+        // incoming frame by the tag in pw[..].w); say so instead of returning something else in its place
+        return fail(MDX_ERR_STATE, "the last slab has no sorted originals (exclusion 0 or 1): pw is filled, "
+                    "po is not; MDX_RDF_SORTED_ORIGINALS=1 materialises them");
+    MDX_HIP(hipMemcpy(po, h->d_po1.as<float4>() + h->last_offset + frame * n_pad, size_t(16) * n_pad,
+                      hipMemcpyDeviceToHost));
     return MDX_OK;
 }
 

@@ -50,9 +50,15 @@ struct CellArgs {
     int n1p, n2p;                // padded particle counts (multiples of 128)
     int n_bins, n_hist, n_rep;
     int self, frame0;
-    int n_frames;                // frames of this launch (grid.y is padded to a multiple of 8)
+    int n_frames;                // frames of this launch
     int tags_everywhere;         // 0: exclusion tags can only collide inside the diagonal tiles
+    // persistent blocks: eight work counters (one per XCD, 32 words apart, zeroed before the launch) hand out
+    // the (frame, i tile) items of the XCD's frames
+    unsigned *work;
 };
+
+constexpr unsigned CELL_WORK_STRIDE = 32;   // words between the work counters of two XCDs (one 128-byte line each)
+constexpr size_t CELL_WORK_BYTES = 8 * CELL_WORK_STRIDE * 4;
 
 constexpr int CELL_MAX = 16384;   // cells per frame (64 KiB of LDS counters)
 constexpr int SORT_THREADS = 1024;
@@ -392,6 +398,26 @@ __device__ inline float cell_uniform(float v)
     return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
 
+// A wave-uniform value the optimiser cannot see through: what is derived from the copy is computed where it is
+// used instead of being hoisted out of the loops around it (and kept in scalar registers across them).
+// The launch's arguments through a pointer the optimiser cannot see through: a by-value kernel argument read
+// inside the item loop is a loop-invariant scalar load, which is hoisted to the top of the kernel and then
+// occupies scalar registers across every loop below it; read through this pointer it is loaded (s_load from the
+// kernarg segment) where the item's prologue needs it.
+__device__ inline const __constant__ CellArgs *cell_args()
+{
+    auto p = __builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return (const __constant__ CellArgs *)p;
+}
+
+__device__ inline unsigned cell_opaque(unsigned v)
+{
+    v = __builtin_amdgcn_readfirstlane(v);   // (a no-op for a value already in a scalar register)
+    asm volatile("" : "+s"(v));
+    return v;
+}
+
 // wave-uniform bookkeeping of the undecided pairs (scalar registers)
 struct CellWave {
     uint2 *todo;         // this wave's list in LDS: (i index, j index | (weight - 1) << 31)
@@ -608,6 +634,18 @@ __device__ inline void cell_slow_unit(const CellHot &c, const CellArgs &a, const
 template <bool EXCL, bool LOWER, int MODE, bool TRI = false>
 // (seven waves per SIMD: 72 VGPRs with 12 more bytes of scratch in the prologue than at six and 80 — +4 % at C2(i);
 // eight do not fit the LDS of seven blocks and lose to their spills)
+//
+// Persistent blocks (round 3): the grid is what the chip holds at once (7 blocks x 256 CUs), and a block pulls
+// (frame, i tile) items from a work counter until none is left.  The LDS histogram, the threshold table and the
+// statistics live as long as the block: they are zeroed / loaded once and flushed once per BLOCK — with one block
+// per item each of a launch's ~250 000 blocks ended in 201 64-bit global atomics (2 MB of the 3 MB a frame moved
+// through HBM) and paid the block's launch, zeroing and flush.  Workgroups are dealt round-robin to the 8 XCDs
+// in linear block order, so block b serves XCD b % 8 and takes only frames of that residue: a frame's sorted
+// copies still stream through ONE XCD's L2.  Nothing waits on another block: a block that becomes resident late
+// finds the counter exhausted and leaves.  What an item needs from the launch (block id, counter, sizes) is
+// re-derived where it is used, behind an opaque copy of the block id (cell_opaque): carried across the hot loops
+// as loop invariants, those values cost 13 scalar registers the kernel does not have (SGPR spills go to VGPR
+// lanes, and with 72 VGPRs the hot loop then spills to scratch).
 __global__ __launch_bounds__(256, TRI ? 4 : 7) void rdf_cell_pair_kernel(CellArgs a)
 {
     constexpr bool GH = MODE == 1;
@@ -615,24 +653,13 @@ __global__ __launch_bounds__(256, TRI ? 4 : 7) void rdf_cell_pair_kernel(CellArg
     float4 *sJ = reinterpret_cast<float4 *>(smem_raw);                        // [4 waves][64]
     double *sT = reinterpret_cast<double *>(smem_raw + sizeof(float4) * 256); // [n_bins+1]
     unsigned *sh = reinterpret_cast<unsigned *>(sT + (a.n_bins + 1));         // [n_bins + 1][n_hist replicas]
-    __shared__ unsigned s_exact, s_units, s_general, s_qn, s_qnext;
+    __shared__ unsigned s_exact, s_units, s_general, s_qn, s_qnext, s_next;
     __shared__ unsigned sQ[CELL_QCAP];
     __shared__ uint2 s_todo[4][CELL_TODO];
     __shared__ float s_geo[48];
     __shared__ unsigned sQimg[TRI ? CELL_QCAP : 1];   // triclinic: surviving images of a queued tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // Workgroups are dealt round-robin to the 8 XCDs in linear block order.  Blocks of one
-    // frame are therefore given linear ids of one residue mod 8, so that a frame's sorted
-    // copies are streamed through a single XCD's L2 instead of all eight.
-    const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x;
-    const unsigned per_xcd = lin >> 3;
-    // (the integer division runs on the VALU: pin its block-uniform results back into SGPRs,
-    // or every pointer derived from them costs two VGPRs)
-    const unsigned q_xcd = __builtin_amdgcn_readfirstlane(per_xcd / gridDim.x);
-    const int frame_l = int(q_xcd) * 8 + int(lin & 7u);
-    if (frame_l >= a.n_frames)
-        return;
     // timing runs: every block adds its span in engine-clock ticks (s_memtime) and in ticks of the
     // constant 100 MHz counter (s_memrealtime); the ratio is the clock this kernel actually ran at
     long long clk0 = 0, rt0 = 0;
@@ -640,8 +667,6 @@ __global__ __launch_bounds__(256, TRI ? 4 : 7) void rdf_cell_pair_kernel(CellArg
         clk0 = clock64();
         rt0 = wall_clock64();
     }
-    const int frame = frame_l + a.frame0;
-    const int I = int(per_xcd - q_xcd * gridDim.x); // 128-particle i tile = two 64-particle halves
     const int t64_2 = a.n2p / 64;
 
     if (!GH) {
@@ -654,45 +679,107 @@ __global__ __launch_bounds__(256, TRI ? 4 : 7) void rdf_cell_pair_kernel(CellArg
         s_exact = 0u;
         s_units = 0u;
         s_general = 0u;
+        s_next = atomicAdd(a.work + CELL_WORK_STRIDE * (blockIdx.x & 7u), 1u);
     }
     __syncthreads();
 
-    // Per-block geometry and constants are derived once (fp64 error-bound arithmetic included)
-    // and parked in LDS; the hot loop keeps only five floats of them, in SGPRs.
+    unsigned long long *out = a.counts + int64_t(blockIdx.x % unsigned(a.n_rep)) * a.n_bins;
+    const double *thr = GH ? a.thresh : sT;
+    // n_bins + 1 bins of n_hist (a power of two) interleaved replicas: the extra bin absorbs a (proven
+    // impossible, DESIGN.md §4.2) index n_bins
+    const int rep_log = __builtin_amdgcn_readfirstlane(31 - __clz(a.n_hist));
+    HistLdsRep hl{sh + (GH ? 0 : (lane & (a.n_hist - 1))), GH ? 0 : rep_log};
+    HistGlobal hg{out};
+    CellHot hot{};
+
+    float4 *sJw = sJ + wave * 64;
+    CellWave wv{s_todo[wave], 0u, 0u, 0u};
+    unsigned n_units = 0, n_general = 0;
+    // upper bound of what any 32-bit LDS bin may hold, in units of 2^14 adds (= 128 i x 64 j x weight 2, one
+    // j tile of one item); at 2^18 units the bins are flushed to the 64-bit replicas
+    unsigned lds_units = 0;
+    for (;;) {
+    // the item: frame = 8 (item / tiles) + xcd, i tile = item % tiles, over the frames of this launch with
+    // frame % 8 == xcd
+    const unsigned item = __builtin_amdgcn_readfirstlane(s_next);
+    int frame_l, I;
+    {
+        const unsigned xcd = cell_opaque(blockIdx.x) & 7u;
+        const auto *A = cell_args();
+        const unsigned tiles = unsigned(A->n1p) >> 7;                       // 128-particle i tiles of a frame
+        const unsigned nfx = unsigned(A->n_frames + 7 - int(xcd)) >> 3;
+        if (item >= nfx * tiles)
+            break;
+        // (the integer division runs on the VALU: pin its block-uniform results back into SGPRs,
+        // or every pointer derived from them costs two VGPRs)
+        const unsigned fq = __builtin_amdgcn_readfirstlane(item / tiles);
+        frame_l = int(fq * 8u + xcd);
+        I = int(item - fq * tiles);
+        frame_l += A->frame0;
+    }
+    const int frame = frame_l;
+    // this frame's original coordinates, for the (cold) exact passes: formed where they are used
+#define MDX_PO1F()                                                                                             \
+    CellOrig { a.po1 ? a.po1 + int64_t(cell_opaque(frame)) * a.n1p : nullptr, a.pw1 + int64_t(cell_opaque(frame)) * a.n1p, \
+               a.in1 ? a.in1 + int64_t(cell_opaque(frame)) * a.n1_in * 3 : nullptr }
+#define MDX_PO2()                                                                                              \
+    CellOrig { a.po2 ? a.po2 + int64_t(cell_opaque(frame)) * a.n2p : nullptr, a.pw2 + int64_t(cell_opaque(frame)) * a.n2p, \
+               a.in2 ? a.in2 + int64_t(cell_opaque(frame)) * a.n2_in * 3 : nullptr }
+    const float4 *PW2, *BB2, *BB16;
+    {
+        const auto *A = cell_args();
+        PW2 = A->pw2 + int64_t(frame) * A->n2p;
+        BB2 = A->bb2 + int64_t(frame) * t64_2 * 2;
+        BB16 = A->bb16_2 + int64_t(frame) * t64_2 * 2 * CELL_NCHUNK;
+    }
+    {
+    // Per-item geometry and the frame's constants are derived by one thread (fp64 error-bound
+    // arithmetic included) and parked in LDS; the hot loop keeps only five floats of them, in SGPRs.
     //   s_geo: [0..2] L, [3..5] 1/L (float32), [6] cut, [7] cut^2,
     //          [8..10] cI, [11..13] hI, [14..19] cH[2][3], [20..25] hH[2][3],
     //          [26] cand_hi, [27] cand_lo, [28] inv_w, [29] -r0/w - eta, [30] 1 - 2 eta
-    unsigned long long *out =
-        a.counts + int64_t((I + 7 * frame_l) % a.n_rep) * a.n_bins;
     //   triclinic: [31..39] cell matrix B (rows a, b, c); L and 1/L are unused
+    // (the previous item's last barrier has passed: nobody reads s_geo or the queue any more)
     if (tid == 0) {
-        PairCtx<true> ctx;
-        if (TRI) {
-            // error bound of the float32 path: the shifted difference
-            // fl(fl(x_j + t) - x_i) against the contract's (double)(x_j - x_i) + t deviates by less
-            // than 7 * 2^-24 * sum|B| per component; the orthorhombic formula with the pseudo
-            // length 4 sum|B| gives 2^-22 (2 M + 4 sum|B|) >= 2^-20 sum|B|
-            const float *B = a.tri + int64_t(frame) * 9;
-            float sum = 0.f;
-            for (int i = 0; i < 9; ++i) {
-                s_geo[31 + i] = B[i];
-                sum += fabsf(B[i]);
+        const auto *A = cell_args();
+        {
+            PairCtx<true> ctx;
+            if (TRI) {
+                // error bound of the float32 path: the shifted difference
+                // fl(fl(x_j + t) - x_i) against the contract's (double)(x_j - x_i) + t deviates by less
+                // than 7 * 2^-24 * sum|B| per component; the orthorhombic formula with the pseudo
+                // length 4 sum|B| gives 2^-22 (2 M + 4 sum|B|) >= 2^-20 sum|B|
+                const float *B = A->tri + int64_t(frame) * 9;
+                float sum = 0.f;
+                for (int i = 0; i < 9; ++i) {
+                    s_geo[31 + i] = B[i];
+                    sum += fabsf(B[i]);
+                }
+                const float pseudo[3] = {4.f * sum, 4.f * sum, 4.f * sum};
+                ctx.init(pseudo, A->maxabs_bits, A->r0, A->r1, A->n_bins);
+            } else {
+                ctx.init(A->boxes + int64_t(frame) * 6, A->maxabs_bits, A->r0, A->r1, A->n_bins);
             }
-            const float pseudo[3] = {4.f * sum, 4.f * sum, 4.f * sum};
-            ctx.init(pseudo, a.maxabs_bits, a.r0, a.r1, a.n_bins);
-        } else {
-            ctx.init(a.boxes + int64_t(frame) * 6, a.maxabs_bits, a.r0, a.r1, a.n_bins);
+            const float Lmax = fmaxf(ctx.Lf[0], fmaxf(ctx.Lf[1], ctx.Lf[2]));
+            // a tile pair is culled when its box gap exceeds r1 + error bound + slack
+            const float cut = sqrtf(ctx.cand_hi) + 1e-5f * Lmax;
+            for (int k = 0; k < 3; ++k) {
+                s_geo[k] = ctx.Lf[k];
+                s_geo[3 + k] = ctx.invf[k];
+            }
+            s_geo[6] = cut;
+            s_geo[7] = cut * cut;
+            s_geo[26] = ctx.cand_hi;
+            s_geo[27] = ctx.cand_lo;
+            s_geo[28] = ctx.inv_wf;
+            s_geo[29] = -ctx.r0f * ctx.inv_wf - ctx.eta;
+            s_geo[30] = 1.0f - 2.0f * ctx.eta;
         }
-        const float Lmax = fmaxf(ctx.Lf[0], fmaxf(ctx.Lf[1], ctx.Lf[2]));
-        // a tile pair is culled when its box gap exceeds r1 + error bound + slack
-        const float cut = sqrtf(ctx.cand_hi) + 1e-5f * Lmax;
-        const float4 *BB1 = a.bb1 + int64_t(frame) * (a.n1p / 64) * 2 + int64_t(I) * 4;
+        const float4 *BB1 = A->bb1 + int64_t(frame) * (A->n1p / 64) * 2 + int64_t(I) * 4;
         const float4 l0 = BB1[0], h0 = BB1[1], l1 = BB1[2], h1 = BB1[3];
         const float lo0[3] = {l0.x, l0.y, l0.z}, hi0[3] = {h0.x, h0.y, h0.z};
         const float lo1[3] = {l1.x, l1.y, l1.z}, hi1[3] = {h1.x, h1.y, h1.z};
         for (int k = 0; k < 3; ++k) {
-            s_geo[k] = ctx.Lf[k];
-            s_geo[3 + k] = ctx.invf[k];
             const float lo = fminf(lo0[k], lo1[k]), hi = fmaxf(hi0[k], hi1[k]);
             s_geo[8 + k] = 0.5f * (lo + hi);
             s_geo[11 + k] = 0.5f * (hi - lo);
@@ -701,62 +788,64 @@ __global__ __launch_bounds__(256, TRI ? 4 : 7) void rdf_cell_pair_kernel(CellArg
             s_geo[20 + k] = 0.5f * (hi0[k] - lo0[k]);
             s_geo[23 + k] = 0.5f * (hi1[k] - lo1[k]);
         }
-        s_geo[6] = cut;
-        s_geo[7] = cut * cut;
-        s_geo[26] = ctx.cand_hi;
-        s_geo[27] = ctx.cand_lo;
-        s_geo[28] = ctx.inv_wf;
-        s_geo[29] = -ctx.r0f * ctx.inv_wf - ctx.eta;
-        s_geo[30] = 1.0f - 2.0f * ctx.eta;
+        s_qn = 0u;        // the queue of the item's first round
+        s_qnext = 0u;
     }
-    __syncthreads();
-    CellHot hot;
-    hot.cand_hi = cell_uniform(s_geo[26]);
-    hot.cand_lo = cell_uniform(s_geo[27]);
-    hot.inv_w = cell_uniform(s_geo[28]);
-    hot.pos0 = s_geo[29];
-    asm volatile("" : "+v"(hot.pos0));   // stays in a VGPR
-    hot.sure_w = cell_uniform(s_geo[30]);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        hot.L[k] = cell_uniform(s_geo[k]);
-        hot.invL[k] = cell_uniform(s_geo[3 + k]);
+    float4 p0, p1;
+    {
+        const auto *A = cell_args();
+        const float4 *PW1 = A->pw1 + int64_t(frame) * A->n1p + int64_t(I) * 128;
+        p0 = PW1[lane];
+        p1 = PW1[64 + lane];
     }
-    hot.tri = TRI ? s_geo + 31 : nullptr;
-    const double *thr = GH ? a.thresh : sT;
-    // n_bins + 1 bins of n_hist (a power of two) interleaved replicas: the extra bin absorbs a (proven
-    // impossible, DESIGN.md §4.2) index n_bins
-    const int rep_log = __builtin_amdgcn_readfirstlane(31 - __clz(a.n_hist));
-    HistLdsRep hl{sh + (GH ? 0 : (lane & (a.n_hist - 1))), GH ? 0 : rep_log};
-    HistGlobal hg{out};
-
-    const float4 *PW1 = a.pw1 + int64_t(frame) * a.n1p + int64_t(I) * 128;
-    // this frame's original coordinates
-    const CellOrig PO1f{a.po1 ? a.po1 + int64_t(frame) * a.n1p : nullptr, a.pw1 + int64_t(frame) * a.n1p,
-                        a.in1 ? a.in1 + int64_t(frame) * a.n1_in * 3 : nullptr};
     const unsigned i_base0 = unsigned(I) * 128u;   // wave-uniform; + lane = this lane's i index
     const unsigned i_idx0 = i_base0 + unsigned(lane);
-    const float4 *PW2 = a.pw2 + int64_t(frame) * a.n2p;
-    const CellOrig PO2{a.po2 ? a.po2 + int64_t(frame) * a.n2p : nullptr, a.pw2 + int64_t(frame) * a.n2p,
-                       a.in2 ? a.in2 + int64_t(frame) * a.n2_in * 3 : nullptr};
-    const float4 *BB2 = a.bb2 + int64_t(frame) * t64_2 * 2;
-    const float4 *BB16 = a.bb16_2 + int64_t(frame) * t64_2 * 2 * CELL_NCHUNK;
-    const float4 p0 = PW1[lane], p1 = PW1[64 + lane];
-
-    float4 *sJw = sJ + wave * 64;
-    CellWave wv{s_todo[wave], 0u, 0u, 0u};
-    unsigned n_units = 0, n_general = 0;
+    __syncthreads();
+    {
+        hot.cand_hi = cell_uniform(s_geo[26]);
+        hot.cand_lo = cell_uniform(s_geo[27]);
+        hot.inv_w = cell_uniform(s_geo[28]);
+        hot.pos0 = s_geo[29];
+        asm volatile("" : "+v"(hot.pos0));   // stays in a VGPR
+        hot.sure_w = cell_uniform(s_geo[30]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            hot.L[k] = cell_uniform(s_geo[k]);
+            hot.invL[k] = cell_uniform(s_geo[3 + k]);
+        }
+        hot.tri = TRI ? s_geo + 31 : nullptr;
+    }
     const int Jbeg = a.self ? 2 * I : 0;
     // Rounds of up to CELL_QCAP candidate j tiles: all four waves test candidates and append
     // the survivors to one LDS queue, then pull tiles from it one at a time (LDS atomic), so
     // the waves of a block stay evenly loaded whatever the spatial distribution of survivors.
     for (int round0 = Jbeg; round0 < t64_2; round0 += CELL_QCAP) {
-        if (tid == 0) {
-            s_qn = 0u;
-            s_qnext = 0u;
-        }
-        __syncthreads();
         const int round1 = min(t64_2, round0 + CELL_QCAP);
+        // 32-bit LDS bins: one round adds at most (128 i) x (64 j) x weight 2 = 2^14 per j tile to a bin.  Before
+        // a round could take a bin past 2^32 the bins are flushed to the 64-bit replicas, so no count can wrap
+        // however many items a block serves and however large the second set is (it could,
+        // silently, from ~1.6e7 particles with coarse bins).  Uniform decision; the adds of earlier rounds are
+        // behind a barrier, the next adds come after the barrier that closes the cull below.
+        if (!GH && lds_units + unsigned(round1 - round0) >= (1u << 18)) {
+            for (int b = tid; b < a.n_bins; b += 256) {
+                unsigned long long sum = 0;
+                for (int h = 0; h < a.n_hist; ++h) {
+                    sum += sh[b * a.n_hist + h];
+                    sh[b * a.n_hist + h] = 0u;
+                }
+                if (sum)
+                    atomicAdd(out + b, sum);
+            }
+            lds_units = 0u;
+        }
+        lds_units += unsigned(round1 - round0);
+        if (round0 != Jbeg) {   // (the first round's queue was reset with the item's geometry)
+            if (tid == 0) {
+                s_qn = 0u;
+                s_qnext = 0u;
+            }
+            __syncthreads();
+        }
         for (int Jb = round0; Jb < round1; Jb += 256) {
             const int J = Jb + tid;
             float g2 = __int_as_float(0x7f800000);
@@ -828,6 +917,11 @@ __global__ __launch_bounds__(256, TRI ? 4 : 7) void rdf_cell_pair_kernel(CellArg
             }
         }
         __syncthreads();
+        // the next item is requested while the other waves already pull tiles (the queue is dynamic: they take
+        // what this wave misses while it waits for the counter); every wave has read s_next before the item's
+        // first barrier, the next read comes after the round's last one
+        if (tid == 0 && round0 == Jbeg)
+            s_next = atomicAdd(cell_args()->work + CELL_WORK_STRIDE * (cell_opaque(blockIdx.x) & 7u), 1u);
         const unsigned nq = s_qn;
         while (true) {
             unsigned e = 0;
@@ -1045,8 +1139,8 @@ __global__ __launch_bounds__(256, TRI ? 4 : 7) void rdf_cell_pair_kernel(CellArg
                                                   ? (unsigned((sub >> s) & 1ull) | (unsigned((sub1 >> s) & 1ull) << 1))
                                                   : (unsigned(rem >> (2 * s)) & 3u);
                         rem &= CELL_CHUNK == 1 ? ~(1ull << s) : ~(3ull << (2 * s));
-                        if (GH) cell_slow_unit<LOWER, EXCL>(hot, a, thr, hg, sJw, CELL_CHUNK * s, CELL_CHUNK, bits, tags, 0, s_geo, p0, p1, PO1f, PO2, i_idx0, jbase, w, wv);
-                        else cell_slow_unit<LOWER, EXCL>(hot, a, thr, hl, sJw, CELL_CHUNK * s, CELL_CHUNK, bits, tags, 0, s_geo, p0, p1, PO1f, PO2, i_idx0, jbase, w, wv);
+                        if (GH) cell_slow_unit<LOWER, EXCL>(hot, a, thr, hg, sJw, CELL_CHUNK * s, CELL_CHUNK, bits, tags, 0, s_geo, p0, p1, MDX_PO1F(), MDX_PO2(), i_idx0, jbase, w, wv);
+                        else cell_slow_unit<LOWER, EXCL>(hot, a, thr, hl, sJw, CELL_CHUNK * s, CELL_CHUNK, bits, tags, 0, s_geo, p0, p1, MDX_PO1F(), MDX_PO2(), i_idx0, jbase, w, wv);
                     }
                 }
             } else {
@@ -1089,38 +1183,28 @@ __global__ __launch_bounds__(256, TRI ? 4 : 7) void rdf_cell_pair_kernel(CellArg
                 if (__builtin_expect(wv.overflow != 0u, 0)) {
                     wv.overflow = 0u;
                     wv.n_todo = mark;
-                    if (GH) cell_slow_unit<LOWER, EXCL>(hot, a, thr, hg, sJw, 0, 64, 3u, true, gen, s_geo, p0, p1, PO1f, PO2, i_idx0, jbase, w, wv);
-                    else cell_slow_unit<LOWER, EXCL>(hot, a, thr, hl, sJw, 0, 64, 3u, true, gen, s_geo, p0, p1, PO1f, PO2, i_idx0, jbase, w, wv);
+                    if (GH) cell_slow_unit<LOWER, EXCL>(hot, a, thr, hg, sJw, 0, 64, 3u, true, gen, s_geo, p0, p1, MDX_PO1F(), MDX_PO2(), i_idx0, jbase, w, wv);
+                    else cell_slow_unit<LOWER, EXCL>(hot, a, thr, hl, sJw, 0, 64, 3u, true, gen, s_geo, p0, p1, MDX_PO1F(), MDX_PO2(), i_idx0, jbase, w, wv);
                 }
             }
             if (wv.n_todo >= 64u) {   // enough undecided pairs for a full-width exact pass
-                if (GH) cell_flush(hot, a, thr, hg, wv, PO1f, PO2);
-                else cell_flush(hot, a, thr, hl, wv, PO1f, PO2);
+                if (GH) cell_flush(hot, a, thr, hg, wv, MDX_PO1F(), MDX_PO2());
+                else cell_flush(hot, a, thr, hl, wv, MDX_PO1F(), MDX_PO2());
             }
             }   // images
         }
-        __syncthreads();   // the queue is reset by the next round
-        // 32-bit LDS bins hold at most (128 i) x (64 CELL_QCAP j) x weight 2 = 2^24 adds of one round;
-        // with more j tiles than one round the bins are flushed to the 64-bit replicas between
-        // rounds, so no count can wrap however large the second set is (it could, silently,
-        // from ~1.6e7 particles with coarse bins)
-        if (!GH && round0 + CELL_QCAP < t64_2) {
-            for (int b = tid; b < a.n_bins; b += 256) {
-                unsigned long long sum = 0;
-                for (int h = 0; h < a.n_hist; ++h) {
-                    sum += sh[b * a.n_hist + h];
-                    sh[b * a.n_hist + h] = 0u;
-                }
-                if (sum)
-                    atomicAdd(out + b, sum);
-            }
-            __syncthreads();
+        // the undecided pairs of an item are evaluated before its last barrier: their indices are the item's
+        // frame's, and the exact arithmetic reads the frame's constants
+        if (round0 + CELL_QCAP >= t64_2 && wv.n_todo) {
+            if (GH) cell_flush(hot, a, thr, hg, wv, MDX_PO1F(), MDX_PO2());
+            else cell_flush(hot, a, thr, hl, wv, MDX_PO1F(), MDX_PO2());
         }
+        __syncthreads();   // the queue, s_geo and s_next are rewritten after this
     }
-    if (wv.n_todo) {
-        if (GH) cell_flush(hot, a, thr, hg, wv, PO1f, PO2);
-        else cell_flush(hot, a, thr, hl, wv, PO1f, PO2);
     }
+#undef MDX_PO1F
+#undef MDX_PO2
+    }   // items
     if (lane == 0) {
         if (wv.n_exact) atomicAdd(&s_exact, wv.n_exact);
         if (n_units) atomicAdd(&s_units, n_units);
@@ -1128,7 +1212,7 @@ __global__ __launch_bounds__(256, TRI ? 4 : 7) void rdf_cell_pair_kernel(CellArg
     }
     __syncthreads();
     if (tid == 0) {
-        const unsigned so = rdf_stat_offset(lin);
+        const unsigned so = rdf_stat_offset(blockIdx.x);
         if (s_exact) atomicAdd(a.exact_counter + so, (unsigned long long)s_exact);
         if (s_units) atomicAdd(a.tilepair_counter + so, (unsigned long long)s_units);
         if (s_general) atomicAdd(a.tilepair_counter + so + 1, (unsigned long long)s_general);

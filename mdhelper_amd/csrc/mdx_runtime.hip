@@ -85,24 +85,32 @@ void StreamTimer::end(hipEvent_t start)
     pending.emplace_back(start, ev);
 }
 
-void StreamTimer::collect()
+static void timer_recycle(StreamTimer &t)
 {
     // pairs dropped by reset() while their events were still in flight: recycle them once they have fired
     // (an event recorded again before it has fired gave elapsed times that spanned two uses)
-    for (size_t i = 0; i < limbo.size();) {
-        if (hipEventQuery(limbo[i].second) == hipSuccess) {
-            pool.push_back(limbo[i].first);
-            pool.push_back(limbo[i].second);
-            limbo[i] = limbo.back();
-            limbo.pop_back();
+    for (size_t i = 0; i < t.limbo.size();) {
+        if (hipEventQuery(t.limbo[i].second) == hipSuccess) {
+            t.pool.push_back(t.limbo[i].first);
+            t.pool.push_back(t.limbo[i].second);
+            t.limbo[i] = t.limbo.back();
+            t.limbo.pop_back();
         } else {
             (void)hipGetLastError();
             ++i;
         }
     }
+}
+
+void StreamTimer::collect()
+{
+    timer_recycle(*this);
     for (auto &p : pending) {
+        // a bracket whose end has not fired yet is waited for, not dropped: every collected figure
+        // covers every bracket closed before the call, on whatever stream it ran
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+        if (hipEventSynchronize(p.second) == hipSuccess &&
+            hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
             total_ms += ms;
             pool.push_back(p.first);
             pool.push_back(p.second);
@@ -116,7 +124,10 @@ void StreamTimer::collect()
 
 void StreamTimer::reset()
 {
-    collect();
+    timer_recycle(*this);
+    for (auto &p : pending)
+        limbo.push_back(p);
+    pending.clear();
     total_ms = 0.0;
     launches = 0;
 }
@@ -134,6 +145,241 @@ void StreamTimer::destroy()
     pool.clear();
 }
 
+// ------------------------------------------------------------------ host workers + pinned ring
+
+void HostWorkers::start(int n_threads)
+{
+    if (!threads.empty() || n_threads <= 1)
+        return;
+    for (int t = 1; t < n_threads; ++t)
+        threads.emplace_back([this] { loop(); });
+}
+
+void HostWorkers::loop()
+{
+    uint64_t seen = 0;
+    for (;;) {
+        const std::function<void(int)> *fn;
+        int total;
+        {
+            std::unique_lock<std::mutex> lk(m);
+            cv_work.wait(lk, [&] { return stopping || generation != seen; });
+            if (stopping)
+                return;
+            seen = generation;
+            fn = job;
+            total = n_tasks;
+            ++active;
+        }
+        for (int i; (i = next.fetch_add(1)) < total;)
+            (*fn)(i);
+        {
+            std::lock_guard<std::mutex> lk(m);
+            if (--active == 0)
+                cv_done.notify_all();
+        }
+    }
+}
+
+void HostWorkers::parallel_for(int n, const std::function<void(int)> &fn)
+{
+    if (n <= 0)
+        return;
+    if (threads.empty() || n == 1) {
+        for (int i = 0; i < n; ++i)
+            fn(i);
+        return;
+    }
+    {
+        std::lock_guard<std::mutex> lk(m);
+        job = &fn;
+        n_tasks = n;
+        next.store(0);
+        ++generation;
+    }
+    cv_work.notify_all();
+    for (int i; (i = next.fetch_add(1)) < n;)
+        fn(i);
+    // every task has been claimed; wait for the workers that are still inside one.  A worker that
+    // wakes up late finds the counter exhausted and goes back to sleep without touching `fn`
+    // after it has left `active`, and `fn` outlives this wait.
+    std::unique_lock<std::mutex> lk(m);
+    cv_done.wait(lk, [&] { return active == 0; });
+    job = nullptr;
+}
+
+void HostWorkers::stop()
+{
+    {
+        std::lock_guard<std::mutex> lk(m);
+        stopping = true;
+    }
+    cv_work.notify_all();
+    for (std::thread &t : threads)
+        t.join();
+    threads.clear();
+    stopping = false;
+}
+
+static int io_threads()
+{
+    static const int n = [] {
+        const char *e = getenv("MDX_IO_THREADS");
+        int v = e ? atoi(e) : 8;
+        const int hw = (int)std::thread::hardware_concurrency();
+        if (hw > 0 && v > hw)
+            v = hw;
+        return v < 1 ? 1 : (v > 64 ? 64 : v);
+    }();
+    return n;
+}
+
+int HostStager::ensure(int device, size_t chunk_bytes)
+{
+    if (dev >= 0 && dev != device)
+        return fail(MDX_ERR_STATE, "staging ring is bound to device %d", dev);
+    dev = device;
+    if (!io) {
+        MDX_HIP(hipStreamCreateWithFlags(&io, hipStreamNonBlocking));
+        MDX_HIP(hipEventCreateWithFlags(&ev_batch, hipEventDisableTiming));
+        for (int b = 0; b < NBUF; ++b)
+            MDX_HIP(hipEventCreateWithFlags(&ev_sent[b], hipEventDisableTiming));
+        workers.start(io_threads());
+    }
+    if (pinned_bytes < chunk_bytes) {
+        MDX_TRY(drain());
+        for (int b = 0; b < NBUF; ++b) {
+            if (pinned[b])
+                MDX_HIP(hipHostFree(pinned[b]));
+            pinned[b] = nullptr;
+        }
+        pinned_bytes = 0;
+        for (int b = 0; b < NBUF; ++b)
+            MDX_HIP(hipHostMalloc(&pinned[b], chunk_bytes, hipHostMallocDefault));
+        pinned_bytes = chunk_bytes;
+    }
+    return MDX_OK;
+}
+
+int HostStager::after(hipStream_t producer)
+{
+    // a throw-away event: recorded on the producer's stream, waited for by io, and gone before
+    // the producer's stream can be (destroying an event that a stream still waits for is allowed;
+    // the wait itself holds what it needs)
+    hipEvent_t ev;
+    MDX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, producer);
+    if (e == hipSuccess)
+        e = hipStreamWaitEvent(io, ev, 0);
+    (void)hipEventDestroy(ev);
+    MDX_HIP(e);
+    return MDX_OK;
+}
+
+int HostStager::acquire(int *b, void **host)
+{
+    const int k = int(turn++ % NBUF);
+    if (in_flight[k]) {
+        MDX_HIP(hipEventSynchronize(ev_sent[k]));
+        in_flight[k] = false;
+    }
+    *b = k;
+    *host = pinned[k];
+    return MDX_OK;
+}
+
+int HostStager::send(int b, void *d_dst, size_t bytes)
+{
+    MDX_HIP(hipMemcpyAsync(d_dst, pinned[b], bytes, hipMemcpyHostToDevice, io));
+    MDX_HIP(hipEventRecord(ev_sent[b], io));
+    in_flight[b] = true;
+    return MDX_OK;
+}
+
+int HostStager::finish(hipStream_t consumer)
+{
+    MDX_HIP(hipEventRecord(ev_batch, io));
+    MDX_HIP(hipStreamWaitEvent(consumer, ev_batch, 0));
+    return MDX_OK;
+}
+
+int HostStager::drain()
+{
+    for (int b = 0; b < NBUF; ++b)
+        if (in_flight[b]) {
+            MDX_HIP(hipEventSynchronize(ev_sent[b]));
+            in_flight[b] = false;
+        }
+    return MDX_OK;
+}
+
+int HostStager::upload(int device, hipStream_t consumer, void *d_dst, const void *src, size_t bytes)
+{
+    if (bytes == 0)
+        return MDX_OK;
+    // memory the device can read where it lies (hipHostMalloc / hipHostRegister, e.g. through
+    // mdx_host_register): one DMA, no staging copy
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, src) == hipSuccess && attr.type == hipMemoryTypeHost) {
+        MDX_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, consumer));
+        return MDX_OK;
+    }
+    (void)hipGetLastError();
+    if (bytes < (size_t(1) << 20)) {
+        // small: the runtime's own staging is as good
+        MDX_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, consumer));
+        return MDX_OK;
+    }
+    const size_t chunk = size_t(16) << 20;
+    MDX_TRY(ensure(device, chunk));
+    MDX_TRY(after(consumer));
+    const uint8_t *from = static_cast<const uint8_t *>(src);
+    uint8_t *to = static_cast<uint8_t *>(d_dst);
+    const int parts = workers.size();
+    for (size_t off = 0; off < bytes; off += chunk) {
+        const size_t n = bytes - off < chunk ? bytes - off : chunk;
+        int b;
+        void *host;
+        MDX_TRY(acquire(&b, &host));
+        // 64-byte aligned slices, one per thread
+        const size_t slice = ((n + parts - 1) / parts + 63) & ~size_t(63);
+        const std::function<void(int)> copy = [&](int t) {
+            const size_t lo = size_t(t) * slice;
+            if (lo < n)
+                memcpy(static_cast<uint8_t *>(host) + lo, from + off + lo, n - lo < slice ? n - lo : slice);
+        };
+        workers.parallel_for(parts, copy);
+        MDX_TRY(send(b, to + off, n));
+    }
+    return finish(consumer);
+}
+
+void HostStager::destroy()
+{
+    if (dev >= 0)
+        (void)hipSetDevice(dev);
+    if (io)
+        (void)hipStreamSynchronize(io);
+    for (int b = 0; b < NBUF; ++b) {
+        if (ev_sent[b])
+            (void)hipEventDestroy(ev_sent[b]);
+        ev_sent[b] = nullptr;
+        in_flight[b] = false;
+        if (pinned[b])
+            (void)hipHostFree(pinned[b]);
+        pinned[b] = nullptr;
+    }
+    pinned_bytes = 0;
+    if (ev_batch)
+        (void)hipEventDestroy(ev_batch);
+    ev_batch = nullptr;
+    if (io)
+        (void)hipStreamDestroy(io);
+    io = nullptr;
+    workers.stop();
+    dev = -1;
+}
+
 int StagePipeline::ensure()
 {
     if (copy_stream)
@@ -148,6 +394,7 @@ int StagePipeline::ensure()
 
 void StagePipeline::destroy()
 {
+    stager.destroy();
     if (!copy_stream)
         return;
     (void)hipStreamSynchronize(copy_stream);
@@ -299,6 +546,22 @@ int mdx_memset(int dev, void *dst, int value, size_t bytes)
 {
     MDX_TRY(set_device(dev));
     MDX_HIP(hipMemset(dst, value, bytes));
+    return MDX_OK;
+}
+
+int mdx_host_register(int dev, void *ptr, size_t bytes)
+{
+    MDX_REQUIRE(ptr && bytes, "NULL buffer");
+    MDX_TRY(set_device(dev));
+    MDX_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return MDX_OK;
+}
+
+int mdx_host_unregister(int dev, void *ptr)
+{
+    MDX_REQUIRE(ptr, "NULL buffer");
+    MDX_TRY(set_device(dev));
+    MDX_HIP(hipHostUnregister(ptr));
     return MDX_OK;
 }
 

@@ -393,9 +393,8 @@ int mdx_sq_accumulate(mdx_sq_t h, const float *pos, int64_t n, int64_t n_frames)
         h->stream, n_frames, slab,
         [&](int b, int64_t f0, int64_t nf) -> int {
             MDX_TRY(h->d_stage[b].ensure(size_t(12) * n * slab));
-            MDX_HIP(hipMemcpyAsync(h->d_stage[b].ptr, pos + f0 * n * 3, size_t(12) * n * nf,
-                                   hipMemcpyHostToDevice, h->pipe.copy_stream));
-            return MDX_OK;
+            return h->pipe.stager.upload(h->dev, h->pipe.copy_stream, h->d_stage[b].ptr,
+                                         pos + f0 * n * 3, size_t(12) * n * nf);
         },
         [&](int b, int64_t, int64_t nf) -> int {
             return sq_accumulate_device(h, h->d_stage[b].as<float>(), n, nf);

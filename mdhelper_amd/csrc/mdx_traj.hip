@@ -487,15 +487,9 @@ void Trajectory::close()
 {
     if (dev >= 0) {
         (void)hipSetDevice(dev);
-        for (int b = 0; b < 2; ++b) {
-            if (ev_free[b]) {
-                (void)hipEventSynchronize(ev_free[b]);
-                (void)hipEventDestroy(ev_free[b]);
-            }
-            if (pinned[b])
-                (void)hipHostFree(pinned[b]);
-            d_raw[b].release();
-        }
+        stager.destroy();
+        d_raw.release();
+        dev = -1;
     }
     if (fd >= 0)
         ::close(fd);
@@ -503,46 +497,46 @@ void Trajectory::close()
 }
 
 // raw coordinate bytes of the listed frames, 12 N per frame, in file order and layout
-int Trajectory::fill_raw(const int64_t *frames, int64_t n, uint8_t *dst) const
+int Trajectory::fill_raw(const int64_t *frames, int64_t n, uint8_t *dst, HostWorkers *workers) const
 {
     const int64_t per_frame = 12 * n_atoms;
-    const int n_threads = (int)std::max<int64_t>(1, std::min<int64_t>(4, (n * per_frame) >> 22));
+    // pieces of about 1 MiB (a frame, or a slice of a large frame's bytes / planes): enough of them
+    // for every reader thread whatever the frame size
+    const int64_t unit = format == TRAJ_NETCDF ? per_frame : 4 * n_atoms;     // one contiguous run on disk
+    const int64_t units_per_frame = format == TRAJ_NETCDF ? 1 : 3;
+    const int64_t split = std::max<int64_t>(1, std::min<int64_t>(64, unit >> 20));
+    const int64_t n_tasks = n * units_per_frame * split;
     // Workers only record (status, message): mdx_last_error() is thread-local, so the failing
     // thread's own fail() would be invisible to the caller; the message is restated on the calling
     // thread after the join.
-    std::vector<int> rcs(n_threads, MDX_OK);
-    std::vector<std::string> msgs((size_t)n_threads);
-    auto work = [&](int t) {
-        for (int64_t i = t; i < n; i += n_threads) {
-            const int64_t at = coord_first + frames[i] * frame_stride;
-            uint8_t *out = dst + i * per_frame;
-            int rc = MDX_OK;
-            if (format == TRAJ_NETCDF) {
-                rc = read_at(at, out, (size_t)per_frame);
-            } else {
-                for (int k = 0; k < 3 && rc == MDX_OK; ++k)
-                    rc = read_at(at + k * plane_stride, out + k * 4 * n_atoms, size_t(4) * n_atoms);
-            }
-            if (rc != MDX_OK) {
-                rcs[t] = rc;
-                msgs[size_t(t)] = mdx_last_error();   // this thread's message
-                return;
+    std::mutex err_lock;
+    int first_rc = MDX_OK;
+    std::string first_msg;
+    const std::function<void(int)> work = [&](int task) {
+        const int64_t i = task / (units_per_frame * split);
+        const int64_t r = task - i * units_per_frame * split;
+        const int64_t k = r / split, part = r - k * split;
+        const int64_t lo = unit * part / split, hi = unit * (part + 1) / split;
+        const int64_t at = coord_first + frames[i] * frame_stride + k * plane_stride + lo;
+        int rc = read_at(at, dst + i * per_frame + k * unit + lo, size_t(hi - lo));
+        if (rc != MDX_OK) {
+            std::lock_guard<std::mutex> lk(err_lock);
+            if (first_rc == MDX_OK) {
+                first_rc = rc;
+                first_msg = mdx_last_error();   // this thread's message
             }
         }
     };
-    if (n_threads == 1) {
-        work(0);
+    if (n_tasks > (int64_t(1) << 30))
+        return fail(MDX_ERR_INVALID_VALUE, "too many frames in one read");
+    if (workers && n * per_frame >= (int64_t(4) << 20)) {
+        workers->parallel_for(int(n_tasks), work);
     } else {
-        std::vector<std::thread> pool;
-        for (int t = 1; t < n_threads; ++t)
-            pool.emplace_back(work, t);
-        work(0);
-        for (std::thread &th : pool)
-            th.join();
+        for (int64_t t = 0; t < n_tasks && first_rc == MDX_OK; ++t)
+            work(int(t));
     }
-    for (int t = 0; t < n_threads; ++t)
-        if (rcs[t] != MDX_OK)
-            return fail(rcs[t], "%s", msgs[size_t(t)].empty() ? "trajectory read failed" : msgs[size_t(t)].c_str());
+    if (first_rc != MDX_OK)
+        return fail(first_rc, "%s", first_msg.empty() ? "trajectory read failed" : first_msg.c_str());
     return MDX_OK;
 }
 
@@ -565,7 +559,10 @@ int Trajectory::read_positions(const int64_t *frames, int64_t n, float *out) con
     MDX_REQUIRE(out, "NULL output");
     const int64_t N = n_atoms;
     if (format == TRAJ_NETCDF) {
-        MDX_TRY(fill_raw(frames, n, reinterpret_cast<uint8_t *>(out)));
+        HostWorkers readers;
+        if (n * N * 12 >= (int64_t(8) << 20))
+            readers.start(4);
+        MDX_TRY(fill_raw(frames, n, reinterpret_cast<uint8_t *>(out), &readers));
         if (swap) {
             uint32_t *w = reinterpret_cast<uint32_t *>(out);
             for (int64_t i = 0; i < n * N * 3; ++i)
@@ -678,32 +675,7 @@ __global__ __launch_bounds__(256) void traj_unpack_kernel(const uint32_t *__rest
     }
 }
 
-int Trajectory::ensure_pipeline(int device, size_t chunk_bytes)
-{
-    if (dev >= 0 && dev != device)
-        return fail(MDX_ERR_STATE, "trajectory handle is bound to device %d", dev);
-    MDX_TRY(set_device(device));
-    dev = device;
-    if (pinned_bytes < chunk_bytes) {
-        for (int b = 0; b < 2; ++b) {
-            if (pinned_busy[b]) {
-                MDX_HIP(hipEventSynchronize(ev_free[b]));
-                pinned_busy[b] = false;
-            }
-            if (pinned[b])
-                MDX_HIP(hipHostFree(pinned[b]));
-            pinned[b] = nullptr;
-            MDX_HIP(hipHostMalloc(&pinned[b], chunk_bytes, hipHostMallocDefault));
-        }
-        pinned_bytes = chunk_bytes;
-    }
-    for (int b = 0; b < 2; ++b)
-        if (!ev_free[b])
-            MDX_HIP(hipEventCreateWithFlags(&ev_free[b], hipEventDisableTiming));
-    return MDX_OK;
-}
-
-int Trajectory::stage_async(int device, hipStream_t stream, const int64_t *frames, int64_t n,
+int Trajectory::stage_async(int device, hipStream_t consumer, const int64_t *frames, int64_t n,
                             const TrajSelection *sel, int n_sel)
 {
     MDX_TRY(check_frames(*this, frames, n));
@@ -713,49 +685,45 @@ int Trajectory::stage_async(int device, hipStream_t stream, const int64_t *frame
                     "selection %d is larger than the trajectory", i);
     if (n == 0)
         return MDX_OK;
+    if (dev >= 0 && dev != device)
+        return fail(MDX_ERR_STATE, "trajectory handle is bound to device %d", dev);
+    MDX_TRY(set_device(device));
+    dev = device;
     const int64_t per_frame = 12 * n_atoms;
-    const int64_t chunk = std::max<int64_t>(1, (int64_t(32) << 20) / per_frame);
-    MDX_TRY(ensure_pipeline(device, size_t(chunk * per_frame)));
-    for (int64_t f0 = 0, c = 0; f0 < n; f0 += chunk, ++c) {
+    const int64_t chunk = std::max<int64_t>(1, (int64_t(16) << 20) / per_frame);
+    MDX_TRY(stager.ensure(device, size_t(chunk * per_frame)));
+    MDX_TRY(d_raw.ensure(size_t(chunk * per_frame)));
+    // the outputs may still be read by kernels the consumer queued earlier
+    MDX_TRY(stager.after(consumer));
+    int rc = MDX_OK;
+    for (int64_t f0 = 0; f0 < n && rc == MDX_OK; f0 += chunk) {
         const int64_t nf = std::min(chunk, n - f0);
-        const int b = int(c & 1);
-        if (pinned_busy[b]) {
-            MDX_HIP(hipEventSynchronize(ev_free[b]));
-            pinned_busy[b] = false;
-        }
-        MDX_TRY(fill_raw(frames + f0, nf, static_cast<uint8_t *>(pinned[b])));
-        MDX_TRY(d_raw[b].ensure(size_t(chunk * per_frame)));
-        MDX_HIP(hipMemcpyAsync(d_raw[b].ptr, pinned[b], size_t(nf * per_frame),
-                               hipMemcpyHostToDevice, stream));
-        MDX_HIP(hipEventRecord(ev_free[b], stream));
-        pinned_busy[b] = true;
+        int b;
+        void *host;
+        if ((rc = stager.acquire(&b, &host)) != MDX_OK)
+            break;
+        if ((rc = fill_raw(frames + f0, nf, static_cast<uint8_t *>(host), &stager.workers)) != MDX_OK)
+            break;
+        // io runs in order: this copy into d_raw follows the unpack kernels of the previous chunk
+        if ((rc = stager.send(b, d_raw.ptr, size_t(nf * per_frame))) != MDX_OK)
+            break;
         for (int i = 0; i < n_sel; ++i) {
             if (sel[i].n_sel == 0)
                 continue;
             const int64_t total = 3 * sel[i].n_sel * nf;
             const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(total, 256), 65536);
-            hipLaunchKernelGGL(traj_unpack_kernel, dim3(grid), dim3(256), 0, stream,
-                               d_raw[b].as<uint32_t>(), sel[i].d_index,
+            hipLaunchKernelGGL(traj_unpack_kernel, dim3(grid), dim3(256), 0, stager.io,
+                               d_raw.as<uint32_t>(), sel[i].d_index,
                                reinterpret_cast<uint32_t *>(sel[i].d_out + f0 * sel[i].n_sel * 3),
                                n_atoms, sel[i].n_sel, nf, format == TRAJ_DCD ? 1 : 0, swap ? 1 : 0);
         }
-        MDX_HIP(hipGetLastError());
+        if (hipGetLastError() != hipSuccess)
+            rc = fail(MDX_ERR_HIP, "trajectory unpack kernel launch failed");
     }
-    // The pinned buffers' hand-over events do not outlive this call unfinished: the stream belongs to the
-    // caller's engine, and the next call may come from another engine after this one (and its stream) is gone —
-    // an event that still refers to a destroyed stream made a later launch fail now and then ("operation not
-    // permitted on an event last recorded in a capturing stream").  Fresh events per stream (ensure_pipeline).
-    for (int b = 0; b < 2; ++b)
-        if (pinned_busy[b]) {
-            MDX_HIP(hipEventSynchronize(ev_free[b]));
-            pinned_busy[b] = false;
-        }
-    for (int b = 0; b < 2; ++b)
-        if (ev_free[b]) {
-            MDX_HIP(hipEventDestroy(ev_free[b]));
-            ev_free[b] = nullptr;
-        }
-    return MDX_OK;
+    // on every path — a failed read included — the consumer is ordered behind what did get queued,
+    // so the outputs are never written behind its back; nothing is left recorded on its stream
+    const int rc2 = stager.finish(consumer);
+    return rc != MDX_OK ? rc : rc2;
 }
 
 }  // namespace mdx

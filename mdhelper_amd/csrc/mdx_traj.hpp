@@ -52,13 +52,12 @@ struct Trajectory {
     int64_t dcd_istart = 0, dcd_nsavc = 1;
     double coord_scale = 1.0;   // NetCDF scale_factor attribute of `coordinates`
 
-    // device pipeline (created on first use)
+    // device pipeline (created on first use): the pinned ring, its stream and its events belong to
+    // the trajectory, and the unpack kernels run on that stream too — nothing here is ever
+    // recorded on a caller's stream, so engines may come and go around one open trajectory
     int dev = -1;
-    void *pinned[2] = {nullptr, nullptr};
-    size_t pinned_bytes = 0;
-    hipEvent_t ev_free[2] = {nullptr, nullptr};
-    bool pinned_busy[2] = {false, false};
-    DeviceBuffer d_raw[2];
+    HostStager stager;
+    DeviceBuffer d_raw;
 
     int open(const char *path);
     void close();
@@ -68,18 +67,18 @@ struct Trajectory {
     int read_boxes(const int64_t *frames, int64_t n, float *boxes6) const;
     int read_times(const int64_t *frames, int64_t n, double *times) const;
 
-    // Queue on `stream`: raw frames -> pinned -> HBM -> unpack into every selection.  Returns
-    // after the last pinned buffer has been handed to the copy engine; the device work may
-    // still be in flight on `stream`.
-    int stage_async(int device, hipStream_t stream, const int64_t *frames, int64_t n,
+    // Raw frames -> pinned -> HBM -> unpack into every selection, on the trajectory's own stream:
+    // that stream first waits for what `consumer` holds so far (the outputs may still be read),
+    // and `consumer` waits for the unpacked frames.  Returns once the last pinned buffer has been
+    // filled; copies and kernels may still be in flight, also across calls.
+    int stage_async(int device, hipStream_t consumer, const int64_t *frames, int64_t n,
                     const TrajSelection *sel, int n_sel);
 
 private:
     int parse_netcdf(const std::vector<uint8_t> &head, bool &need_more);
     int parse_dcd(const std::vector<uint8_t> &head, bool &need_more);
     int read_at(int64_t offset, void *dst, size_t bytes) const;
-    int fill_raw(const int64_t *frames, int64_t n, uint8_t *dst) const;
-    int ensure_pipeline(int device, size_t chunk_bytes);
+    int fill_raw(const int64_t *frames, int64_t n, uint8_t *dst, HostWorkers *workers = nullptr) const;
 };
 
 }  // namespace mdx

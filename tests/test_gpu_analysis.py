@@ -123,6 +123,42 @@ def test_structure_factor_matches_reference_driver(mode, form):
     assert np.allclose(raw.results.ssf, ref["ssf"], rtol=1e-6, atol=1e-8)
 
 
+def test_structure_factor_reference_default_grid_of_32_points():
+    """The reference's default configuration: ``n_points=32`` => 32 768 grid wavevectors
+    (structure.py:1324, 1376-1381): 32-long m_z lists in the register-blocked column kernel, several
+    column chunks, and the round(11) fold of 32 768 rows into the unique wavenumbers.  ~4 000 atoms in
+    two groups, 2 frames, ``mode="partial"``, sort/unique on and off, against oracle/fourier.py."""
+    rng = np.random.default_rng(33)
+    L = 34.2
+    n1, n2 = 2300, 1700
+    frames = (rng.random((2, n1 + n2, 3)) * L).astype(np.float32)
+    u = mdhelper_amd.ArrayUniverse(frames, [L, L, L, 90, 90, 90])
+    groups = (u.atoms[:n1], u.atoms[n1:])
+    q = of.grid_wavevectors([L, L, L], 32)
+    assert q.shape == (32768, 3)
+    raw_ref = of.ssf_run_ref(frames.astype(np.float64), [n1, n2], q, mode="partial", sort=False, unique=False)
+    raw = StructureFactor(groups, mode="partial", sort=False, unique=False).run()       # n_points default
+    assert raw._wavevectors.shape == (32768, 3) and np.array_equal(raw._wavevectors, q)
+    assert raw.results.pairs == raw_ref["pairs"] and raw.results.ssf.shape == (3, 32768)
+    # element-wise: the diagonal columns relative, the cross column against sqrt(S_00 S_11) (its
+    # entries pass through zero); q = 0 (N_j N_k / N) does not enter any norm
+    ref, got = raw_ref["ssf"], raw.results.ssf
+    ntot = n1 + n2
+    for i, (j, k) in enumerate(raw_ref["pairs"]):
+        bound = (1e-6 * np.abs(ref[i]) if j == k else 1e-6 * np.sqrt(ref[0] * ref[2])) + 1e-9
+        assert np.all(np.abs(got[i] - ref[i]) <= bound), (i, float(np.abs(got[i] - ref[i]).max()))
+    assert np.isclose(got[0, 0], n1 * n1 / ntot, rtol=1e-12) and np.isclose(got[1, 0], 2 * n1 * n2 / ntot, rtol=1e-12)
+    # the folded form (the default): unique wavenumbers by round(11), columns averaged, sorted
+    ref = of.ssf_run_ref(frames.astype(np.float64), [n1, n2], q, mode="partial")
+    sf = StructureFactor(groups, mode="partial").run()
+    assert sf.results.wavenumbers.shape == ref["wavenumbers"].shape and len(ref["wavenumbers"]) > 2000
+    assert np.allclose(sf.results.wavenumbers, ref["wavenumbers"], rtol=1e-12, atol=0)
+    for i, (j, k) in enumerate(ref["pairs"]):
+        bound = (1e-6 * np.abs(ref["ssf"][i]) if j == k
+                 else 1e-6 * np.sqrt(np.abs(ref["ssf"][0] * ref["ssf"][2]))) + 1e-9
+        assert np.all(np.abs(sf.results.ssf[i] - ref["ssf"][i]) <= bound), i
+
+
 def test_structure_factor_bragg_peaks():
     n, a = 6, 1.5
     L = n * a

@@ -260,3 +260,81 @@ def test_onsager_molecule_groupings_from_file_on_device(tmp_path, mode):
         x, y = getattr(a.results, name), getattr(b.results, name)
         assert np.allclose(x, y, rtol=1e-8, atol=1e-8 * np.abs(y).max()), name
     assert np.abs(b.results.msd_self).max() > 1.0
+
+
+def test_one_trajectory_outlives_the_engines_that_stage_from_it(tmp_path):
+    """
+    Round-2 fault (commit 5575fea), as a sequence: engine A stages frames out of a TrajectoryFile
+    and is destroyed — with it its streams — while the trajectory stays open; engine B then stages
+    out of the same trajectory.  The pinned ring's hand-over events used to be recorded on the
+    engine's stream; HIP keeps a pointer to that stream inside the event and reads its capture state
+    on the next hipEventSynchronize, i.e. freed memory once the stream is gone ("operation not
+    permitted on an event last recorded in a capturing stream", now and then).  The ring, its
+    stream and its events now belong to the trajectory (csrc/mdx_common.hpp: HostStager), copies
+    stay in flight across calls, and this sequence — several engine generations, of three kinds,
+    on different streams — must give the counts of the in-memory frames every time.
+    """
+    from oracle import fourier as of
+    F, N, L = 96, 9000, 44.0                      # 10 MB: the ring (3 x 16 MiB) is never drained by size
+    pos = _frames(F, N, L, 21)
+    path = tmp_path / "shared.nc"
+    write_amber_netcdf(path, pos, (L, L, L))
+    t = TrajectoryFile(path)
+    dims = np.array([L, L, L, 90, 90, 90], dtype=np.float32)
+    edges = np.linspace(0.0, 10.0, 51)
+    ref = _core.RdfEngine(edges, (1, 1))
+    ref.accumulate(pos, None, dims)
+    want = ref.counts()
+    ref.close()
+    frames = np.arange(F)
+    boxes = np.tile(dims, (F, 1))
+    q = of.grid_wavevectors([L, L, L], 3)
+    for generation in range(4):
+        a = _core.RdfEngine(edges, (1, 1))
+        a.accumulate_traj(t, frames, boxes)
+        if generation % 2:
+            a.close()                              # closed with its kernels possibly still queued
+            a = None
+        s = _core.SqEngine(q, [N], of.ssf_pairs(1, None))      # another engine kind, another stream
+        s.accumulate_traj(t, frames[:8])
+        s.close()
+        b = _core.RdfEngine(edges, (1, 1))
+        b.accumulate_traj(t, frames[::-1], boxes)
+        assert np.array_equal(b.counts(), want), generation
+        b.close()
+        if a is not None:
+            assert np.array_equal(a.counts(), want), generation
+            a.close()
+    t.close()
+
+
+def test_failed_read_leaves_the_trajectory_usable(tmp_path):
+    """A read that fails in the middle of a staged batch (the file loses its tail after it was
+    opened) returns the I/O error and leaves ring, events and stream consistent: the next engine
+    stages the frames that are still there and bins the right counts."""
+    import os
+    F, N, L = 64, 6000, 38.0
+    pos = _frames(F, N, L, 22)
+    path = tmp_path / "cut.nc"
+    write_amber_netcdf(path, pos, (L, L, L))
+    t = TrajectoryFile(path)
+    assert t.n_frames == F
+    size = os.path.getsize(path)
+    os.truncate(path, size - 20 * 12 * N)          # the last ~20 frames are gone
+    dims = np.array([L, L, L, 90, 90, 90], dtype=np.float32)
+    edges = np.linspace(0.0, 9.0, 41)
+    boxes = np.tile(dims, (F, 1))
+    a = _core.RdfEngine(edges, (1, 1))
+    with pytest.raises(OSError):
+        a.accumulate_traj(t, np.arange(F), boxes)
+    a.close()
+    keep = np.arange(32)
+    b = _core.RdfEngine(edges, (1, 1))
+    b.accumulate_traj(t, keep, boxes[:32])
+    got = b.counts()
+    b.close()
+    ref = _core.RdfEngine(edges, (1, 1))
+    ref.accumulate(pos[:32], None, dims)
+    assert np.array_equal(got, ref.counts())
+    ref.close()
+    t.close()

@@ -4,6 +4,8 @@ NetCDF-3 implementation (scipy.io.netcdf_file) and by the DCD writer of tests/tr
 Host-side parsing and reads only: runs without a GPU.
 """
 
+import pathlib
+
 import numpy as np
 import pytest
 
@@ -159,3 +161,27 @@ def test_mutated_headers_fail_cleanly(tmp_path):
             except (ValueError, OSError, NotImplementedError, RuntimeError, MemoryError):
                 outcomes["refused"] += 1
     assert outcomes["ok"] + outcomes["refused"] == 300 and outcomes["refused"] > 20
+
+
+def test_bench_fast_netcdf_writer_is_read_back_by_scipy_and_by_the_native_reader(tmp_path):
+    """bench.py writes its NetCDF input as scipy's header + one big-endian structured array of
+    records (scipy's per-record writes take minutes at bench sizes): scipy — an independent NetCDF-3
+    implementation — and the native reader must both return what went in."""
+    import sys
+    sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+    import bench
+    from scipy.io import netcdf_file
+    rng = np.random.default_rng(5)
+    pos = (rng.random((9, 1237, 3)) * 40).astype(np.float32)
+    box = np.array([40, 41, 42, 90, 90, 90], dtype=np.float32)
+    path = tmp_path / "fast.nc"
+    bench.write_amber_netcdf_fast(str(path), pos, box)
+    with netcdf_file(str(path), "r", mmap=False) as nc:
+        assert np.array_equal(nc.variables["coordinates"][:], pos)
+        assert np.array_equal(nc.variables["cell_lengths"][:], np.tile(box[:3].astype(np.float64), (9, 1)))
+        assert np.array_equal(nc.variables["time"][:], np.arange(9, dtype=np.float32))
+    t = TrajectoryFile(path)
+    assert (t.n_frames, t.n_atoms) == (9, 1237)
+    assert np.array_equal(t.read_positions(np.arange(9)), pos)
+    assert np.array_equal(t.read_boxes([4])[0], box)
+    t.close()
