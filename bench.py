@@ -826,7 +826,7 @@ def bench_rdf_ingest(args, world, resident_fps):
     from mdhelper_amd.analysis import RadialDistributionFunction
     from mdhelper_amd.io import FileUniverse, TrajectoryFile
     dev = world.dev
-    N, F, L = 32768, 3000, 68.94
+    N, F, L = 32768, 6000, 68.94
     box = np.array([L, L, L, 90, 90, 90], dtype=np.float32)
     edges = np.linspace(0.0, 15.0, 202)
     d_traj = _core.synth_random_walk(F, N, box[:3], 0.3, seed=2, dev=dev)

@@ -330,6 +330,12 @@ int mdx_msd_set_grouping(mdx_msd_t h, int64_t n_molecules, const int64_t *offset
 int mdx_msd_system_com_traj(mdx_msd_t h, mdx_traj_t traj, const int64_t *frames, int64_t n_frames,
                             const int32_t *index, int64_t n_index, const double *masses, int unwrap,
                             const double *dims, int wrap, double *out);
+/* Molecules made whole in the first analysed frame (Onsager(unwrap=True), reference
+ * transport.py:936-941: make_whole over universe.atoms.fragments before the starting positions are
+ * stored): images int32[n_sel][3] = the periodic image each row starts in, i.e. the flags the
+ * reference's first unwrap call derives from x - x_whole.  They apply to every following unwrapped
+ * push / system-COM call, whose selection must have n_sel rows in this order; n_sel = 0 clears. */
+int mdx_msd_set_initial_images(mdx_msd_t h, const int32_t *images, int64_t n_sel);
 /* The same frame preparation for frames in host memory (an in-memory trajectory): pos
  * float32[n_frames][n_sel][3] holds the selection, already gathered, in analysis order (rows sorted
  * molecule by molecule when mdx_msd_set_grouping is active); arguments otherwise as for

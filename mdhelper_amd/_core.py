@@ -458,6 +458,15 @@ class MsdEngine(_Engine):
             raise ValueError("masses must hold one entry per particle of the grouping.")
         check(lib().mdx_msd_set_grouping(self.handle, len(o) - 1, _ptr(o), _ptr(m)))
 
+    def set_initial_images(self, images):
+        """int[n_sel, 3] image flags the rows of the following unwrapped pushes / system-COM calls
+        start from (molecules made whole in the first analysed frame); ``None`` clears."""
+        if images is None:
+            check(lib().mdx_msd_set_initial_images(self.handle, None, 0))
+            return
+        im = np.ascontiguousarray(images, dtype=np.int32).reshape(-1, 3)
+        check(lib().mdx_msd_set_initial_images(self.handle, _ptr(im), im.shape[0]))
+
     def push_f32(self, group, positions, *, unwrap_dims=None, zero_dims=0, shift=None):
         """A group's float32 (or float64) positions ``[T, n_sel, 3]`` from host memory through the
         device-side frame preparation (unwrap, molecule centres, shift): ``mdx_msd_push_f32`` /

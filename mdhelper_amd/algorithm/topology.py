@@ -39,6 +39,52 @@ def unwrap(positions, positions_old, dimensions, *, thresholds=None, images=None
     return positions, positions_old, images
 
 
+def make_whole_images(universe, dimensions) -> np.ndarray:
+    """
+    Image flags that make every fragment of the CURRENT frame whole: int[n_atoms, 3] with
+    ``positions + images * dimensions`` = what ``MDAnalysis.lib.mdamath.make_whole`` leaves in each
+    fragment — the walk the reference takes before it stores the starting positions of
+    ``Onsager(unwrap=True)`` (reference transport.py:936-941).
+
+    Restated from MDAnalysis' published algorithm ([ext]; the package is absent here, so this
+    step is parity-unpinned at the ULP level): breadth-first from the fragment's first atom along
+    the bonds; an atom reached over a bond is placed at its placed neighbour + the minimum image of
+    the bond vector.  Orthorhombic cells.  A universe without bonds gives zeros.
+    """
+    n = universe.atoms.n_atoms
+    images = np.zeros((n, 3), dtype=int)
+    bonds = getattr(universe, "_bonds", None)
+    if bonds is None or len(bonds) == 0:
+        return images
+    L = np.asarray(dimensions, dtype=float)[:3]
+    pos = np.asarray(universe.atoms.positions, dtype=float)
+    # adjacency in CSR form, neighbours in index order
+    both = np.concatenate((bonds, bonds[:, ::-1]))
+    both = both[np.lexsort((both[:, 1], both[:, 0]))]
+    start = np.searchsorted(both[:, 0], np.arange(n + 1))
+    placed = np.zeros(n, dtype=bool)
+    for root in range(n):
+        if placed[root] or start[root] == start[root + 1]:
+            continue
+        placed[root] = True
+        queue = [root]
+        while queue:
+            nxt = []
+            for a in queue:
+                for b in both[start[a]:start[a + 1], 1]:
+                    if placed[b]:
+                        continue
+                    # bond vector between the STORED coordinates, folded to its minimum image; the
+                    # neighbour then sits in the image of the atom it was reached from, shifted by
+                    # the fold
+                    d = pos[b] - pos[a]
+                    images[b] = images[a] - np.rint(d / L).astype(int)
+                    placed[b] = True
+                    nxt.append(b)
+            queue = nxt
+    return images
+
+
 def _minimum_image(vectors, dimensions):
     """Shortest periodic image of displacement vectors (``MDAnalysis.lib.distances.
     minimize_vectors`` as called at reference topology.py:497-500): orthorhombic cells by

@@ -333,6 +333,10 @@ class RadialDistributionFunction(DynamicAnalysisBase):
         if native is not None:
             # trajectory file: raw frames stream file -> pinned memory -> HBM inside the library
             block = max(block, 4096)
+        else:
+            # in-memory frames are handed over where they lie (slices, no copy): ~1 GiB per call, the
+            # library pipelines inside a call (copy of slab k + 1 beside the kernels of slab k)
+            block = max(block, (1 << 30) // max(12 * traj.n_atoms, 1))
         for b0 in np.arange(0, len(mine), block):
             sel = mine[b0:b0 + block]
             boxes = traj.box_block(sel)
@@ -565,7 +569,8 @@ class StructureFactor(NumbaAnalysisBase):
             index = np.zeros(0, dtype=int)
         identity = len(index) == traj.n_atoms and np.array_equal(index, np.arange(len(index)))
         native = getattr(traj, "native", None)
-        block = 4096 if native is not None else self._batch.capacity
+        block = 4096 if native is not None else max(self._batch.capacity,
+                                                     (1 << 30) // max(12 * traj.n_atoms, 1))
         for b0 in np.arange(0, len(mine), block):
             sel = mine[b0:b0 + block]
             if self._engine is None:       # an ISF rank without wavevectors of its own

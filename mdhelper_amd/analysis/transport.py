@@ -30,7 +30,7 @@ from scipy import optimize
 from .. import _core
 from ..algorithm import correlation
 from ..algorithm.molecule import center_of_mass
-from ..algorithm.topology import unwrap, wrap
+from ..algorithm.topology import make_whole_images, unwrap, wrap
 from ..algorithm.unit import strip_unit
 from ..comm import shard_range
 from .base import SerialAnalysisBase
@@ -161,13 +161,14 @@ class Onsager(SerialAnalysisBase):
         (a time correlation needs every lag, so frames cannot); the per-group
         accumulators meet in one all-reduce
 
-    One deliberate difference: with ``unwrap=True`` the reference first makes every fragment of the
-    first analysed frame whole (``make_whole`` through the bond graph, transport.py:936-941) before it
-    stores the starting positions.  Bond topologies are not part of this package's AtomGroup surface,
-    so that step is not taken.  Displacements — hence every MSD of atoms and of molecule centres —
-    are unaffected; only ``center=True, center_wrap=True`` with molecule groupings can see it, and
-    only when a molecule is split across the boundary in the first frame (its wrapped centre then
-    starts from the image the stored coordinates imply).
+    With ``unwrap=True`` every fragment of the first analysed frame is made whole before the starting
+    positions are stored (reference transport.py:936-941): a universe that carries bonds
+    (``ArrayUniverse(..., bonds=...)`` / ``FileUniverse``) is walked along them
+    (``algorithm.topology.make_whole_images``), and the image flags that result are where the
+    unwrapping starts — on the host path through ``_positions_old``, on the device paths through
+    ``mdx_msd_set_initial_images``.  Displacements, hence every MSD, do not depend on it; what does is
+    ``center=True, center_wrap=True`` with molecule groupings when a molecule is split across the
+    boundary in that frame.  A universe without bonds has nothing to make whole.
 
     Results: ``results.pairs``, ``results.times``, ``results.msd_cross``
     ``[N_pairs, N_b, N_t]``, ``results.msd_self`` ``[N_g, N_b, N_t]``, ``results.units``;
@@ -287,12 +288,20 @@ class Onsager(SerialAnalysisBase):
         self._from_file = getattr(self, "_from_file", False)
         self._positions = None if self._from_file else np.empty((self.n_frames, index, 3))
 
-        if self._unwrap and not self._from_file:
+        self._images0 = None
+        if self._unwrap:
+            # every fragment of the first analysed frame is made whole before the starting positions
+            # are stored (reference :936-941); universes without bonds have nothing to make whole
             first = st.frames[0] if hasattr(st, "frames") else (self.start or 0)
             self.universe.trajectory[first]
-            self._positions_old = np.array(self.universe.atoms.positions, dtype=float)
-            self._images = np.zeros((self.universe.atoms.n_atoms, 3), dtype=int)
-            self._thresholds = self._dimensions / 2
+            images0 = make_whole_images(self.universe, self._dimensions)
+            if images0.any():
+                self._images0 = images0
+            if not self._from_file:
+                self._positions_old = (np.array(self.universe.atoms.positions, dtype=float)
+                                       + images0 * self._dimensions)
+                self._images = np.zeros((self.universe.atoms.n_atoms, 3), dtype=int)
+                self._thresholds = self._dimensions / 2
 
         self._n_frames_block = self.n_frames // self._n_blocks
         self._n_frames = self._n_blocks * self._n_frames_block
@@ -374,14 +383,22 @@ class Onsager(SerialAnalysisBase):
 
                     def push(g, rows, **kw):
                         eng.push_f32(g, block[:, rows], **kw)
+                def start_images(rows):
+                    # image flags the rows start from (molecules made whole in the first frame)
+                    if self._unwrap:
+                        eng.set_initial_images(None if self._images0 is None else
+                                               self._images0 if rows is None else self._images0[rows])
+
                 shift = None
                 if self._center:
                     # system centre of mass per frame (reference :993-1014), every rank the same
                     wrap_dims = self._dimensions if self._center_wrap else None
                     if self._center_atom:
+                        start_images(None)
                         shift = system_com(None, self.universe.atoms.masses,
                                            unwrap_dims=unwrap_dims, wrap_dims=wrap_dims)
                     elif wrap_dims is None or all(gr == "atoms" for gr in self._groupings):
+                        start_images(np.concatenate([g.indices for g in self._groups]))
                         shift = system_com(np.concatenate([g.indices for g in self._groups]),
                                            np.concatenate([g.masses for g in self._groups]),
                                            unwrap_dims=unwrap_dims, wrap_dims=wrap_dims)
@@ -397,6 +414,7 @@ class Onsager(SerialAnalysisBase):
                             else:
                                 rows, off, m = _R._selection(grp, gr)
                                 eng.set_grouping(off, m)
+                            start_images(rows)
                             com = system_com(rows, m, unwrap_dims=unwrap_dims, wrap_dims=wrap_dims)
                             num = num + com * m.sum()
                             mass += m.sum()
@@ -415,6 +433,7 @@ class Onsager(SerialAnalysisBase):
                         idx, off, m = RadialDistributionFunction._selection(grp, gr)
                         eng.set_grouping(off[lo:hi + 1] - off[lo], m[off[lo]:off[hi]])
                         rows = idx[off[lo]:off[hi]]
+                    start_images(rows)
                     push(g, rows, unwrap_dims=unwrap_dims, zero_dims=zero_mask, shift=shift)
             for g, own in enumerate(self._own_slices):
                 if own.stop > own.start and not self._from_file:

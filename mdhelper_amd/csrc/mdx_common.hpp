@@ -55,10 +55,21 @@ int set_device(int dev);
 struct DeviceBuffer {
     void *ptr = nullptr;
     size_t bytes = 0;
-    int ensure(size_t need);   // reallocates (contents lost) when need > bytes
-    void release();
+    int ensure(size_t need);   // reallocates (contents lost) when need > bytes; takes a cached block when one fits
+    void release();            // hipFree (waits for the device: safe while kernels may still read the block)
+    // Hands the block to the per-device cache instead of freeing it — ONLY after every stream that may have
+    // touched it has been synchronised (the destroy paths).  An analysis object per call, the reference's
+    // usage, otherwise pays ~10 ms of hipMalloc / hipFree per object; the cache is bounded (4 GiB, blocks
+    // up to 512 MiB) and lives as long as the process.
+    void recycle();
     template <typename T> T *as() const { return static_cast<T *>(ptr); }
 };
+
+// Non-blocking streams are handed out from a per-device pool and go back to it when a handle is destroyed
+// (after they have been synchronised): creating and destroying a stream costs about a millisecond each way,
+// and an analysis object per call — the reference's usage — holds three.
+int stream_acquire(hipStream_t *out);      // on the current device
+void stream_release(hipStream_t stream);   // idle streams only
 
 // HIP-event timer on one stream: accumulates the device time of bracketed regions
 struct StreamTimer {
@@ -118,6 +129,7 @@ struct HostStager {
     hipEvent_t ev_batch = nullptr;      // behind everything queued on io so far (consumers wait on it)
     int64_t turn = 0;
     HostWorkers workers;
+    std::mutex lock;                    // one user at a time: the ring of a device is shared by its handles
 
     int ensure(int device, size_t chunk_bytes);
     int after(hipStream_t producer);                 // io waits for what `producer` holds so far
@@ -131,6 +143,11 @@ struct HostStager {
     void destroy();
 };
 
+// The staging ring of a device, shared by every handle on it and kept for the life of the process: pinned
+// allocations and stream creation are milliseconds, an analysis object per call (the reference's usage:
+// RadialDistributionFunction(...).run()) must not pay them every time.  Users hold `lock` while they queue.
+HostStager &device_stager(int dev);
+
 // Double-buffered staging between a producer on a copy stream and the kernels on a handle's
 // compute stream: the fill of slab k+1 overlaps the kernels of slab k.  A buffer is refilled
 // only after the kernels that read it have finished (event), and run() returns once the last
@@ -138,7 +155,6 @@ struct HostStager {
 // still be in flight on the compute stream.
 struct StagePipeline {
     hipStream_t copy_stream = nullptr;
-    HostStager stager;                  // host buffers -> HBM for the fills that start in host memory
     hipEvent_t ev_filled[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
     bool busy[2] = {false, false};
     int ensure();

@@ -290,6 +290,7 @@ struct mdx_msd {
     DeviceBuffer d_masses, d_com_x, d_shift;        // system centre of mass per frame
     // trajectory-file path with groupings="residues"/"segments": rows sorted molecule by molecule
     std::vector<int64_t> mol_offsets;               // CSR over the rows of a push_traj call
+    std::vector<int> images0;                       // initial image flags [n_sel][3] of the next unwrapped pushes
     double mol_mass = 0.0;                          // total mass of the grouping's molecules
     DeviceBuffer d_mol_offsets, d_mol_masses, d_mol_total, d_mol_com;
     bool own_fft = false;                           // n_fft = 2^15, 2^16, 2^18..2^20: mdx_msd_fft.hpp
@@ -403,8 +404,11 @@ __global__ __launch_bounds__(256) void msd_unwrap_widen_kernel(
     const int k = int(e % 3);
     const double L = k == 0 ? lx : (k == 1 ? ly : lz);
     const double half = 0.5 * L;
+    // first_block: 1 = the walk starts here without image flags; 2 = it starts here from the flags in
+    // `image` (molecules made whole in the first analysed frame, transport.py:936-941: the reference's first
+    // unwrap call finds x - x_whole = -k L and sets the flag to k; the flags are given directly here)
     In x_old = first_block ? in[e] : prev[e];
-    int img = first_block ? 0 : image[e];
+    int img = first_block == 1 ? 0 : image[e];
     for (int64_t f = 0; f < n_frames; ++f) {
         const In x = in[f * n_coord + e];
         double v = (double)x;
@@ -474,7 +478,8 @@ struct FrameSource {
 
 // unwrap + widen (+ shift) of one staged block of frames, in the block's element type
 static void msd_launch_unwrap(mdx_msd *h, const FrameSource &src, int64_t n_coord, int64_t nf, int first,
-                              int unwrap, const double *dims, double *d_out, const double *d_shift);
+                              int unwrap, const double *dims, double *d_out, const double *d_shift,
+                              int64_t a0 = 0);
 
 // a trajectory file: listed frames, listed particles (gathered by the unpack kernel)
 struct TrajFrames final : FrameSource {
@@ -524,10 +529,17 @@ template <typename In> struct HostFrames final : FrameSource {
 };
 
 static void msd_launch_unwrap(mdx_msd *h, const FrameSource &src, int64_t n_coord, int64_t nf, int first,
-                              int unwrap, const double *dims, double *d_out, const double *d_shift)
+                              int unwrap, const double *dims, double *d_out, const double *d_shift,
+                              int64_t a0)
 {
     const dim3 grid((unsigned)ceil_div(n_coord, 256));
     const double lx = dims ? dims[0] : 0.0, ly = dims ? dims[1] : 0.0, lz = dims ? dims[2] : 0.0;
+    if (first && unwrap && !h->images0.empty()) {
+        // initial image flags of rows [a0, a0 + n_coord / 3) (mdx_msd_set_initial_images)
+        (void)hipMemcpyAsync(h->d_image.ptr, h->images0.data() + 3 * a0, size_t(4) * n_coord,
+                             hipMemcpyHostToDevice, h->stream);
+        first = 2;
+    }
     if (src.elem() == 8)
         hipLaunchKernelGGL(msd_unwrap_widen_kernel<double>, grid, dim3(256), 0, h->stream,
                            h->d_f32.as<double>(), n_coord, nf, first, unwrap, lx, ly, lz,
@@ -563,6 +575,9 @@ static int msd_system_com_frames(mdx_msd *h, FrameSource &src, int64_t n_frames,
     for (int64_t i = 0; i < n_sel; ++i)
         total += masses[i];
     MDX_REQUIRE(total > 0.0, "the selection has no mass");
+    MDX_REQUIRE(!unwrap || h->images0.empty() || (int64_t)h->images0.size() == 3 * n_sel,
+                "initial image flags were set for %lld particles, %lld are staged",
+                (long long)h->images0.size() / 3, (long long)n_sel);
     MDX_TRY(src.prepare(h, n_sel));
     MDX_TRY(h->d_masses.ensure(size_t(8) * n_sel));
     MDX_HIP(hipMemcpy(h->d_masses.ptr, masses, size_t(8) * n_sel, hipMemcpyHostToDevice));
@@ -662,6 +677,9 @@ static int msd_push_frames(mdx_msd *h, int group, FrameSource &src, int64_t n_se
             cuts.push_back(a0);
         cuts.push_back(n_sel);
     }
+    MDX_REQUIRE(!unwrap || h->images0.empty() || (int64_t)h->images0.size() == 3 * n_sel,
+                "initial image flags were set for %lld particles, %lld are staged",
+                (long long)h->images0.size() / 3, (long long)n_sel);
     MDX_TRY(src.prepare(h, n_sel));
     MDX_TRY(h->d_stage.ensure(size_t(T) * chunk * 24));
     const int64_t row_bytes = int64_t(3) * src.elem();
@@ -686,7 +704,7 @@ static int msd_push_frames(mdx_msd *h, int group, FrameSource &src, int64_t n_se
             MDX_TRY(src.stage(h, a0, c, f0, nf, h->d_f32.ptr));
             msd_launch_unwrap(h, src, 3 * c, nf, f0 == 0 ? 1 : 0, unwrap, dims,
                               h->d_stage.as<double>() + f0 * c * 3,
-                              shift_rows ? h->d_shift.as<double>() + 3 * f0 : nullptr);
+                              shift_rows ? h->d_shift.as<double>() + 3 * f0 : nullptr, a0);
             MDX_HIP(hipGetLastError());
         }
         if (!molecules) {
@@ -968,6 +986,17 @@ int mdx_msd_system_com_f64(mdx_msd_t h, const double *pos, int64_t n_frames, int
         return MDX_OK;
     HostFrames<double> src(pos, n_sel);
     return msd_system_com_frames(h, src, n_frames, n_sel, masses, unwrap, dims, wrap, out);
+}
+
+int mdx_msd_set_initial_images(mdx_msd_t h, const int32_t *images, int64_t n_sel)
+{
+    MDX_REQUIRE(h, "NULL handle");
+    MDX_REQUIRE(n_sel >= 0 && (n_sel == 0 || images), "bad image flags");
+    MDX_TRY(set_device(h->dev));
+    // an earlier call's copy out of the vector may still be queued
+    MDX_HIP(hipStreamSynchronize(h->stream));
+    h->images0.assign(images, images + 3 * n_sel);
+    return MDX_OK;
 }
 
 int mdx_msd_push_f32(mdx_msd_t h, int group, const float *pos, int64_t n_frames, int64_t n_sel,

@@ -377,6 +377,7 @@ struct mdx_rdf {
     DeviceBuffer d_drop[2], d_drop_box;
     // host-buffer entry point: double-buffered staging, copy stream, hand-over events
     DeviceBuffer d_stage1[2], d_stage2[2], d_boxes[2], d_index[2];
+    DeviceBuffer d_rawslab[2];   // trajectory files: a slab of raw frames between the copy and the unpack kernel
     StagePipeline pipe;
     DeviceBuffer d_pw1, d_po1, d_bb1, d_pw2, d_po2, d_bb2;   // cell path: sorted copies + tile boxes
     DeviceBuffer d_bb16_1, d_bb16_2;                         // boxes of the CELL_CHUNK-particle chunks
@@ -481,7 +482,7 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
         MDX_TRY(h->d_bb2.ensure(16 * e_b2 * n_sets));
     }
     if (n_sets == 2 && !h->sort_stream) {
-        MDX_HIP(hipStreamCreateWithFlags(&h->sort_stream, hipStreamNonBlocking));
+        MDX_TRY(stream_acquire(&h->sort_stream));
         MDX_HIP(hipEventCreateWithFlags(&h->ev_inputs, hipEventDisableTiming));
         for (int b = 0; b < 2; ++b) {
             MDX_HIP(hipEventCreateWithFlags(&h->ev_sorted[b], hipEventDisableTiming));
@@ -982,19 +983,25 @@ static int check_host_boxes(const float *boxes, int64_t n_frames)
 // Host-buffer and trajectory-file entry points: slabs of frames go through the double-buffered
 // staging sets (StagePipeline).  fill(b, f0, nf) queues on the copy stream whatever brings
 // frames [f0, f0+nf) into d_stage1[b] (and d_stage2[b] unless `same`).
-template <typename Fill>
+// prepare(b, f0, nf): queued on the COMPUTE stream ahead of the slab's kernels (the unpack of raw frames).
+template <typename Fill, typename Prepare>
 static int accumulate_pipelined(mdx_rdf *h, int64_t n1, int64_t n2, bool same, const float *boxes,
-                                int64_t n_frames, int64_t source_bytes_per_frame, Fill fill)
+                                int64_t n_frames, int64_t source_bytes_per_frame, Fill fill, Prepare prepare)
 {
-    const int64_t slab = std::min<int64_t>(
-        n_frames, std::max<int64_t>(1, (int64_t(64) << 20) / source_bytes_per_frame));
+    // slabs of ~128 MiB: each slab is one sort + one pair launch on the compute stream, and the sort (one block per
+    // frame, latency-bound, ~0.5 ms per round of 512 frames) cannot run beside the persistent pair kernel, so
+    // small slabs pay it again and again; a multiple of 8 frames, so that every XCD gets the same number
+    int64_t slab = std::max<int64_t>(1, (int64_t(128) << 20) / source_bytes_per_frame);
+    if (slab >= 8)
+        slab -= slab % 8;
+    slab = std::min<int64_t>(n_frames, slab);
     return h->pipe.run(
         h->stream, n_frames, slab,
         [&](int b, int64_t f0, int64_t nf) -> int {
             MDX_TRY(h->d_stage1[b].ensure(size_t(12) * n1 * slab));
             if (!same)
                 MDX_TRY(h->d_stage2[b].ensure(size_t(12) * n2 * slab));
-            MDX_TRY(fill(b, f0, nf));
+            MDX_TRY(fill(b, f0, nf, slab));
             if (boxes) {
                 MDX_TRY(h->d_boxes[b].ensure(size_t(24) * slab));
                 MDX_HIP(hipMemcpyAsync(h->d_boxes[b].ptr, boxes + f0 * 6, size_t(24) * nf,
@@ -1003,6 +1010,7 @@ static int accumulate_pipelined(mdx_rdf *h, int64_t n1, int64_t n2, bool same, c
             return MDX_OK;
         },
         [&](int b, int64_t f0, int64_t nf) -> int {
+            MDX_TRY(prepare(b, f0, nf));
             return accumulate_device(h, h->d_stage1[b].as<float>(), n1,
                                      same ? nullptr : h->d_stage2[b].as<float>(), n2,
                                      boxes ? h->d_boxes[b].as<float>() : nullptr,
@@ -1041,10 +1049,8 @@ int mdx_rdf_create(mdx_rdf_t *out, int dev, int n_bins, const double *edges, int
     h->t_hi = thresh_gt(edges[n_bins]);
     int rc = MDX_OK;
     do {
-        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
-            rc = fail(MDX_ERR_HIP, "hipStreamCreate failed");
+        if ((rc = stream_acquire(&h->stream)) != MDX_OK)
             break;
-        }
         h->timer.stream = h->stream;
         if ((rc = h->d_thresh.ensure(sizeof(double) * (n_bins + 1))) != MDX_OK) break;
         if ((rc = h->d_counts.ensure(sizeof(uint64_t) * size_t(h->n_rep) * n_bins)) != MDX_OK) break;
@@ -1071,21 +1077,26 @@ int mdx_rdf_destroy(mdx_rdf_t h)
     if (!h)
         return MDX_OK;
     (void)hipSetDevice(h->dev);
+    // every stream that may still touch the handle's memory drains first: the blocks go back to the device's
+    // cache (DeviceBuffer::recycle), not through hipFree, which would wait for the device itself
     if (h->stream)
         (void)hipStreamSynchronize(h->stream);
+    if (h->sort_stream)
+        (void)hipStreamSynchronize(h->sort_stream);
+    if (h->pipe.copy_stream)
+        (void)hipStreamSynchronize(h->pipe.copy_stream);
     h->timer.destroy();
     h->pipe.destroy();
     for (DeviceBuffer *b : {&h->d_thresh, &h->d_counts, &h->d_total, &h->d_pack1, &h->d_pack2,
                             &h->d_stage1[0], &h->d_stage2[0], &h->d_boxes[0], &h->d_stage1[1],
-                            &h->d_stage2[1], &h->d_boxes[1], &h->d_index[0], &h->d_index[1], &h->d_tri, &h->d_misc, &h->d_stats, &h->d_work, &h->d_pw1,
+                            &h->d_stage2[1], &h->d_boxes[1], &h->d_rawslab[0], &h->d_rawslab[1], &h->d_index[0], &h->d_index[1], &h->d_tri, &h->d_misc, &h->d_stats, &h->d_work, &h->d_pw1,
                             &h->d_po1, &h->d_bb1, &h->d_pw2, &h->d_po2, &h->d_bb2, &h->d_bb16_1,
                             &h->d_bb16_2, &h->d_drop[0], &h->d_drop[1], &h->d_drop_box})
-        b->release();
+        b->recycle();
     h->grouping[0].release();
     h->grouping[1].release();
     if (h->sort_stream) {
-        (void)hipStreamSynchronize(h->sort_stream);
-        (void)hipStreamDestroy(h->sort_stream);
+        stream_release(h->sort_stream);
         (void)hipEventDestroy(h->ev_inputs);
         for (int b = 0; b < 2; ++b) {
             (void)hipEventDestroy(h->ev_sorted[b]);
@@ -1093,7 +1104,7 @@ int mdx_rdf_destroy(mdx_rdf_t h)
         }
     }
     if (h->stream)
-        (void)hipStreamDestroy(h->stream);
+        stream_release(h->stream);
     delete h;
     return MDX_OK;
 }
@@ -1158,16 +1169,17 @@ int mdx_rdf_accumulate(mdx_rdf_t h, const float *pos1, int64_t n1, const float *
     MDX_TRY(check_host_boxes(boxes, n_frames));
     return accumulate_pipelined(
         h, n1, n2, same, boxes, n_frames, 12 * std::max(n1, n2),
-        [&](int b, int64_t f0, int64_t nf) -> int {
+        [&](int b, int64_t f0, int64_t nf, int64_t) -> int {
             // caller memory -> pinned ring (host threads) -> HBM; pinned / registered caller
             // memory is read by the DMA engine where it lies
-            MDX_TRY(h->pipe.stager.upload(h->dev, h->pipe.copy_stream, h->d_stage1[b].ptr,
+            MDX_TRY(device_stager(h->dev).upload(h->dev, h->pipe.copy_stream, h->d_stage1[b].ptr,
                                           pos1 + f0 * n1 * 3, size_t(12) * n1 * nf));
             if (!same)
-                MDX_TRY(h->pipe.stager.upload(h->dev, h->pipe.copy_stream, h->d_stage2[b].ptr,
+                MDX_TRY(device_stager(h->dev).upload(h->dev, h->pipe.copy_stream, h->d_stage2[b].ptr,
                                               pos2 + f0 * n2 * 3, size_t(12) * n2 * nf));
             return MDX_OK;
-        });
+        },
+        [](int, int64_t, int64_t) -> int { return MDX_OK; });
 }
 
 // Frames straight from a trajectory file (mdx_traj.hip): raw records -> pinned -> HBM ->
@@ -1210,12 +1222,19 @@ int mdx_rdf_accumulate_traj(mdx_rdf_t h, mdx_traj_t traj, const int64_t *frames,
                           hipMemcpyHostToDevice));
         d_idx[g] = h->d_index[g].as<int>();
     }
+    // raw frames -> pinned ring -> HBM by DMA on the ring's stream, beside the kernels of the previous slab;
+    // the unpack kernel (byte swap / plane transpose / gather) is queued on the compute stream ahead of the
+    // slab's sort: the persistent pair kernel leaves no wave slot for a kernel on another stream
     return accumulate_pipelined(
         h, n1, n2, same, boxes, n_frames, 12 * t->n_atoms,
-        [&](int b, int64_t f0, int64_t nf) -> int {
+        [&](int b, int64_t f0, int64_t nf, int64_t slab) -> int {
+            MDX_TRY(h->d_rawslab[b].ensure(size_t(12) * t->n_atoms * slab));
+            return t->stage_raw_async(h->dev, h->pipe.copy_stream, frames + f0, nf, h->d_rawslab[b].ptr);
+        },
+        [&](int b, int64_t, int64_t nf) -> int {
             TrajSelection sel[2] = {{d_idx[0], n1, h->d_stage1[b].as<float>()},
                                     {d_idx[1], n2, same ? nullptr : h->d_stage2[b].as<float>()}};
-            return t->stage_async(h->dev, h->pipe.copy_stream, frames + f0, nf, sel, same ? 1 : 2);
+            return t->unpack_async(h->stream, h->d_rawslab[b].ptr, nf, sel, same ? 1 : 2);
         });
 }
 

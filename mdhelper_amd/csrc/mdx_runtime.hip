@@ -33,6 +33,20 @@ int set_device(int dev)
     return MDX_OK;
 }
 
+namespace {
+struct BlockCache {
+    std::mutex m;
+    std::vector<std::pair<size_t, void *>> blocks[64];   // per device: (bytes, pointer)
+    size_t cached[64] = {};
+};
+BlockCache &block_cache()
+{
+    static BlockCache *c = new BlockCache();   // never destroyed: the HIP runtime may be gone at exit
+    return *c;
+}
+constexpr size_t CACHE_BLOCK_MAX = size_t(512) << 20, CACHE_TOTAL_MAX = size_t(4) << 30;
+}  // namespace
+
 int DeviceBuffer::ensure(size_t need)
 {
     if (need <= bytes)
@@ -40,7 +54,44 @@ int DeviceBuffer::ensure(size_t need)
     release();
     // round up so a slowly growing batch does not reallocate every call
     size_t want = (need + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
-    MDX_HIP(hipMalloc(&ptr, want));
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        BlockCache &c = block_cache();
+        std::lock_guard<std::mutex> lk(c.m);
+        auto &v = c.blocks[dev];
+        // smallest cached block that fits without wasting more than half of itself
+        size_t best = v.size();
+        for (size_t i = 0; i < v.size(); ++i)
+            if (v[i].first >= want && v[i].first <= 2 * want && (best == v.size() || v[i].first < v[best].first))
+                best = i;
+        if (best != v.size()) {
+            ptr = v[best].second;
+            bytes = v[best].first;
+            c.cached[dev] -= bytes;
+            v[best] = v.back();
+            v.pop_back();
+            return MDX_OK;
+        }
+    }
+    hipError_t e = hipMalloc(&ptr, want);
+    if (e == hipErrorOutOfMemory) {
+        // give the cache back before giving up
+        (void)hipGetLastError();
+        BlockCache &c = block_cache();
+        {
+            std::lock_guard<std::mutex> lk(c.m);
+            if (dev >= 0 && dev < 64) {
+                for (auto &b : c.blocks[dev])
+                    (void)hipFree(b.second);
+                c.blocks[dev].clear();
+                c.cached[dev] = 0;
+            }
+        }
+        e = hipMalloc(&ptr, want);
+    }
+    if (e != hipSuccess)
+        ptr = nullptr;
+    MDX_HIP(e);
     bytes = want;
     return MDX_OK;
 }
@@ -51,6 +102,70 @@ void DeviceBuffer::release()
         (void)hipFree(ptr);
     ptr = nullptr;
     bytes = 0;
+}
+
+void DeviceBuffer::recycle()
+{
+    if (!ptr)
+        return;
+    int dev = -1;
+    if (bytes <= CACHE_BLOCK_MAX && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        BlockCache &c = block_cache();
+        std::lock_guard<std::mutex> lk(c.m);
+        if (c.cached[dev] + bytes <= CACHE_TOTAL_MAX) {
+            c.blocks[dev].emplace_back(bytes, ptr);
+            c.cached[dev] += bytes;
+            ptr = nullptr;
+            bytes = 0;
+            return;
+        }
+    }
+    release();
+}
+
+namespace {
+struct StreamPool {
+    std::mutex m;
+    std::vector<hipStream_t> idle[64];
+};
+StreamPool &stream_pool()
+{
+    static StreamPool *p = new StreamPool();
+    return *p;
+}
+}  // namespace
+
+int stream_acquire(hipStream_t *out)
+{
+    int dev = 0;
+    MDX_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64) {
+        StreamPool &p = stream_pool();
+        std::lock_guard<std::mutex> lk(p.m);
+        if (!p.idle[dev].empty()) {
+            *out = p.idle[dev].back();
+            p.idle[dev].pop_back();
+            return MDX_OK;
+        }
+    }
+    MDX_HIP(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+    return MDX_OK;
+}
+
+void stream_release(hipStream_t stream)
+{
+    if (!stream)
+        return;
+    int dev = -1;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        StreamPool &p = stream_pool();
+        std::lock_guard<std::mutex> lk(p.m);
+        if (p.idle[dev].size() < 16) {
+            p.idle[dev].push_back(stream);
+            return;
+        }
+    }
+    (void)hipStreamDestroy(stream);
 }
 
 hipEvent_t StreamTimer::begin()
@@ -313,10 +428,23 @@ int HostStager::drain()
     return MDX_OK;
 }
 
+HostStager &device_stager(int dev)
+{
+    // (never destroyed: at process exit the HIP runtime may already be gone)
+    static HostStager *rings[64] = {};
+    static std::mutex m;
+    std::lock_guard<std::mutex> lk(m);
+    const int i = dev < 0 ? 0 : dev % 64;
+    if (!rings[i])
+        rings[i] = new HostStager();
+    return *rings[i];
+}
+
 int HostStager::upload(int device, hipStream_t consumer, void *d_dst, const void *src, size_t bytes)
 {
     if (bytes == 0)
         return MDX_OK;
+    std::lock_guard<std::mutex> guard(lock);
     // memory the device can read where it lies (hipHostMalloc / hipHostRegister, e.g. through
     // mdx_host_register): one DMA, no staging copy
     hipPointerAttribute_t attr;
@@ -384,7 +512,7 @@ int StagePipeline::ensure()
 {
     if (copy_stream)
         return MDX_OK;
-    MDX_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    MDX_TRY(stream_acquire(&copy_stream));
     for (int b = 0; b < 2; ++b) {
         MDX_HIP(hipEventCreateWithFlags(&ev_filled[b], hipEventDisableTiming));
         MDX_HIP(hipEventCreateWithFlags(&ev_consumed[b], hipEventDisableTiming));
@@ -394,11 +522,10 @@ int StagePipeline::ensure()
 
 void StagePipeline::destroy()
 {
-    stager.destroy();
     if (!copy_stream)
         return;
     (void)hipStreamSynchronize(copy_stream);
-    (void)hipStreamDestroy(copy_stream);
+    stream_release(copy_stream);
     copy_stream = nullptr;
     for (int b = 0; b < 2; ++b) {
         if (ev_filled[b]) (void)hipEventDestroy(ev_filled[b]);

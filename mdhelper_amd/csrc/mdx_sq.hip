@@ -393,7 +393,7 @@ int mdx_sq_accumulate(mdx_sq_t h, const float *pos, int64_t n, int64_t n_frames)
         h->stream, n_frames, slab,
         [&](int b, int64_t f0, int64_t nf) -> int {
             MDX_TRY(h->d_stage[b].ensure(size_t(12) * n * slab));
-            return h->pipe.stager.upload(h->dev, h->pipe.copy_stream, h->d_stage[b].ptr,
+            return device_stager(h->dev).upload(h->dev, h->pipe.copy_stream, h->d_stage[b].ptr,
                                          pos + f0 * n * 3, size_t(12) * n * nf);
         },
         [&](int b, int64_t, int64_t nf) -> int {

@@ -487,7 +487,13 @@ void Trajectory::close()
 {
     if (dev >= 0) {
         (void)hipSetDevice(dev);
-        stager.destroy();
+        {
+            // what this trajectory queued on the shared ring's stream reads d_raw
+            HostStager &ring = device_stager(dev);
+            std::lock_guard<std::mutex> guard(ring.lock);
+            if (ring.io)
+                (void)hipStreamSynchronize(ring.io);
+        }
         d_raw.release();
         dev = -1;
     }
@@ -675,55 +681,111 @@ __global__ __launch_bounds__(256) void traj_unpack_kernel(const uint32_t *__rest
     }
 }
 
+static int check_selections(const Trajectory &t, const TrajSelection *sel, int n_sel)
+{
+    MDX_REQUIRE(n_sel >= 1 && sel, "no selection given");
+    for (int i = 0; i < n_sel; ++i)
+        MDX_REQUIRE(sel[i].n_sel >= 0 && (sel[i].d_index || sel[i].n_sel <= t.n_atoms),
+                    "selection %d is larger than the trajectory", i);
+    return MDX_OK;
+}
+
+static void launch_unpack(const Trajectory &t, hipStream_t stream, const void *d_raw, int64_t f0, int64_t nf,
+                          const TrajSelection *sel, int n_sel)
+{
+    for (int i = 0; i < n_sel; ++i) {
+        if (sel[i].n_sel == 0)
+            continue;
+        const int64_t total = 3 * sel[i].n_sel * nf;
+        const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(total, 256), 65536);
+        hipLaunchKernelGGL(traj_unpack_kernel, dim3(grid), dim3(256), 0, stream,
+                           static_cast<const uint32_t *>(d_raw), sel[i].d_index,
+                           reinterpret_cast<uint32_t *>(sel[i].d_out + f0 * sel[i].n_sel * 3), t.n_atoms,
+                           sel[i].n_sel, nf, t.format == TRAJ_DCD ? 1 : 0, t.swap ? 1 : 0);
+    }
+}
+
 int Trajectory::stage_async(int device, hipStream_t consumer, const int64_t *frames, int64_t n,
                             const TrajSelection *sel, int n_sel)
 {
     MDX_TRY(check_frames(*this, frames, n));
-    MDX_REQUIRE(n_sel >= 1 && sel, "no selection given");
-    for (int i = 0; i < n_sel; ++i)
-        MDX_REQUIRE(sel[i].n_sel >= 0 && (sel[i].d_index || sel[i].n_sel <= n_atoms),
-                    "selection %d is larger than the trajectory", i);
+    MDX_TRY(check_selections(*this, sel, n_sel));
     if (n == 0)
         return MDX_OK;
     if (dev >= 0 && dev != device)
         return fail(MDX_ERR_STATE, "trajectory handle is bound to device %d", dev);
     MDX_TRY(set_device(device));
     dev = device;
+    HostStager &ring = device_stager(device);
+    std::lock_guard<std::mutex> guard(ring.lock);
     const int64_t per_frame = 12 * n_atoms;
     const int64_t chunk = std::max<int64_t>(1, (int64_t(16) << 20) / per_frame);
-    MDX_TRY(stager.ensure(device, size_t(chunk * per_frame)));
+    MDX_TRY(ring.ensure(device, size_t(chunk * per_frame)));
     MDX_TRY(d_raw.ensure(size_t(chunk * per_frame)));
     // the outputs may still be read by kernels the consumer queued earlier
-    MDX_TRY(stager.after(consumer));
+    MDX_TRY(ring.after(consumer));
     int rc = MDX_OK;
     for (int64_t f0 = 0; f0 < n && rc == MDX_OK; f0 += chunk) {
         const int64_t nf = std::min(chunk, n - f0);
         int b;
         void *host;
-        if ((rc = stager.acquire(&b, &host)) != MDX_OK)
+        if ((rc = ring.acquire(&b, &host)) != MDX_OK)
             break;
-        if ((rc = fill_raw(frames + f0, nf, static_cast<uint8_t *>(host), &stager.workers)) != MDX_OK)
+        if ((rc = fill_raw(frames + f0, nf, static_cast<uint8_t *>(host), &ring.workers)) != MDX_OK)
             break;
-        // io runs in order: this copy into d_raw follows the unpack kernels of the previous chunk
-        if ((rc = stager.send(b, d_raw.ptr, size_t(nf * per_frame))) != MDX_OK)
+        // the ring's stream runs in order: this copy into d_raw follows the unpack kernels of the previous chunk
+        if ((rc = ring.send(b, d_raw.ptr, size_t(nf * per_frame))) != MDX_OK)
             break;
-        for (int i = 0; i < n_sel; ++i) {
-            if (sel[i].n_sel == 0)
-                continue;
-            const int64_t total = 3 * sel[i].n_sel * nf;
-            const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(total, 256), 65536);
-            hipLaunchKernelGGL(traj_unpack_kernel, dim3(grid), dim3(256), 0, stager.io,
-                               d_raw.as<uint32_t>(), sel[i].d_index,
-                               reinterpret_cast<uint32_t *>(sel[i].d_out + f0 * sel[i].n_sel * 3),
-                               n_atoms, sel[i].n_sel, nf, format == TRAJ_DCD ? 1 : 0, swap ? 1 : 0);
-        }
+        launch_unpack(*this, ring.io, d_raw.ptr, f0, nf, sel, n_sel);
         if (hipGetLastError() != hipSuccess)
             rc = fail(MDX_ERR_HIP, "trajectory unpack kernel launch failed");
     }
     // on every path — a failed read included — the consumer is ordered behind what did get queued,
     // so the outputs are never written behind its back; nothing is left recorded on its stream
-    const int rc2 = stager.finish(consumer);
+    const int rc2 = ring.finish(consumer);
     return rc != MDX_OK ? rc : rc2;
+}
+
+int Trajectory::stage_raw_async(int device, hipStream_t consumer, const int64_t *frames, int64_t n,
+                                void *d_raw_out)
+{
+    MDX_TRY(check_frames(*this, frames, n));
+    if (n == 0)
+        return MDX_OK;
+    MDX_REQUIRE(d_raw_out, "NULL output");
+    if (dev >= 0 && dev != device)
+        return fail(MDX_ERR_STATE, "trajectory handle is bound to device %d", dev);
+    MDX_TRY(set_device(device));
+    dev = device;
+    HostStager &ring = device_stager(device);
+    std::lock_guard<std::mutex> guard(ring.lock);
+    const int64_t per_frame = 12 * n_atoms;
+    const int64_t chunk = std::max<int64_t>(1, (int64_t(16) << 20) / per_frame);
+    MDX_TRY(ring.ensure(device, size_t(chunk * per_frame)));
+    int rc = MDX_OK;
+    for (int64_t f0 = 0; f0 < n && rc == MDX_OK; f0 += chunk) {
+        const int64_t nf = std::min(chunk, n - f0);
+        int b;
+        void *host;
+        if ((rc = ring.acquire(&b, &host)) != MDX_OK)
+            break;
+        if ((rc = fill_raw(frames + f0, nf, static_cast<uint8_t *>(host), &ring.workers)) != MDX_OK)
+            break;
+        rc = ring.send(b, static_cast<uint8_t *>(d_raw_out) + f0 * per_frame, size_t(nf * per_frame));
+    }
+    const int rc2 = ring.finish(consumer);
+    return rc != MDX_OK ? rc : rc2;
+}
+
+int Trajectory::unpack_async(hipStream_t stream, const void *d_raw_in, int64_t n, const TrajSelection *sel,
+                             int n_sel) const
+{
+    MDX_TRY(check_selections(*this, sel, n_sel));
+    if (n == 0)
+        return MDX_OK;
+    launch_unpack(*this, stream, d_raw_in, 0, n, sel, n_sel);
+    MDX_HIP(hipGetLastError());
+    return MDX_OK;
 }
 
 }  // namespace mdx

@@ -52,11 +52,11 @@ struct Trajectory {
     int64_t dcd_istart = 0, dcd_nsavc = 1;
     double coord_scale = 1.0;   // NetCDF scale_factor attribute of `coordinates`
 
-    // device pipeline (created on first use): the pinned ring, its stream and its events belong to
-    // the trajectory, and the unpack kernels run on that stream too — nothing here is ever
-    // recorded on a caller's stream, so engines may come and go around one open trajectory
+    // device pipeline (created on first use): frames travel through the device's shared pinned ring
+    // (device_stager: its stream, its events — nothing is ever recorded on a caller's stream, so
+    // engines may come and go around one open trajectory); d_raw holds one chunk of raw frames
+    // between the copy and the unpack kernel of stage_async
     int dev = -1;
-    HostStager stager;
     DeviceBuffer d_raw;
 
     int open(const char *path);
@@ -73,6 +73,16 @@ struct Trajectory {
     // filled; copies and kernels may still be in flight, also across calls.
     int stage_async(int device, hipStream_t consumer, const int64_t *frames, int64_t n,
                     const TrajSelection *sel, int n_sel);
+
+    // The same in two halves, for consumers whose own kernels leave no room on the chip (the RDF's
+    // persistent pair kernel holds every wave slot until its launch ends, so a kernel on another
+    // stream waits for it — and with it would every copy queued behind that kernel):
+    //   stage_raw_async  raw frames -> pinned -> d_raw_out[n][12 n_atoms bytes], copies only (DMA), on
+    //                    the ring's stream; `consumer` waits for them;
+    //   unpack_async     the unpack kernel(s) on the CALLER's stream, in order with its other kernels.
+    int stage_raw_async(int device, hipStream_t consumer, const int64_t *frames, int64_t n, void *d_raw_out);
+    int unpack_async(hipStream_t stream, const void *d_raw_in, int64_t n, const TrajSelection *sel,
+                     int n_sel) const;
 
 private:
     int parse_netcdf(const std::vector<uint8_t> &head, bool &need_more);

@@ -168,9 +168,10 @@ class FileUniverse(ArrayUniverse):
     path : str
     dt : float, optional
         Time between frames; by default the spacing of the first two stored times.
-    masses, charges, resids, segids : per-atom arrays, optional (as for ``ArrayUniverse``)
+    masses, charges, resids, segids, bonds : optional (as for ``ArrayUniverse``)
     """
 
-    def __init__(self, path, dt=None, *, masses=None, charges=None, resids=None, segids=None):
+    def __init__(self, path, dt=None, *, masses=None, charges=None, resids=None, segids=None,
+                 bonds=None):
         self.trajectory = FileTrajectory(path, dt)
-        self._init_topology(masses, charges, resids, segids)
+        self._init_topology(masses, charges, resids, segids, bonds)

@@ -236,6 +236,17 @@ class AtomGroup:
     def atoms(self):
         return self
 
+    @property
+    def fragments(self):
+        """Connected components of the bond graph that hold atoms of this group, each as an
+        AtomGroup of ALL its atoms in index order, ordered by first atom (MDAnalysis'
+        ``AtomGroup.fragments``).  A universe without bonds: every atom is its own fragment."""
+        labels = self.universe._fragment_labels()
+        keep = np.unique(labels[self.indices])
+        order = np.argsort(labels, kind="stable")
+        bounds = np.searchsorted(labels[order], np.arange(labels.max() + 2))
+        return tuple(AtomGroup(self.universe, order[bounds[k]:bounds[k + 1]]) for k in keep)
+
     def __getattr__(self, name):
         if name == "charges":
             if self.universe._charges is None:
@@ -267,14 +278,43 @@ class ArrayUniverse:
     dt : float
         Time between frames (ps, or reduced time).
     masses, charges, resids, segids : per-atom arrays, optional
+    bonds : int[n_bonds, 2], optional
+        Bonded atom pairs; they define ``atoms.fragments`` (what ``Onsager(unwrap=True)`` makes
+        whole in the first analysed frame, reference transport.py:936-941).
     """
 
     def __init__(self, positions, dimensions=None, dt: float = 1.0, *, masses=None,
-                 charges=None, resids=None, segids=None):
+                 charges=None, resids=None, segids=None, bonds=None):
         self.trajectory = ArrayTrajectory(positions, dimensions, dt)
-        self._init_topology(masses, charges, resids, segids)
+        self._init_topology(masses, charges, resids, segids, bonds)
 
-    def _init_topology(self, masses, charges, resids, segids):
+    def _fragment_labels(self):
+        """Fragment number of every atom, fragments numbered by their first atom."""
+        if self._fragments is None:
+            n = self.trajectory.n_atoms
+            if self._bonds is None or len(self._bonds) == 0:
+                self._fragments = np.arange(n)
+            else:
+                from scipy.sparse import coo_matrix
+                from scipy.sparse.csgraph import connected_components
+                b = self._bonds
+                graph = coo_matrix((np.ones(len(b), dtype=np.int8), (b[:, 0], b[:, 1])), shape=(n, n))
+                _, raw = connected_components(graph, directed=False)
+                # renumber by first appearance, so that fragments come out ordered by first atom
+                _, first = np.unique(raw, return_index=True)
+                rank = np.empty(len(first), dtype=int)
+                rank[np.argsort(first)] = np.arange(len(first))
+                self._fragments = rank[raw]
+        return self._fragments
+
+    def _init_topology(self, masses, charges, resids, segids, bonds=None):
+        self._bonds = None
+        self._fragments = None
+        if bonds is not None:
+            b = np.asarray(bonds, dtype=int).reshape(-1, 2)
+            if len(b) and (b.min() < 0 or b.max() >= self.trajectory.n_atoms):
+                raise ValueError("bond indices out of range.")
+            self._bonds = b
         n = self.trajectory.n_atoms
         self._masses = np.ones(n) if masses is None else np.asarray(masses, dtype=float)
         self._charges = None if charges is None else np.asarray(charges, dtype=float)

@@ -338,3 +338,71 @@ def test_failed_read_leaves_the_trajectory_usable(tmp_path):
     assert np.array_equal(got, ref.counts())
     ref.close()
     t.close()
+
+
+def test_onsager_unwrap_makes_split_molecules_whole_first(tmp_path):
+    """
+    Reference transport.py:936-941: with ``unwrap=True`` every fragment of the first analysed frame is
+    made whole before the starting positions are stored.  Dimers, several of them split across the
+    cell boundary in frame 0, ``groupings="residues"``, ``center=True, center_wrap=True`` (the one
+    combination that sees it: the wrapped CENTRE of a split molecule depends on which images its atoms
+    start in).  Three routes must agree: the device stages fed from memory, the device stages fed from
+    a file, the per-frame host protocol; and all of them must equal the analysis of the TRUE
+    (never wrapped, whole) coordinates without unwrapping — those differ from the made-whole walk by
+    one lattice vector per molecule, which the wrap of the centres removes.  A universe without bonds
+    (nothing to make whole) must NOT agree: that is what the step is for.
+    """
+    import warnings
+    from mdhelper_amd.analysis import Onsager
+    rng = np.random.default_rng(44)
+    T, M, L = 48, 40, np.array([12.0, 13.0, 11.5])
+    masses = np.tile([12.0, 1.5], M)
+    centre0 = rng.uniform(0, L, (M, 3))
+    centre0[:6, 0] = L[0] - 0.05 * np.arange(1, 7)         # six dimers straddle the x boundary in frame 0
+    centre0[6:9, 2] = 0.02                                 # three the z boundary
+    axis = rng.normal(size=(M, 3))
+    axis[:6] = [1.0, 0.1, 0.0]
+    axis[6:9] = [0.0, 0.1, 1.0]
+    axis /= np.linalg.norm(axis, axis=1, keepdims=True)
+    walk = centre0 + np.cumsum(rng.normal(0, 0.25, (T, M, 3)), axis=0)
+    true = np.empty((T, 2 * M, 3))
+    true[:, 0::2] = walk - 0.5 * axis + rng.normal(0, 0.01, (T, M, 3))
+    true[:, 1::2] = walk + 0.5 * axis + rng.normal(0, 0.01, (T, M, 3))
+    wrapped = np.mod(true, L).astype(np.float32)
+    split0 = np.any(np.abs(wrapped[0, 0::2] - wrapped[0, 1::2]) > 0.5 * L, axis=1)
+    assert split0.sum() >= 8
+    dims = np.array([*L, 90, 90, 90], dtype=np.float32)
+    resids = np.repeat(np.arange(M), 2)
+    bonds = np.stack((np.arange(0, 2 * M, 2), np.arange(1, 2 * M, 2)), axis=1)
+    half = M                                              # atoms of the first 20 dimers / the rest
+    kw = dict(temperature=300, groupings="residues", center=True, center_wrap=True, verbose=False)
+
+    def run(u, unwrap, route=None):
+        groups = [u.atoms[:half], u.atoms[half:]]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            o = Onsager(groups, unwrap=unwrap, **kw)
+            if route == "per_frame":
+                o = per_frame(o)
+            return o.run()
+
+    um = mdhelper_amd.ArrayUniverse(wrapped, dims, dt=1.0, masses=masses, resids=resids, bonds=bonds)
+    dev = run(um, True)
+    host = run(um, True, "per_frame")
+    assert dev._from_file and not host._from_file
+    path = tmp_path / "split.nc"
+    write_amber_netcdf(path, wrapped, L)
+    uf = mdhelper_amd.FileUniverse(path, dt=1.0, masses=masses, resids=resids, bonds=bonds)
+    fil = run(uf, True)
+    ut = mdhelper_amd.ArrayUniverse(true.astype(np.float32), dims, dt=1.0, masses=masses, resids=resids)
+    ref = run(ut, False, "per_frame")
+    nobond = run(mdhelper_amd.ArrayUniverse(wrapped, dims, dt=1.0, masses=masses, resids=resids), True)
+    for name in ("msd_self", "msd_cross"):
+        want = host.results[name]
+        scale = np.abs(want).max()
+        assert np.allclose(dev.results[name], want, rtol=1e-8, atol=1e-9 * scale), name
+        assert np.allclose(fil.results[name], want, rtol=1e-8, atol=1e-9 * scale), name
+        # float32 storage of wrapped vs never-wrapped coordinates: ~1e-6 A per coordinate
+        assert np.allclose(want, ref.results[name], rtol=2e-4, atol=2e-5 * scale), name
+    far = np.abs(nobond.results.msd_self - host.results.msd_self).max()
+    assert far > 1e-3 * np.abs(host.results.msd_self).max(), far
