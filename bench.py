@@ -343,11 +343,21 @@ def bench_rdf(args, world, wide=False):
     steps64 = st["pairs_computed"] / 64.0          # hot-loop trips: 64 distance evaluations each
     # this rank's own share of the reduced counts (weak scaling: every rank bins the same amount)
     binned_mine = binned / (1 if args.shard_fixed else world.world) * (F_mine / max(F, 1) if args.shard_fixed else 1.0)
-    celled = args.algo in ("auto", "cell")
+    celled = args.algo == "cell" or (args.algo == "auto" and N >= 1024)   # below 1 024: brute-force tiles
     # VALU / SALU / LDS instructions per hot-loop trip and the engine clock under this kernel come from
     # SQ counters of a separate rocprofv3 pass over the SAME sources (scripts/profile_counters.sh ->
     # profiles/counters.json); dropped (None) when the kernel sources have changed since
-    ctr = profiled("rdf_wide" if wide else "rdf_c2", *RDF_SOURCES) if (celled and N == 32768) else None
+    # (entries: C2(i), C2(ii), the C5 size, a C1-like small system; another size takes the entry measured at
+    # the nearest size on the same kernel and says so — the mix per trip moves by a few per cent with N)
+    ctr, ctr_atoms = None, None
+    if args.algo == "auto":
+        small = N < 1024                      # below that the auto path is the brute-force tile kernel
+        names = ["rdf_c1"] if small else (["rdf_wide"] if wide else ["rdf_c2", "rdf_c5"])
+        found = [(abs(np.log(e.get("atoms", 32768) / N)), e) for e in
+                 (profiled(n, *RDF_SOURCES) for n in names) if e]
+        if found:
+            ctr = min(found, key=lambda t: t[0])[1]
+            ctr_atoms = ctr.get("atoms", 32768)
     clock = st.get("clock_hz") or None
     valu = None
     if ctr and kernel_s > 0:
@@ -370,8 +380,9 @@ def bench_rdf(args, world, wide=False):
                 "salu_instructions_per_step": ctr.get("salu_per_step"),
                 "lds_instructions_per_step": ctr.get("lds_per_step"),
                 "valu_busy_fraction_of_simd_cycles": ctr.get("valu_busy_frac"),
-                "counters_source": ctr.get("source")}
-    traffic = ctr.get("hbm_bytes_per_frame") if ctr else None
+                "counters_source": ctr.get("source"),
+                "counters_measured_at_atoms": ctr_atoms}
+    traffic = ctr.get("hbm_bytes_per_frame") if (ctr and ctr_atoms == N) else None
     hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": achieved / HBM_PEAK_GBS,
            "traffic": traffic * F_mine * args.steps / launches if traffic else None,
@@ -388,6 +399,7 @@ def bench_rdf(args, world, wide=False):
         "traffic": hbm["traffic"],
         "kernel": "rdf_cell_pair_kernel" if celled else "rdf_tile_kernel",
         "kernel_ms_per_launch": st["kernel_ms"] / launches,
+        "launches": launches,
         "definition": "hot-loop trips/s (64 distance evaluations each, counted by the kernel) x VALU issue "
                       "cycles per trip (SQ_INSTS_VALU per trip from profiles/, 2 cycles per wave64 VALU "
                       "instruction on a SIMD-32, 4 for v_sqrt_f32: MI355X_MICROARCH.md) / (1024 SIMDs x "
@@ -565,9 +577,13 @@ def bench_sq(args, world):
     evals_rank = args.steps * F_mine * float(N) * len(q)
     alg = F_mine * (12 * N) + 24 * len(q)
     achieved = alg * args.steps / kernel_s / 1e9 if kernel_s > 0 else 0.0
-    # fp64 VALU bound: 4.5 v_fma_f64-class wave-instructions per 64 terms in the register-blocked column
-    # kernel; a wave64 fp64 FMA takes 4 cycles on a SIMD-32 (half the fp32 rate: 78.6 vs 157.3 TFLOP/s)
-    issue = evals_rank / max(kernel_s, 1e-9) / 64.0 * 4.5 * 4.0
+    # fp64 VALU bound: the kernel's fp64 wave-instructions per 64 terms (4.5 by construction in the
+    # register-blocked column kernel; the measured figure and the clock come from profiles/counters.json when
+    # it was taken on these sources); a wave64 fp64 instruction takes 4 cycles on a SIMD-32 (half the fp32
+    # rate: 78.6 vs 157.3 TFLOP/s)
+    sq_ctr = profiled("sq_c3", *SQ_SOURCES) if len(q) == 512 else None
+    fp64_per_64 = sq_ctr["fp64_per_64_terms"] if sq_ctr else 4.5
+    issue = evals_rank / max(kernel_s, 1e-9) / 64.0 * fp64_per_64 * 4.0
     out = {
         "metric": "exp(iq.r) evaluations/sec", "value": evals / dt, "unit": "evals/s",
         "n_gpus": world.world, "steps": args.steps, "warmup": args.warmup,
@@ -590,6 +606,12 @@ def bench_sq(args, world):
                                    "address arithmetic and the DVFS clock under fp64 load (~2.07 GHz measured) "
                                    "are what is left",
                      "evaluations_per_sec_kernel": evals_rank / max(kernel_s, 1e-9),
+                     "kernel_ms_per_step": st["kernel_ms"] / max(args.steps, 1),
+                     "fp64_instructions_per_64_terms": fp64_per_64,
+                     "valu_instructions_per_64_terms": sq_ctr.get("valu_per_64_terms") if sq_ctr else None,
+                     "clock_hz_under_this_kernel": sq_ctr.get("clock_hz") if sq_ctr else None,
+                     "frac_at_measured_clock": issue / (SIMDS * sq_ctr["clock_hz"]) if sq_ctr else None,
+                     "counters_source": sq_ctr.get("source") if sq_ctr else None,
                      "hbm": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_step": alg}},
         "checksum": float(ssf.sum()),

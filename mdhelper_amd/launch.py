@@ -98,6 +98,7 @@ class Rendezvous:
         self._server = None
         self._thread = None
         self._error = None
+        self._timeout = float(timeout)
         if self.rank == 0:
             self._server = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
             self._server.bind(self._addr)
@@ -125,12 +126,34 @@ class Rendezvous:
     def _serve(self):
         conns = [None] * self.world
         try:
-            for _ in range(self.world):
-                c, _addr = self._server.accept()
+            # every rank has to show up before the constructor's deadline (a rank that died on its way
+            # must not leave rank 0 blocked in accept), and only processes of this user are let in: an
+            # abstract socket has no file permissions, the peer's credentials stand in for them
+            deadline = time.monotonic() + self._timeout
+            missing = self.world
+            while missing:
+                left = deadline - time.monotonic()
+                if left <= 0:
+                    raise TimeoutError(f"{missing} of {self.world} ranks did not reach the rendezvous "
+                                       f"within {self._timeout:.0f} s")
+                self._server.settimeout(left)
+                try:
+                    c, _addr = self._server.accept()
+                except socket.timeout:
+                    continue
+                _pid, uid, _gid = struct.unpack("3i", c.getsockopt(socket.SOL_SOCKET, socket.SO_PEERCRED,
+                                                                  struct.calcsize("3i")))
+                if uid != os.getuid():
+                    c.close()                # not ours: the slot stays open
+                    continue
+                c.settimeout(self._timeout)
                 (r,) = struct.unpack("<I", _recv_exact(c, 4))
                 if not 0 <= r < self.world or conns[r] is not None:
                     raise ValueError(f"unexpected rank {r} at the rendezvous")
                 conns[r] = c
+                missing -= 1
+            for c in conns:
+                c.settimeout(None)           # collectives wait as long as the slowest rank computes
             while True:
                 frames = []
                 for c in conns:
@@ -156,8 +179,17 @@ class Rendezvous:
     def _exchange(self, op, payload):
         if self._error is not None:
             raise RuntimeError(f"rendezvous service failed: {self._error}")
-        _send_frame(self._sock, op, payload)
-        rop, out = _recv_frame(self._sock)
+        try:
+            _send_frame(self._sock, op, payload)
+            rop, out = _recv_frame(self._sock)
+        except (ConnectionError, OSError) as exc:
+            # the service closes every connection when it fails: rank 0 reports WHY it did (its own
+            # socket sees the EOF first), the other ranks the lost connection
+            if self._thread is not None:
+                self._thread.join(timeout=2)
+            if self._error is not None:
+                raise RuntimeError(f"rendezvous service failed: {self._error}") from exc
+            raise
         assert rop == op
         return out
 

@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (source_digest only; nothing touches the GPU in this process)
 
+ROUND = os.environ.get("MDX_ROUND", "r03")
 OUT = os.path.join(ROOT, "gpurun_out", "counters")
 os.makedirs(OUT, exist_ok=True)
 ENV = dict(os.environ, TMPDIR="/tmp")
@@ -79,45 +80,105 @@ def pick(res, needle):
     raise SystemExit(f"no kernel matching {needle}")
 
 
-def rdf_entry(tag, workload, frames):
+def rdf_entry(tag, workload, frames, atoms=None):
+    """SQ instruction mix per hot-loop trip (64 distance evaluations), clock, LDS figures and HBM traffic of
+    the RDF kernels of one bench configuration.  The dominant kernel is the cell-sorted pair kernel, or the
+    brute-force tile kernel for systems below 1 024 particles (C1-like)."""
     args = ["--workload", workload, "--frames", str(frames), "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
-            "--no-extras"]
+            "--no-extras"] + (["--atoms", str(atoms)] if atoms else [])
     out = {}
     line, res, calls, dur = run_pmc(tag, ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH"], args)
-    k = pick(res, "rdf_cell_pair_kernel")
+    needle = "rdf_cell_pair_kernel" if any("rdf_cell_pair_kernel" in k for k in res) else "rdf_tile_kernel"
+    k = pick(res, needle)
     evals = line["roofline"]["work"]["distance_evaluations_per_sec_kernel"] * line["roofline"]["kernel_ms_per_launch"] \
-        * 1e-3 * len(calls[k])
+        * 1e-3 * max(1, line["roofline"].get("launches", 1))
     steps = evals / 64.0
     valu = res[k]["SQ_INSTS_VALU"] / steps
-    out.update(valu_per_step=valu, valu_trans_per_step=1.0, valu_plain_per_step=valu - 1.0,
+    out.update(kernel=needle, valu_per_step=valu,
                salu_per_step=res[k]["SQ_INSTS_SALU"] / steps, lds_per_step=res[k]["SQ_INSTS_LDS"] / steps,
                branch_per_step=res[k]["SQ_INSTS_BRANCH"] / steps, steps_per_frame=steps / frames)
-    line, res, calls, dur = run_pmc(tag, ["GRBM_GUI_ACTIVE", "SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES"], args)
-    k = pick(res, "rdf_cell_pair_kernel")
+    line, res, calls, dur = run_pmc(tag, ["GRBM_GUI_ACTIVE", "SQ_WAVES", "SQ_INSTS_VALU_TRANS_F32", "SQ_WAVE_CYCLES"], args)
+    k = pick(res, needle)
+    trans = res[k]["SQ_INSTS_VALU_TRANS_F32"] / steps
     out.update(clock_hz=res[k]["GRBM_GUI_ACTIVE"] / 8.0 / dur[k] * 1e9,          # summed over the 8 XCDs
-               waves_per_simd=res[k]["SQ_WAVE_CYCLES"] * 4.0 / (1024.0 * res[k]["GRBM_GUI_ACTIVE"] / 8.0) / 4.0 * 4.0)
+               waves_per_simd=res[k]["SQ_WAVE_CYCLES"] * 4.0 / (1024.0 * res[k]["GRBM_GUI_ACTIVE"] / 8.0) / 4.0 * 4.0,
+               valu_trans_per_step=trans, valu_plain_per_step=valu - trans)
     line, res, calls, dur = run_pmc(tag, ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_LDS",
                                           "SQ_WAIT_INST_LDS"], args)
-    k = pick(res, "rdf_cell_pair_kernel")
+    k = pick(res, needle)
     out.update(lds_bank_conflict_cycles_per_step=res[k]["SQ_LDS_BANK_CONFLICT"] / steps,
                lds_idx_active_cycles_per_step=res[k]["SQ_LDS_IDX_ACTIVE"] / steps,
                lds_wait_quadcycles_per_step=res[k]["SQ_WAIT_INST_LDS"] / steps)
-    fetch = write = 0.0
+    # HBM traffic of EVERY RDF kernel of the step (sort / pack + pair), per frame
+    per_kernel = collections.defaultdict(float)
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         line, res, calls, dur = run_pmc(tag, [ctr], args)
-        k = pick(res, "rdf_cell_pair_kernel")
-        if ctr == "FETCH_SIZE":
-            fetch = res[k][ctr] * 1024.0
-        else:
-            write = res[k][ctr] * 1024.0
-    # gfx950: FETCH_SIZE reports half of a wide coalesced read stream -> doubled; WRITE_SIZE exact
-    out.update(hbm_bytes_per_frame=(2.0 * fetch + write) / frames,
-               traffic_source=f"profiles/r02_{tag}_FETCH_SIZE_pmc.csv + r02_{tag}_WRITE_SIZE_pmc.csv "
-                              f"(separate passes, FETCH doubled per MI355X_MICROARCH.md)",
-               source=f"profiles/r02_{tag}_SQ_INSTS_VALU_SQ_INSTS_SALU_SQ_INSTS_LDS_pmc.csv, "
+        for kk in res:
+            if "rdf_" in kk:
+                # gfx950: FETCH_SIZE reports half of a wide coalesced read stream -> doubled; WRITE_SIZE exact
+                per_kernel[kk.split("(")[0][-40:]] += res[kk][ctr] * 1024.0 * (2.0 if ctr == "FETCH_SIZE" else 1.0) / frames
+    out.update(hbm_bytes_per_frame=sum(per_kernel.values()),
+               hbm_bytes_per_frame_by_kernel=dict(per_kernel),
+               traffic_source=f"profiles/{ROUND}_{tag}_FETCH_SIZE_pmc.csv + {ROUND}_{tag}_WRITE_SIZE_pmc.csv "
+                              f"(separate passes, FETCH doubled per MI355X_MICROARCH.md; sort + pair kernels)",
+               source=f"profiles/{ROUND}_{tag}_SQ_INSTS_VALU_SQ_INSTS_SALU_SQ_INSTS_LDS_pmc.csv, "
                       f"{frames} frames, scripts/make_counters.py",
+               atoms=atoms or 32768,
                source_digest=bench.source_digest(*bench.RDF_SOURCES))
     return out
+
+
+def sq_entry(tag):
+    """fp64 instruction mix of the S(q) kernel per 64 phase terms, and the clock it ran at."""
+    args = ["--workload", "sq", "--steps", "2", "--warmup", "0", "--no-cpu-baseline"]
+    line, res, calls, dur = run_pmc(tag, ["SQ_INSTS_VALU", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64",
+                                          "SQ_INSTS_VALU_ADD_F64"], args)
+    k = pick(res, "sq_rho_quads_kernel")
+    terms64 = line["roofline"]["evaluations_per_sec_kernel"] * line["roofline"]["kernel_ms_per_step"] * 1e-3 \
+        * line["steps"] / 64.0
+    out = dict(valu_per_64_terms=res[k]["SQ_INSTS_VALU"] / terms64,
+               fp64_per_64_terms=(res[k]["SQ_INSTS_VALU_FMA_F64"] + res[k]["SQ_INSTS_VALU_MUL_F64"]
+                                  + res[k]["SQ_INSTS_VALU_ADD_F64"]) / terms64,
+               kernel_share_of_step=dur[k] / max(sum(dur.values()), 1.0))
+    line, res, calls, dur = run_pmc(tag, ["GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS"], args)
+    k = pick(res, "sq_rho_quads_kernel")
+    out.update(clock_hz=res[k]["GRBM_GUI_ACTIVE"] / 8.0 / dur[k] * 1e9,
+               lds_per_64_terms=res[k]["SQ_INSTS_LDS"] / terms64,
+               source=f"profiles/{ROUND}_{tag}_SQ_INSTS_VALU_SQ_INSTS_VALU_FMA_F64_SQ_INST_pmc.csv, scripts/make_counters.py",
+               source_digest=bench.source_digest(*bench.SQ_SOURCES))
+    return out
+
+
+# What the MSD passes ask of the memory system (VERDICT r2 item 3: a counter that names the cause): request sizes
+# and stalls at the L2 <-> fabric interface, L2 hit rate, queue depths.  Separate passes; per kernel sums.
+MSD_TCC_PASSES = (
+    ["TCC_EA0_RDREQ", "TCC_EA0_RDREQ_32B", "TCC_EA0_RDREQ_64B", "TCC_EA0_RDREQ_128B"],
+    ["TCC_EA0_WRREQ", "TCC_EA0_WRREQ_64B", "TCC_EA0_WRREQ_STALL", "TCC_TOO_MANY_EA_WRREQS_STALL"],
+    ["TCC_EA0_RDREQ_DRAM_CREDIT_STALL", "TCC_EA0_WRREQ_DRAM_CREDIT_STALL", "TCC_EA0_RDREQ_LEVEL", "TCC_EA0_WRREQ_LEVEL"],
+    ["TCC_HIT", "TCC_MISS", "TCC_TAG_STALL", "TCC_BUSY"],
+    ["TCC_CYCLE", "TCC_REQ", "TCP_PENDING_STALL_CYCLES", "TCP_TCR_TCP_STALL_CYCLES"],
+)
+
+
+def msd_tcc(tag):
+    args = ["--workload", "msd", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    table = collections.defaultdict(dict)
+    for ctrs in MSD_TCC_PASSES:
+        try:
+            line, res, calls, dur = run_pmc(tag + "_tcc", ctrs, args)
+        except SystemExit as exc:          # a counter this build of rocprofv3 refuses: keep the other passes
+            sys.stderr.write(f"{ctrs}: {exc}\n")
+            continue
+        for k in res:
+            if "msd" in k:
+                name = k.split("(")[0][-48:]
+                table[name]["dispatches"] = len(calls[k])
+                table[name]["duration_ms"] = dur[k] / 1e6
+                for c in ctrs:
+                    table[name][c] = res[k][c]
+    with open(os.path.join(OUT, f"{tag}_tcc_summary.json"), "w") as fh:
+        json.dump(table, fh, indent=1, sort_keys=True)
+    return table
 
 
 def msd_entry(tag):
@@ -133,31 +194,45 @@ def msd_entry(tag):
                 total += v
                 per_kernel[k[:60] + ":" + ctr] = v
     return dict(hbm_bytes_per_step=total, per_kernel_bytes_per_step=per_kernel,
-                traffic_source=f"profiles/r02_{tag}_FETCH_SIZE_pmc.csv + r02_{tag}_WRITE_SIZE_pmc.csv (separate passes, "
+                traffic_source=f"profiles/{ROUND}_{tag}_FETCH_SIZE_pmc.csv + {ROUND}_{tag}_WRITE_SIZE_pmc.csv (separate passes, "
                                f"FETCH doubled per MI355X_MICROARCH.md)",
                 source_digest=bench.source_digest(*bench.MSD_SOURCES))
 
 
 def main():
-    which = sys.argv[1:] or ["rdf_c2", "rdf_wide", "msd_c4", "stats"]
+    which = sys.argv[1:] or ["rdf_c2", "rdf_wide", "rdf_c5", "rdf_c1", "sq_c3", "msd_c4", "msd_tcc", "stats"]
     path = os.path.join(OUT, "counters.json")
     data = {}
     if os.path.exists(os.path.join(ROOT, "profiles", "counters.json")):
         with open(os.path.join(ROOT, "profiles", "counters.json")) as fh:
             data = json.load(fh)
+    if os.path.exists(path):                       # entries of an earlier call of this script on this box
+        with open(path) as fh:
+            data.update(json.load(fh))
     if "rdf_c2" in which:
         data["rdf_c2"] = rdf_entry("rdf_c2", "rdf", 2000)
     if "rdf_wide" in which:
         data["rdf_wide"] = rdf_entry("rdf_wide", "rdf_wide", 400)
+    if "rdf_c5" in which:                          # C5 size on one GPU
+        data["rdf_c5"] = rdf_entry("rdf_c5", "rdf", 250, atoms=131072)
+    if "rdf_c1" in which:                          # C1-like: 1 000 atoms, range (0, L/2): the brute-force tile kernel
+        data["rdf_c1"] = rdf_entry("rdf_c1", "rdf_wide", 20000, atoms=1000)
+    if "sq_c3" in which:
+        data["sq_c3"] = sq_entry("sq_c3")
     if "msd_c4" in which:
         data["msd_c4"] = msd_entry("msd_c4")
+    with open(path, "w") as fh:
+        json.dump(data, fh, indent=1, sort_keys=True)
+    if "msd_tcc" in which:
+        msd_tcc("msd_c4")
     if "stats" in which:
         run_stats("rdf_c2", ["--frames", "2000", "--steps", "4", "--no-cpu-baseline", "--no-extras"])
         run_stats("rdf_wide", ["--workload", "rdf_wide", "--frames", "500", "--steps", "2", "--no-cpu-baseline"])
+        run_stats("rdf_c5", ["--atoms", "131072", "--frames", "500", "--steps", "2", "--no-cpu-baseline", "--no-extras"])
         run_stats("msd_c4", ["--workload", "msd", "--steps", "3", "--no-cpu-baseline"])
         run_stats("sq_c3", ["--workload", "sq", "--steps", "5", "--no-cpu-baseline"])
-    with open(path, "w") as fh:
-        json.dump(data, fh, indent=1, sort_keys=True)
+        run_stats("sq_default_grid", ["--workload", "sq", "--n-points", "32", "--frames", "200", "--steps", "3",
+                                      "--no-cpu-baseline"])
     print(json.dumps(data, indent=1, sort_keys=True))
 
 

@@ -79,3 +79,43 @@ def test_rendezvous_under_torch_distributed_run():
     from mdhelper_amd import launch
     res = launch.last_json_line(out.stdout)
     assert res["uid_ok"] and res["ints"] == (np.arange(5) * 3).tolist() and res["names"] == "r0;r1;"
+
+
+def test_rendezvous_does_not_wait_forever_for_a_rank_that_never_came():
+    """A rank that died before connecting must not leave rank 0 blocked in accept(): the service gives
+    up at the constructor's deadline and rank 0's next collective says why."""
+    import os
+    import time
+    from mdhelper_amd.launch import Rendezvous
+    r0 = Rendezvous(0, 2, key=f"test-missing-{os.getpid()}", timeout=1.0)
+    time.sleep(1.3)
+    with pytest.raises(RuntimeError, match="did not reach the rendezvous"):
+        r0.barrier()
+    r0.close()
+
+
+def test_rendezvous_reports_the_service_error_on_rank_zero():
+    """Ranks entering different collectives: the service fails and closes every connection; rank 0 —
+    whose own socket sees the EOF first — reports the stored reason, not a bare ConnectionError."""
+    import os
+    import threading
+    from mdhelper_amd.launch import Rendezvous
+    key = f"test-mismatch-{os.getpid()}"
+    out = {}
+
+    def rank1():
+        r1 = Rendezvous(1, 2, key=key, timeout=20.0)
+        try:
+            r1.allreduce(np.arange(3, dtype=np.int64))
+        except Exception as exc:           # EOF or reset: the service went away
+            out["r1"] = exc
+        r1.close()
+
+    r0 = Rendezvous(0, 2, key=key, timeout=20.0)
+    t = threading.Thread(target=rank1)
+    t.start()
+    with pytest.raises(RuntimeError, match="different collectives"):
+        r0.barrier()
+    t.join(timeout=20)
+    assert isinstance(out.get("r1"), (ConnectionError, OSError))
+    r0.close()
