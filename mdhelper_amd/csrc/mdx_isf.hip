@@ -323,7 +323,7 @@ static int isf_accumulate(mdx_isf *h, int64_t n, int64_t n_frames, Source source
                 dst = h->d_rho_parts.as<double2>();
             }
             if (h->quads)
-                hipLaunchKernelGGL(sq_rho_quads_kernel, dim3(rblocks, h->n_groups * rs, (unsigned)nf),
+                hipLaunchKernelGGL(sq_rho_quads_pick(h->quad.regular_stride), dim3(rblocks, h->n_groups * rs, (unsigned)nf),
                                    dim3(SQ_QUAD_THREADS), h->quad.lds, h->stream, d_new, n,
                                    h->d_qitems.as<SqQuadItem>(), h->quad.n_items, h->quad.items_p2,
                                    h->quad.n_sub, (int)h->n_q, h->quad.lat, h->d_offsets.as<int64_t>(),
@@ -365,7 +365,7 @@ static int isf_accumulate(mdx_isf *h, int64_t n, int64_t n_frames, Source source
                        max_range / (n_split * 2) >= 4 * h->quad.lat.tile)
                     n_split *= 2;
                 MDX_TRY(h->d_part.ensure(size_t(8) * n_out * n_split));
-                hipLaunchKernelGGL(isf_incoherent_quads_kernel,
+                hipLaunchKernelGGL(isf_incoherent_quads_pick(h->quad.regular_stride),
                                    dim3(iblocks, h->n_slots * n_split, h->n_lags), dim3(SQ_QUAD_THREADS),
                                    h->quad.lds, h->stream, h->d_pos_ring.as<float>(), h->ring_slots, n,
                                    h->d_qitems.as<SqQuadItem>(), h->quad.n_items, h->quad.items_p2,
@@ -543,10 +543,10 @@ int mdx_isf_create(mdx_isf_t *out, int dev, const double *wavevectors, int64_t n
                 if ((rc = h->d_qitems.ensure(sizeof(SqQuadItem) * qitems.size())) != MDX_OK) break;
                 if (hipMemcpy(h->d_qitems.ptr, qitems.data(), sizeof(SqQuadItem) * qitems.size(),
                               hipMemcpyHostToDevice) != hipSuccess ||
-                    hipFuncSetAttribute(reinterpret_cast<const void *>(isf_incoherent_quads_kernel),
+                    hipFuncSetAttribute(reinterpret_cast<const void *>(isf_incoherent_quads_pick(h->quad.regular_stride)),
                                         hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)h->quad.lds) != hipSuccess ||
-                    hipFuncSetAttribute(reinterpret_cast<const void *>(sq_rho_quads_kernel),
+                    hipFuncSetAttribute(reinterpret_cast<const void *>(sq_rho_quads_pick(h->quad.regular_stride)),
                                         hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)h->quad.lds) != hipSuccess) {
                     rc = fail(MDX_ERR_HIP, "quad table setup failed");

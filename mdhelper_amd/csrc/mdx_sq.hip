@@ -140,6 +140,7 @@ struct mdx_sq {
     int n_qitems = 0, items_p2 = 0, n_sub = 1;
     SqLattice quad_lat{};
     size_t quad_lds = 0;
+    int quad_regular = 0;        // row stride of the regular-item form of the quad kernel, 0: general items
     DeviceBuffer d_qitems;
     bool columns = false;
     int n_items = 0, col_threads = 0;
@@ -193,7 +194,7 @@ static int sq_accumulate_points(mdx_sq *h, const float *d_pos, int64_t n, int64_
     for (int64_t f0 = 0; f0 < n_frames; f0 += slab) {
         const int64_t nf = std::min(slab, n_frames - f0);
         if (h->quads)
-            hipLaunchKernelGGL(sq_rho_quads_kernel, dim3(qblocks, h->n_groups * n_split, (unsigned)nf),
+            hipLaunchKernelGGL(sq_rho_quads_pick(h->quad_regular), dim3(qblocks, h->n_groups * n_split, (unsigned)nf),
                                dim3(SQ_QUAD_THREADS), h->quad_lds, h->stream, d_pos + f0 * n * 3, n,
                                h->d_qitems.as<SqQuadItem>(), h->n_qitems, h->items_p2, h->n_sub,
                                (int)h->n_q, h->quad_lat, h->d_offsets.as<int64_t>(), h->n_groups,
@@ -291,10 +292,11 @@ int mdx_sq_create(mdx_sq_t *out, int dev, const double *wavevectors, int64_t n_q
                 h->n_sub = shape.n_sub;
                 h->quad_lat = shape.lat;
                 h->quad_lds = shape.lds;
+                h->quad_regular = shape.regular_stride;
                 if ((rc = h->d_qitems.ensure(sizeof(SqQuadItem) * qitems.size())) != MDX_OK) break;
                 if (hipMemcpy(h->d_qitems.ptr, qitems.data(), sizeof(SqQuadItem) * qitems.size(),
                               hipMemcpyHostToDevice) != hipSuccess ||
-                    hipFuncSetAttribute(reinterpret_cast<const void *>(sq_rho_quads_kernel),
+                    hipFuncSetAttribute(reinterpret_cast<const void *>(sq_rho_quads_pick(shape.regular_stride)),
                                         hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)h->quad_lds) != hipSuccess) {
                     rc = fail(MDX_ERR_HIP, "quad table setup failed");

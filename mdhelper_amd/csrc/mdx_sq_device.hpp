@@ -350,7 +350,13 @@ __device__ __forceinline__ SqQuadThread sq_quad_thread(const SqQuadItem *items, 
 
 // Particles [lo, hi) of one frame (or of one pair of frames: Pprev) into the thread's 4 x 8
 // accumulators; REAL_ONLY keeps Re(E_x E_y E_z) only (two FMAs per term).  Ends on a barrier.
-template <bool REAL_ONLY>
+// RS > 0: every item is REGULAR — its four columns share m_x and have consecutive m_y, its eight m_z are
+// consecutive — and the table rows are RS entries apart (a compile-time constant: tile + SQ_QUAD_PAD).  A thread
+// then reads ONE e_x, four e_y and eight e_z per particle, the latter two at immediate offsets c * RS * 16 from
+// one address each: 13 LDS reads and three address registers where the general form has 16 and 16 (the address
+// arithmetic was 0.5 of the 6.3 VALU instructions per 64 terms, the reads 0.5 per term).  Full grids — the
+// reference's default wavevector sets, structure.py:1376-1381 — are regular; anything else takes RS = 0.
+template <bool REAL_ONLY, int RS>
 __device__ __forceinline__ void sq_quad_frame(double2 *lat_tab, const SqLattice &lat,
                                               const SqQuadThread &t, const float *P, const float *Pprev,
                                               int64_t lo, int64_t hi, double (&ar)[SQ_QCOLS][SQ_ZPT],
@@ -377,6 +383,46 @@ __device__ __forceinline__ void sq_quad_frame(double2 *lat_tab, const SqLattice 
         // otherwise waits for every read right after issuing it).  The read past a thread's
         // last particle stays inside the allocation and is discarded.
         const int ib0 = cur * t.set_len * 16;
+        if constexpr (RS > 0) {
+            constexpr int ROW = RS * 16;   // bytes between the table rows of m and m + 1
+            int px = t.o0[0] + ib0, py = t.o1[0] + ib0, pz = t.oz[0] + ib0;
+            double2 ex = at(px, 0), ey[SQ_QCOLS];
+#pragma unroll
+            for (int c = 0; c < SQ_QCOLS; ++c)
+                ey[c] = at(py, c * ROW);
+#pragma unroll 1
+            for (int i = 0; i < mine; ++i) {
+                double tr[SQ_QCOLS], ti[SQ_QCOLS];
+#pragma unroll
+                for (int c = 0; c < SQ_QCOLS; ++c) {
+                    tr[c] = fma(ex.x, ey[c].x, -ex.y * ey[c].y);
+                    ti[c] = fma(ex.x, ey[c].y, ex.y * ey[c].x);
+                }
+                double2 ez = at(pz, 0);
+                px += 16;
+                py += 16;
+                ex = at(px, 0);
+#pragma unroll
+                for (int c = 0; c < SQ_QCOLS; ++c)
+                    ey[c] = at(py, c * ROW);
+#pragma unroll
+                for (int j = 0; j < SQ_ZPT; ++j) {
+                    double2 ezn = ez;
+                    if (j + 1 < SQ_ZPT)
+                        ezn = at(pz, (j + 1) * ROW);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int c = 0; c < SQ_QCOLS; ++c) {
+                        ar[c][j] = fma(tr[c], ez.x, fma(-ti[c], ez.y, ar[c][j]));
+                        if (!REAL_ONLY)
+                            ai[c][j] = fma(tr[c], ez.y, fma(ti[c], ez.x, ai[c][j]));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    ez = ezn;
+                }
+                pz += 16;
+            }
+        } else {
         double2 ex[SQ_QCOLS], ey[SQ_QCOLS];
 #pragma unroll
         for (int c = 0; c < SQ_QCOLS; ++c) {
@@ -413,6 +459,7 @@ __device__ __forceinline__ void sq_quad_frame(double2 *lat_tab, const SqLattice 
                 __builtin_amdgcn_sched_barrier(0);
                 ez = ezn;
             }
+        }
         }
         __syncthreads();
     }
@@ -465,6 +512,7 @@ __device__ __forceinline__ void sq_quad_store(double2 *lat_tab, const SqQuadThre
     }
 }
 
+template <int RS>
 __global__ __launch_bounds__(SQ_QUAD_THREADS, 2) void sq_rho_quads_kernel(
     const float *__restrict__ pos, int64_t n_atoms, const SqQuadItem *__restrict__ items,
     int n_items, int items_p2, int n_sub, int n_q, SqLattice lat,
@@ -483,7 +531,7 @@ __global__ __launch_bounds__(SQ_QUAD_THREADS, 2) void sq_rho_quads_kernel(
     const int64_t g_lo = group_offsets[g], g_hi = group_offsets[g + 1];
     const int64_t per = (g_hi - g_lo + n_split - 1) / n_split;
     const int64_t lo = g_lo + sp * per, hi = min(g_hi, lo + per);
-    sq_quad_frame<false>(lat_tab, lat, t, pos + int64_t(frame) * n_atoms * 3, nullptr, lo, hi, ar, ai);
+    sq_quad_frame<false, RS>(lat_tab, lat, t, pos + int64_t(frame) * n_atoms * 3, nullptr, lo, hi, ar, ai);
     sq_quad_store<false>(lat_tab, t, items, n_items, items_p2, n_sub, ar, ai,
                          rho + ((int64_t(frame) * n_groups + g) * n_split + sp) * n_q, nullptr);
 }
@@ -491,6 +539,7 @@ __global__ __launch_bounds__(SQ_QUAD_THREADS, 2) void sq_rho_quads_kernel(
 // Incoherent ISF through the same blocking: part[split][lag][slot][q] = sum over the block's new
 // frames f >= lag and the slot's particles of cos q.(r(f) - r(f - lag)) — only the real part of
 // E_x E_y E_z is accumulated, two FMAs per term.  grid (item blocks, slots x splits, lags).
+template <int RS>
 __global__ __launch_bounds__(SQ_QUAD_THREADS, 2) void isf_incoherent_quads_kernel(
     const float *__restrict__ pos_ring, int ring_slots, int64_t n_atoms,
     const SqQuadItem *__restrict__ items, int n_items, int items_p2, int n_sub, int n_q,
@@ -514,11 +563,36 @@ __global__ __launch_bounds__(SQ_QUAD_THREADS, 2) void isf_incoherent_quads_kerne
         const long long f = f_first + i;
         if (f < lag)
             continue;
-        sq_quad_frame<true>(lat_tab, lat, t, pos_ring + int64_t(f % ring_slots) * n_atoms * 3,
+        sq_quad_frame<true, RS>(lat_tab, lat, t, pos_ring + int64_t(f % ring_slots) * n_atoms * 3,
                             pos_ring + int64_t((f - lag) % ring_slots) * n_atoms * 3, lo, hi, ar, ai);
     }
     sq_quad_store<true>(lat_tab, t, items, n_items, items_p2, n_sub, ar, ai, nullptr,
                         part + ((int64_t(sp) * n_lags + lag) * n_slots + slot) * n_q);
+}
+
+// The instantiated row strides (tile + SQ_QUAD_PAD) of the regular form; 0 = general items.
+#define MDX_SQ_QUAD_STRIDES(X) X(17) X(33) X(49) X(65) X(81) X(97) X(129)
+using SqRhoQuadsFn = void (*)(const float *, int64_t, const SqQuadItem *, int, int, int, int, SqLattice,
+                              const int64_t *, int, int, double2 *);
+using IsfIncQuadsFn = void (*)(const float *, int, int64_t, const SqQuadItem *, int, int, int, int, SqLattice,
+                               const int64_t *, int, int, int, long long, int, double *);
+inline SqRhoQuadsFn sq_rho_quads_pick(int regular_stride)
+{
+    switch (regular_stride) {
+#define MDX_CASE(S) case S: return sq_rho_quads_kernel<S>;
+        MDX_SQ_QUAD_STRIDES(MDX_CASE)
+#undef MDX_CASE
+    default: return sq_rho_quads_kernel<0>;
+    }
+}
+inline IsfIncQuadsFn isf_incoherent_quads_pick(int regular_stride)
+{
+    switch (regular_stride) {
+#define MDX_CASE(S) case S: return isf_incoherent_quads_kernel<S>;
+        MDX_SQ_QUAD_STRIDES(MDX_CASE)
+#undef MDX_CASE
+    default: return isf_incoherent_quads_kernel<0>;
+    }
 }
 
 // Host: quad items of a detected lattice set.  Columns are cut into chunks of SQ_ZPT consecutive
@@ -583,11 +657,31 @@ inline bool sq_build_quads(const std::vector<short> &trip, int64_t n_q, const Sq
     return !items.empty() && double(n_q) >= 0.6 * double(items.size()) * SQ_QCOLS * SQ_ZPT;
 }
 
+// Host: true when every item is regular — four columns of one m_x and consecutive m_y, eight consecutive m_z,
+// every entry a wavevector of the set (full grids).
+inline bool sq_quads_regular(const std::vector<SqQuadItem> &items)
+{
+    for (const SqQuadItem &it : items) {
+        for (int c = 0; c < SQ_QCOLS; ++c) {
+            if (it.i0[c] != it.i0[0] || it.i1[c] != it.i1[0] + c)
+                return false;
+            for (int z = 0; z < SQ_ZPT; ++z)
+                if (it.q[c][z] < 0)
+                    return false;
+        }
+        for (int z = 0; z < SQ_ZPT; ++z)
+            if (it.z[z] != it.z[0] + z)
+                return false;
+    }
+    return !items.empty();
+}
+
 // Host: launch shape of the quad kernels for a lattice set — items, copies per item (threads of a
 // block beyond the item count), table tile (two blocks per CU, two table sets per block: ~36 KB per
 // set, a multiple of the copies) and dynamic LDS.  false: the set does not suit the quad form.
 struct SqQuadShape {
     int n_items = 0, items_p2 = 0, n_sub = 1;
+    int regular_stride = 0;   // > 0: every item is regular and the table rows are this many entries apart
     SqLattice lat{};
     size_t lds = 0;
     int blocks() const { return (int)((int64_t(items_p2) * n_sub + SQ_QUAD_THREADS - 1) / SQ_QUAD_THREADS); }
@@ -610,9 +704,20 @@ inline bool sq_quad_plan(const std::vector<short> &trip, int64_t n_q, const SqLa
     const size_t fit = size_t(36) * 1024 / (size_t(16) * total_r);
     if (fit <= size_t(SQ_QUAD_PAD))
         return false;
-    const int tile = (int)(std::min<size_t>(512, fit - SQ_QUAD_PAD) / unit * unit);
+    int tile = (int)(std::min<size_t>(512, fit - SQ_QUAD_PAD) / unit * unit);
     if (tile < 16)
         return false;
+    // regular items (sq_quad_frame, RS > 0): the row stride is a template argument, so the tile is taken from
+    // the instantiated sizes — the largest one that fits and that the copies of an item divide
+    sh.regular_stride = 0;
+    if (sq_quads_regular(items) && !getenv("MDX_SQ_NO_REGULAR")) {
+        for (int cand : {128, 96, 80, 64, 48, 32, 16})
+            if (cand <= tile && cand % unit == 0) {
+                tile = cand;
+                sh.regular_stride = cand + SQ_QUAD_PAD;
+                break;
+            }
+    }
     sh.lat = base;
     sh.lat.tile = tile;
     sh.lds = std::max<size_t>(size_t(32) * (tile + SQ_QUAD_PAD) * total_r + 256, size_t(32) * 1024);
