@@ -795,8 +795,13 @@ __global__ __launch_bounds__(256, TRI ? 4 : 7) void rdf_cell_pair_kernel(CellArg
     {
         const auto *A = cell_args();
         const float4 *PW1 = A->pw1 + int64_t(frame) * A->n1p + int64_t(I) * 128;
-        p0 = PW1[lane];
-        p1 = PW1[64 + lane];
+        // (the lane's byte offset is formed here, per item: hoisted out of the item loop as a 64-bit value it was
+        // spilled to scratch and reloaded — and written back — once per item: 4 KB of scratch traffic per item,
+        // a sixth of what the kernel moved through HBM)
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        p0 = PW1[l];
+        p1 = PW1[64 + l];
     }
     const unsigned i_base0 = unsigned(I) * 128u;   // wave-uniform; + lane = this lane's i index
     const unsigned i_idx0 = i_base0 + unsigned(lane);

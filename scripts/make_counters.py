@@ -226,6 +226,8 @@ def main():
     if "msd_tcc" in which:
         msd_tcc("msd_c4")
     if "stats" in which:
+        # the default command itself (what the driver runs): its kernel averages must agree with the line's own
+        run_stats("bench_default", ["--no-extras", "--cpu-seconds", "2"])
         run_stats("rdf_c2", ["--frames", "2000", "--steps", "4", "--no-cpu-baseline", "--no-extras"])
         run_stats("rdf_wide", ["--workload", "rdf_wide", "--frames", "500", "--steps", "2", "--no-cpu-baseline"])
         run_stats("rdf_c5", ["--atoms", "131072", "--frames", "500", "--steps", "2", "--no-cpu-baseline", "--no-extras"])
