@@ -365,6 +365,9 @@ struct mdx_rdf {
     DeviceBuffer d_thresh, d_counts, d_total, d_pack1, d_pack2, d_misc, d_tri;
     DeviceBuffer d_stats;   // RDF_STAT_SHARDS x RDF_STAT_STRIDE 64-bit words (mdx_rdf_device.hpp)
     DeviceBuffer d_work;    // work counters of the persistent pair kernel (one line per XCD)
+    const void *occ_kernel = nullptr;   // occupancy of the persistent pair kernel: last kernel / LDS size asked for
+    size_t occ_lds = 0;
+    int64_t occ_blocks_per_xcd = 1;
     // what mdx_rdf_debug_sorted needs to find the most recent slab: its set of sorted copies, whether the
     // sorted originals were materialised, its frame count
     size_t last_offset = 0;   // float4 elements from the start of d_pw1 / d_po1 to the slab
@@ -519,12 +522,16 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
     else if (lower) MDX_CELL_PICK(false, true);
     else MDX_CELL_PICK(false, false);
 #undef MDX_CELL_PICK
-    // resident blocks per XCD (32 CUs each) of this kernel at this LDS size
-    int per_cu = 0;
-    MDX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), 256, lds));
-    hipDeviceProp_t prop;
-    MDX_HIP(hipGetDeviceProperties(&prop, h->dev));
-    const int64_t blocks_per_xcd = std::max<int64_t>(1, int64_t(std::max(per_cu, 1)) * prop.multiProcessorCount / 8);
+    // resident blocks per XCD (32 CUs each) of this kernel at this LDS size (asked once per kernel and size)
+    if (h->occ_kernel != reinterpret_cast<const void *>(kern) || h->occ_lds != lds) {
+        int per_cu = 0, cus = 0;
+        MDX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), 256, lds));
+        MDX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->dev));
+        h->occ_kernel = reinterpret_cast<const void *>(kern);
+        h->occ_lds = lds;
+        h->occ_blocks_per_xcd = std::max<int64_t>(1, int64_t(std::max(per_cu, 1)) * std::max(cus, 8) / 8);
+    }
+    const int64_t blocks_per_xcd = h->occ_blocks_per_xcd;
 
     hipStream_t s_sort = n_sets == 2 ? h->sort_stream : h->stream;
     if (n_sets == 2) {
