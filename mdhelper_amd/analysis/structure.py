@@ -330,13 +330,15 @@ class RadialDistributionFunction(DynamicAnalysisBase):
         self._engine.set_drop_axis(self._drop_axis)
         all1 = len(i1) == traj.n_atoms and np.array_equal(i1, np.arange(len(i1)))
         native = getattr(traj, "native", None)
+        contiguous = len(mine) < 2 or bool(np.all(np.diff(mine) == 1))
         if native is not None:
             # trajectory file: raw frames stream file -> pinned memory -> HBM inside the library
-            block = max(block, 4096)
+            block = max(block, 4096, (4 << 30) // max(12 * traj.n_atoms, 1))
         else:
-            # in-memory frames are handed over where they lie (slices, no copy): ~1 GiB per call, the
-            # library pipelines inside a call (copy of slab k + 1 beside the kernels of slab k)
-            block = max(block, (1 << 30) // max(12 * traj.n_atoms, 1))
+            # in-memory frames are handed over where they lie (slices, no copy): ~4 GiB per call (1 GiB when
+            # the selection has to be gathered first); the library pipelines inside a call (copy of slab
+            # k + 1 beside the kernels of slab k), every call boundary drains that pipeline once
+            block = max(block, ((4 if contiguous else 1) << 30) // max(12 * traj.n_atoms, 1))
         for b0 in np.arange(0, len(mine), block):
             sel = mine[b0:b0 + block]
             boxes = traj.box_block(sel)

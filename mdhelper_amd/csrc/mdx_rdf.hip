@@ -612,6 +612,10 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
         // persistent blocks: what the chip holds at once (blocks per CU from the kernel's own occupancy), a
         // multiple of 8 so that every XCD gets the same number; fewer when there is less work than that
         a.work = h->d_work.as<unsigned>();
+        {
+            const char *fu = getenv("MDX_RDF_LDS_FLUSH_UNITS");   // test hook: flush the LDS bins (much) more often
+            a.flush_units = fu ? (unsigned)std::min<long long>(std::max<long long>(atoll(fu), 1), 1 << 18) : (1u << 18);
+        }
         const int64_t tiles = n1p / 128;
         hipEvent_t ev = h->timer.begin();
         // (frames per launch: the item index is 32 bits wide)

@@ -55,6 +55,9 @@ struct CellArgs {
     // persistent blocks: eight work counters (one per XCD, 32 words apart, zeroed before the launch) hand out
     // the (frame, i tile) items of the XCD's frames
     unsigned *work;
+    // 32-bit LDS bins are flushed to the 64-bit replicas before this many j tiles of 2^14 possible adds each
+    // could have gone into one bin since the last flush (2^18; MDX_RDF_LDS_FLUSH_UNITS: test hook)
+    unsigned flush_units;
 };
 
 constexpr unsigned CELL_WORK_STRIDE = 32;   // words between the work counters of two XCDs (one 128-byte line each)
@@ -831,7 +834,7 @@ __global__ __launch_bounds__(256, TRI ? 4 : 7) void rdf_cell_pair_kernel(CellArg
         // however many items a block serves and however large the second set is (it could,
         // silently, from ~1.6e7 particles with coarse bins).  Uniform decision; the adds of earlier rounds are
         // behind a barrier, the next adds come after the barrier that closes the cull below.
-        if (!GH && lds_units + unsigned(round1 - round0) >= (1u << 18)) {
+        if (!GH && lds_units + unsigned(round1 - round0) >= cell_args()->flush_units) {
             for (int b = tid; b < a.n_bins; b += 256) {
                 unsigned long long sum = 0;
                 for (int h = 0; h < a.n_hist; ++h) {

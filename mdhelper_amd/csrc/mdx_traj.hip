@@ -597,38 +597,70 @@ int Trajectory::read_boxes(const int64_t *frames, int64_t n, float *boxes6) cons
     MDX_REQUIRE(boxes6, "NULL output");
     if (!has_box)
         return fail(MDX_ERR_STATE, "the trajectory holds no unit-cell information");
-    for (int64_t i = 0; i < n; ++i) {
-        float *b = boxes6 + 6 * i;
-        uint8_t raw[48];
-        if (format == TRAJ_NETCDF) {
-            const int ls = nc_type_size(cell_type);
-            MDX_TRY(read_at(cell_first + frames[i] * frame_stride, raw, size_t(3) * ls));
-            for (int k = 0; k < 3; ++k)
-                b[k] = (float)load_scalar(raw + k * ls, cell_type, swap);
-            b[3] = b[4] = b[5] = 90.0f;
-            if (angle_first >= 0) {
-                const int as = nc_type_size(angle_type);
-                MDX_TRY(read_at(angle_first + frames[i] * frame_stride, raw, size_t(3) * as));
-                for (int k = 0; k < 3; ++k)
-                    b[3 + k] = (float)load_scalar(raw + k * as, angle_type, swap);
+    // one or two small reads per frame, a record apart on disk: shared out over a few threads for long
+    // lists (12 000 reads for 6 000 frames were 5 % of an RDF over a file at the kernel's rate)
+    std::mutex err_lock;
+    int first_rc = MDX_OK;
+    std::string first_msg;
+    const std::function<void(int)> one = [&](int task) {
+        const int64_t lo = int64_t(task) * 256, hi = std::min<int64_t>(n, lo + 256);
+        for (int64_t i = lo; i < hi; ++i) {
+            const int rc = read_box(frames[i], boxes6 + 6 * i);
+            if (rc != MDX_OK) {
+                std::lock_guard<std::mutex> lk(err_lock);
+                if (first_rc == MDX_OK) {
+                    first_rc = rc;
+                    first_msg = mdx_last_error();
+                }
+                return;
             }
-        } else {
-            MDX_TRY(read_at(cell_first + frames[i] * frame_stride, raw, 48));
-            double u[6];
-            for (int k = 0; k < 6; ++k)
-                u[k] = load_scalar(raw + 8 * k, 6, swap);
-            // stored as A, gamma, B, beta, alpha, C; CHARMM and NAMD store the angle cosines
-            if (std::fabs(u[1]) <= 1.0 && std::fabs(u[3]) <= 1.0 && std::fabs(u[4]) <= 1.0) {
-                for (int k : {1, 3, 4})
-                    u[k] = 90.0 - std::asin(u[k]) * 90.0 / M_PI_2;
-            }
-            b[0] = (float)u[0];
-            b[1] = (float)u[2];
-            b[2] = (float)u[5];
-            b[3] = (float)u[4];
-            b[4] = (float)u[3];
-            b[5] = (float)u[1];
         }
+    };
+    const int tasks = (int)ceil_div(n, 256);
+    if (n >= 2048) {
+        HostWorkers readers;
+        readers.start(8);
+        readers.parallel_for(tasks, one);
+    } else {
+        for (int t = 0; t < tasks && first_rc == MDX_OK; ++t)
+            one(t);
+    }
+    if (first_rc != MDX_OK)
+        return fail(first_rc, "%s", first_msg.empty() ? "trajectory read failed" : first_msg.c_str());
+    return MDX_OK;
+}
+
+int Trajectory::read_box(int64_t frame, float *b) const
+{
+    uint8_t raw[48];
+    if (format == TRAJ_NETCDF) {
+        const int ls = nc_type_size(cell_type);
+        MDX_TRY(read_at(cell_first + frame * frame_stride, raw, size_t(3) * ls));
+        for (int k = 0; k < 3; ++k)
+            b[k] = (float)load_scalar(raw + k * ls, cell_type, swap);
+        b[3] = b[4] = b[5] = 90.0f;
+        if (angle_first >= 0) {
+            const int as = nc_type_size(angle_type);
+            MDX_TRY(read_at(angle_first + frame * frame_stride, raw, size_t(3) * as));
+            for (int k = 0; k < 3; ++k)
+                b[3 + k] = (float)load_scalar(raw + k * as, angle_type, swap);
+        }
+    } else {
+        MDX_TRY(read_at(cell_first + frame * frame_stride, raw, 48));
+        double u[6];
+        for (int k = 0; k < 6; ++k)
+            u[k] = load_scalar(raw + 8 * k, 6, swap);
+        // stored as A, gamma, B, beta, alpha, C; CHARMM and NAMD store the angle cosines
+        if (std::fabs(u[1]) <= 1.0 && std::fabs(u[3]) <= 1.0 && std::fabs(u[4]) <= 1.0) {
+            for (int k : {1, 3, 4})
+                u[k] = 90.0 - std::asin(u[k]) * 90.0 / M_PI_2;
+        }
+        b[0] = (float)u[0];
+        b[1] = (float)u[2];
+        b[2] = (float)u[5];
+        b[3] = (float)u[4];
+        b[4] = (float)u[3];
+        b[5] = (float)u[1];
     }
     return MDX_OK;
 }

@@ -89,6 +89,7 @@ private:
     int parse_dcd(const std::vector<uint8_t> &head, bool &need_more);
     int read_at(int64_t offset, void *dst, size_t bytes) const;
     int fill_raw(const int64_t *frames, int64_t n, uint8_t *dst, HostWorkers *workers = nullptr) const;
+    int read_box(int64_t frame, float *box6) const;
 };
 
 }  // namespace mdx

@@ -705,3 +705,40 @@ def test_rdf_triclinic_culled_kernel(cell, monkeypatch):
     # a range beyond half the smallest height falls back to the brute-force kernel
     want = c_radial_histogram(pos[:1500], pos[:1500], 50, (0.0, 22.0), dims, exclusion=(1, 1))
     assert np.array_equal(_gpu_hist(pos[:1500], None, 50, (0.0, 22.0), dims, (1, 1), "auto"), want)
+
+
+@pytest.mark.parametrize("units", ["1", "40", "1000"])
+def test_rdf_persistent_blocks_flush_their_lds_bins_between_items(units, monkeypatch):
+    """The persistent pair kernel keeps 32-bit LDS bins across the items a block serves and flushes them to
+    the 64-bit replicas before a bin could wrap (2^18 j tiles of 2^14 possible adds; at the BASELINE sizes
+    that happens once per block and launch at C5 only).  MDX_RDF_LDS_FLUSH_UNITS lowers the bound so that
+    small inputs flush before every round ("1"), every few items, or now and then: 160 frames of 2 500
+    particles = 3 200 items on 1 792 blocks, two groups, counts identical with the C oracle."""
+    monkeypatch.setenv("MDX_RDF_LDS_FLUSH_UNITS", units)
+    rng = np.random.default_rng(77)
+    F, n1, n2, L = 160, 2500, 1500, np.float32(29.0)
+    a = (rng.random((F, n1, 3)) * L).astype(np.float32)
+    b = (rng.random((F, n2, 3)) * L).astype(np.float32)
+    dims = np.array([L, L, L, 90, 90, 90], dtype=np.float32)
+    want_self = np.zeros(64, dtype=np.int64)
+    want_cross = np.zeros(64, dtype=np.int64)
+    for f in range(0, F, 16):            # the oracle on every 16th frame; the GPU on the same ten
+        want_self += c_radial_histogram(a[f], a[f], 64, (0.0, 9.0), dims, exclusion=(1, 1))
+        want_cross += c_radial_histogram(a[f], b[f], 64, (0.0, 9.0), dims)
+    sub = np.arange(0, F, 16)
+    eng = _core.RdfEngine(_edges(64, (0.0, 9.0)), (1, 1), algo="cell")
+    # all 160 frames in one launch (many items per block), then minus the 150 the oracle skipped: linearity
+    eng.accumulate(a, None, dims)
+    all_counts = eng.counts()
+    eng.reset()
+    rest = np.setdiff1d(np.arange(F), sub)
+    eng.accumulate(a[rest], None, dims)
+    assert np.array_equal(all_counts - eng.counts(), want_self)
+    eng.close()
+    eng = _core.RdfEngine(_edges(64, (0.0, 9.0)), None, algo="cell")
+    eng.accumulate(a, b, dims)
+    all_counts = eng.counts()
+    eng.reset()
+    eng.accumulate(a[rest], b[rest], dims)
+    assert np.array_equal(all_counts - eng.counts(), want_cross)
+    eng.close()

@@ -249,3 +249,42 @@ def test_bench_contract_without_a_device(tmp_path):
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"],
                              capture_output=True, text=True, env=env, timeout=300)
         assert out.returncode != 0 and out.stdout.strip() == ""      # no JSON line without a GPU
+
+
+def test_fragments_and_make_whole_images():
+    """`ArrayUniverse(..., bonds=...)` -> `atoms.fragments` (connected components, ordered by first atom) and
+    the image flags that make every fragment of the current frame whole (reference transport.py:936-941 ->
+    MDAnalysis make_whole, restated): a chain wrapped twice around the cell, a ring, a lone atom."""
+    import mdhelper_amd
+    from mdhelper_amd.algorithm.topology import make_whole_images
+    L = np.array([10.0, 12.0, 9.0])
+    # chain of 9 atoms, 1.5 apart along x starting at 8.5: crosses the x boundary once; continues wrapping
+    chain = np.stack((8.5 + 1.5 * np.arange(9), np.full(9, 6.0), np.full(9, 4.5)), axis=1)
+    # ring of 4 atoms straddling the y and z boundaries
+    ring = np.array([[2.0, 11.6, 8.7], [2.0, 0.4, 8.7], [2.0, 0.4, 0.3], [2.0, 11.6, 0.3]])
+    ring_true = np.array([[2.0, 11.6, 8.7], [2.0, 12.4, 8.7], [2.0, 12.4, 9.3], [2.0, 11.6, 9.3]])
+    lone = np.array([[5.0, 5.0, 5.0]])
+    true = np.concatenate((chain, ring_true, lone))
+    wrapped = np.mod(true, L).astype(np.float32)
+    bonds = [(i, i + 1) for i in range(8)] + [(9, 10), (10, 11), (11, 12), (12, 9)]
+    # atoms shuffled so that fragments interleave in index order
+    order = np.array([0, 9, 1, 10, 13, 2, 11, 3, 12, 4, 5, 6, 7, 8])
+    inv = np.argsort(order)
+    u = mdhelper_amd.ArrayUniverse(wrapped[order][None], [*L, 90, 90, 90],
+                                   bonds=[(inv[i], inv[j]) for i, j in bonds])
+    frags = u.atoms.fragments
+    assert [len(f) for f in frags] == [9, 4, 1]                     # ordered by first atom: chain, ring, lone
+    assert sorted(order[frags[1].indices]) == [9, 10, 11, 12]
+    assert [len(f) for f in u.atoms[[4]].fragments] == [1]          # fragments of a sub-group: whole fragments
+    img = make_whole_images(u, L)
+    whole = wrapped[order].astype(float) + img * L
+    # whole up to one lattice vector per fragment (the first atom keeps its stored image)
+    for f in frags:
+        d = whole[f.indices] - true[order][f.indices]
+        shift = d[0]
+        assert np.allclose(d, shift, atol=1e-5)
+        assert np.allclose(shift / L, np.rint(shift / L), atol=1e-5)
+    assert img[inv[0]].tolist() == [0, 0, 0] and img[inv[8]].tolist() == [2, 0, 0]
+    # no bonds: nothing to make whole
+    u0 = mdhelper_amd.ArrayUniverse(wrapped[None], [*L, 90, 90, 90])
+    assert not make_whole_images(u0, L).any() and len(u0.atoms.fragments) == 14
