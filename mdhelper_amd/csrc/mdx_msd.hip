@@ -330,7 +330,7 @@ static int msd_push_device(mdx_msd *h, int group, const double *d_pos, int64_t n
     chunk = ceil_div(count, n_chunks);
     if (h->own_fft) {
         const int64_t most = h->fft_batch_atoms > 0 ? std::min(h->fft_batch_atoms, chunk) : chunk;
-        const int64_t p_pad_max = ceil_div(ceil_div(most * 3, 2), msdfft::PG) * msdfft::PG;
+        const int64_t p_pad_max = ceil_div(ceil_div(most * 3 + 15, 2), msdfft::PG) * msdfft::PG;   // (+ 15: head)
         MDX_TRY(h->d_spec.ensure(size_t(B) * h->n_fft * p_pad_max * 16));
         if (h->fused_sums)
             MDX_TRY(h->d_part.ensure(msdfft::fused_part_bytes(h->shape, (int)p_pad_max, B)));
@@ -354,13 +354,20 @@ static int msd_push_device(mdx_msd *h, int group, const double *d_pos, int64_t n
             // and the same addresses are reused by the next batch.
             const int64_t sub = h->fft_batch_atoms > 0 ? std::min<int64_t>(h->fft_batch_atoms, c) : c;
             for (int64_t s0 = 0; s0 < c; s0 += sub) {
-                const int64_t ne = std::min(sub, c - s0) * 3;
+                // rows whose length is a multiple of 128 bytes (and positions from hipMalloc): a chunk that starts
+                // in the middle of a line is entered `head` coordinates early, so that pass A's 128-byte pieces
+                // are whole lines (msd_fft_cols400_fused_kernel); the head is staged as zeros
+                const int head = (h->fused_sums && msdfft::aligns_head(h->shape) && (n_total * 3) % 16 == 0 &&
+                                  (reinterpret_cast<uintptr_t>(d_pos) & 127u) == 0 && !getenv("MDX_MSD_NO_HEAD"))
+                                     ? int(((first + a0 + s0) * 3) % 16)
+                                     : 0;
+                const int64_t ne = std::min(sub, c - s0) * 3 + head;
                 const int p_pad = (int)(ceil_div(ceil_div(ne, 2), msdfft::PG) * msdfft::PG);
                 msdfft::launch(h->shape, h->stream, d_pos, n_total, first + a0 + s0, ne, h->t_block, B,
                                zero_dims, p_pad, tw_r1, tw_r2, twN, h->d_spec.as<double2>(),
                                h->d_pfull.as<double>(), s0 > 0 ? 1 : 0,
                                h->fused_sums ? h->d_part.as<double2>() : nullptr, h->traj(group),
-                               h->dsq(group));
+                               h->dsq(group), head);
             }
             msdfft::launch_fold(h->shape, h->stream, h->d_pfull.as<double>(), B, h->nc, h->power(group));
             // positions read once (twice where the sums are a kernel of their own), Y written and read once

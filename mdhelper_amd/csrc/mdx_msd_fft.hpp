@@ -525,8 +525,14 @@ template <int R2>
 __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols400_fused_kernel(
     const double *__restrict__ pos, int64_t n_total, int64_t first, int64_t n_elem, int64_t t_block,
     int zero_dims, int p_pad, const double2 *__restrict__ tw_r1, const double2 *__restrict__ twN,
-    double2 *__restrict__ Y, double2 *__restrict__ part)
+    double2 *__restrict__ Y, double2 *__restrict__ part, int head)
 {
+    // head: the chunk is entered `head` (< 16) coordinates BEFORE the first particle's x, so that every
+    // 128-byte piece a lane group loads is one cache line (a group that starts 64 bytes off a line touched two
+    // lines per piece: 31 % more fetched and 1.6 ms per step at C4, round 3).  n_elem counts from there; the
+    // head coordinates belong to the neighbouring particles of the row (valid memory) and are staged as zeros;
+    // the dimension of coordinate e is (e - head) % 3 = (e + dshift) % 3.
+    const int dshift = (3 - head % 3) % 3;
     constexpr int R1 = 400, ZS = R1 + 1, LIVE = R1 / 2;
     constexpr int LOADS = (LIVE + 63) / 64;     // 4 row rounds of 64 rows (a lane loads a PAIR: 16 bytes)
     constexpr int OUTS = (R1 + 63) / 64;        // 7 line rounds
@@ -553,7 +559,7 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols400_fused_kernel(
     // lane: 8-byte-per-lane loads run at 0.54-0.70 of the 16-byte rate (MI355X_MICROARCH.md), and the pair is what
     // gets staged anyway
     const int lp = tid & 7, s = 2 * lp, row0 = tid >> 3;
-    const double *base = pos + (int64_t(b) * t_block * n_total + first) * 3;
+    const double *base = pos + (int64_t(b) * t_block * n_total + first) * 3 - head;
     const int64_t row_stride = n_total * 3;
     const int64_t istr = int64_t(64) * R2 * row_stride;       // rows row0 + 64 i -> + i * istr
     // stores: pair p of line kbase + 64 i
@@ -570,13 +576,20 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols400_fused_kernel(
     // the row exists (row0 + 64 i < 200) and its frame (row0 + 64 i) R2 + N2 lies in the block.  32-bit tests
     // against per-thread limits.
     const int e_lim = int(min<int64_t>(n_elem - int64_t(pg0) * 16 - s, 1 << 20));      // 16 Q (+ 1) < e_lim
+    // (head < 16: only pair group 0 of the chunk has dead coordinates, those with 16 * 0 + s (+ 1) < head — a
+    // wave-uniform test on the pair group and one on s3 = s + dshift, the one per-thread value the loop keeps
+    // of `s`: a per-thread limit of its own was one VGPR too many, it spilled, and a scratch reload in this loop
+    // drains vmcnt)
+    const int s3 = s + dshift, head3 = head + dshift;
     const int t_lim = int(min<int64_t>(t_block - int64_t(row0) * R2, int64_t(1) << 30));   // 64 i R2 + N2 < t_lim
     const int i_lim = row0 < LIVE - 64 * (LOADS - 1) ? LOADS : LOADS - 1;                 // i < i_lim
 #define MDX_FUSED_ROW(N2, I) ((I) < i_lim && 64 * R2 * (I) + (N2) < t_lim)
 #define MDX_FUSED_OK0(N2, Q, I)                                                              \
-    (16 * (Q) < e_lim && !((zero_dims >> ((pg0 + (Q) + s) % 3)) & 1) && MDX_FUSED_ROW(N2, I))
+    (16 * (Q) < e_lim && (pg0 + (Q) > 0 || s3 >= head3) && !((zero_dims >> ((pg0 + (Q) + s3) % 3)) & 1) && \
+     MDX_FUSED_ROW(N2, I))
 #define MDX_FUSED_OK1(N2, Q, I)                                                              \
-    (16 * (Q) + 1 < e_lim && !((zero_dims >> ((pg0 + (Q) + s + 1) % 3)) & 1) && MDX_FUSED_ROW(N2, I))
+    (16 * (Q) + 1 < e_lim && (pg0 + (Q) > 0 || s3 + 1 >= head3) && !((zero_dims >> ((pg0 + (Q) + s3 + 1) % 3)) & 1) && \
+     MDX_FUSED_ROW(N2, I))
     // issue the loads of (column N2, pair group pg0 + Q) from CUR; dead rows read `base`; a pair whose second
     // coordinate lies past the chunk is read one coordinate earlier (its first coordinate arrives in .y), so
     // that no load reaches past the chunk's last coordinate
@@ -640,7 +653,7 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols400_fused_kernel(
                 }
             }
             // bring (c0, c1, c2) to absolute dimensions: rotate by (pg + 2 half) % 3
-            const int rot = (pg0 + q + 2 * half) % 3;
+            const int rot = (pg0 + q + 2 * half + dshift) % 3;
             double sx = rot == 0 ? c0 : rot == 1 ? c2 : c1;
             double sy = rot == 0 ? c1 : rot == 1 ? c0 : c2;
             double sz = rot == 0 ? c2 : rot == 1 ? c1 : c0;
@@ -1224,7 +1237,9 @@ inline int rows_parts(const Shape &sh, int n_blocks)
 
 // Shapes whose pass A carries the per-frame sums (x^2 and the coordinate sums of every frame) itself:
 // the caller then skips its own sums kernel and hands `part`, `traj`, `dsq` to launch().
-inline bool fuses_sums(const Shape &sh) { return sh.r1 == 400 || sh.r1 == 64; }   // (16-point factors: trajectories too short to matter)
+inline bool fuses_sums(const Shape &sh) { return sh.r1 == 400 || sh.r1 == 64; }
+// pass A kernels that can enter a chunk a few coordinates early to make its 128-byte pieces whole cache lines
+inline bool aligns_head(const Shape &sh) { return sh.r1 == 400; }   // (16-point factors: trajectories too short to matter)
 inline int fused_super_groups(int p_pad) { return (p_pad / PG + SG - 1) / SG; }
 // bytes of the partial-sum records of one launch: [super group][block][R2][200 rows][4 doubles]
 inline size_t fused_part_bytes(const Shape &sh, int p_pad, int n_blocks)
@@ -1253,7 +1268,7 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
                    int64_t first, int64_t n_elem, int64_t t_block, int n_blocks, int zero_dims,
                    int p_pad, const double2 *tw_r1, const double2 *tw_r2, const double2 *twN,
                    double2 *Y, double *Pfull, int accumulate, double2 *part = nullptr,
-                   double *traj = nullptr, double *dsq = nullptr)
+                   double *traj = nullptr, double *dsq = nullptr, int head = 0)
 {
     // >= ~1024 blocks of pass A where the batch allows it
     int split = 4;
@@ -1304,7 +1319,7 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
         const int fsplit = slots_split(int64_t(n_sg) * n_blocks, 8, 64);
         hipLaunchKernelGGL((msd_fft_cols400_fused_kernel<512>), dim3((unsigned)n_sg, (unsigned)fsplit, (unsigned)n_blocks),
                            dim3(THREADS), 0, stream, pos, n_total, first, n_elem, t_block, zero_dims, p_pad,
-                           tw_r1, twN, Y, part);
+                           tw_r1, twN, Y, part, head);
         hipLaunchKernelGGL(msd_partials_reduce_kernel,
                            dim3((unsigned)((int64_t(sh.r2) * SUMS_ROWS + 255) / 256), (unsigned)n_blocks), dim3(256), 0,
                            stream, part, n_sg, sh.r2, 1, SUMS_ROWS, t_block, traj, dsq);

@@ -545,7 +545,10 @@ def test_rdf_mixed_orthorhombic_and_triclinic_frames_in_one_batch():
                                   (524288, 1, 7, 0), (12500, 8, 30, 0), (8193, 3, 21, 2), (16384, 2, 40, 0),
                                   (16385, 5, 13, 4), (32768, 1, 19, 1), (25000, 4, 23, 0), (33000, 2, 11, 0),
                                   (2049, 7, 50, 0), (4096, 1, 33, 2), (5000, 20, 16, 0), (8192, 2, 25, 1),
-                                  (100000, 1, 29, 0), (102400, 1, 8, 3), (102401, 1, 8, 0), (32769, 3, 17, 0)])
+                                  (100000, 1, 29, 0), (102400, 1, 8, 3), (102401, 1, 8, 0), (32769, 3, 17, 0),
+                                  # rows of whole 128-byte lines (16 | 3 n_atoms): the second push starts 9
+                                  # coordinates into a line and pass A enters its chunk early (head)
+                                  (70001, 1, 16, 0), (40000, 2, 32, 5), (50000, 1, 48, 2)])
 def test_msd_own_two_pass_transform_equals_rocfft(case, monkeypatch):
     """n_fft = 2^13 .. 2^16, 204 800, 2^18, 2^19, 2^20: the engine's own packed two-pass transforms
     against the rocFFT pipeline."""
