@@ -282,6 +282,10 @@ void HostWorkers::loop()
             if (stopping)
                 return;
             seen = generation;
+            // woken after the call it was woken for has ended (its tasks were all claimed by others): nothing to
+            // take part in — and `next` may already belong to the following call, so it is not touched
+            if (!job)
+                continue;
             fn = job;
             total = n_tasks;
             ++active;
@@ -315,9 +319,9 @@ void HostWorkers::parallel_for(int n, const std::function<void(int)> &fn)
     cv_work.notify_all();
     for (int i; (i = next.fetch_add(1)) < n;)
         fn(i);
-    // every task has been claimed; wait for the workers that are still inside one.  A worker that
-    // wakes up late finds the counter exhausted and goes back to sleep without touching `fn`
-    // after it has left `active`, and `fn` outlives this wait.
+    // every task has been claimed; wait for the workers that are still inside one (a worker joins a call — takes
+    // `job`, counts itself in `active` — in ONE critical section, so none can be between the two here), then
+    // close the call: a worker that wakes up late finds no job and goes back to sleep
     std::unique_lock<std::mutex> lk(m);
     cv_done.wait(lk, [&] { return active == 0; });
     job = nullptr;
