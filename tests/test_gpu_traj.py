@@ -406,3 +406,35 @@ def test_onsager_unwrap_makes_split_molecules_whole_first(tmp_path):
         assert np.allclose(want, ref.results[name], rtol=2e-4, atol=2e-5 * scale), name
     far = np.abs(nobond.results.msd_self - host.results.msd_self).max()
     assert far > 1e-3 * np.abs(host.results.msd_self).max(), far
+
+
+def test_page_locked_caller_memory_is_read_in_place(tmp_path):
+    """`mdx_host_register`: a caller buffer page-locked once is handed to the DMA engine where it lies
+    (no staging copy through the pinned ring); pageable, registered and again pageable (after
+    `mdx_host_unregister`) give the same counts, through engines that come and go (cached device blocks
+    and streams are reused between them)."""
+    from mdhelper_amd import _lib
+    rng = np.random.default_rng(9)
+    F, N, L = 300, 5000, np.float32(40.0)                 # 18 MB: more than one 16 MiB ring chunk
+    pos = (rng.random((F, N, 3)) * L).astype(np.float32)
+    dims = np.array([L, L, L, 90, 90, 90], dtype=np.float32)
+    edges = np.linspace(0.0, 8.0, 33)
+
+    def counts():
+        eng = _core.RdfEngine(edges, (1, 1))
+        eng.accumulate(pos, None, dims)
+        out = eng.counts()
+        eng.close()
+        return out
+
+    want = counts()
+    assert want.sum() > 0
+    _lib.check(_lib.lib().mdx_host_register(0, pos.ctypes.data, pos.nbytes))
+    try:
+        for _ in range(3):
+            assert np.array_equal(counts(), want)
+    finally:
+        _lib.check(_lib.lib().mdx_host_unregister(0, pos.ctypes.data))
+    assert np.array_equal(counts(), want)
+    with pytest.raises(ValueError):
+        _lib.check(_lib.lib().mdx_host_register(0, None, 0))
