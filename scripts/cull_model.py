@@ -57,3 +57,53 @@ for cpa in (16, 32, 64):
         sel = rng.choice(len(li), 64, replace=False)
         surv = (gap2(li[sel], hi[sel], lj, hj) <= R * R).sum(1).mean()
         print(f"cells/axis {cpa:3d} G_i={Gi:3d} G_j={Gj:3d}: evaluations per binned pair {surv * Gj / binned_per_i:.2f}")
+
+
+# ---------------------------------------------------------------------------------------------
+# Second model: the two 32-lane halves of a wave take different j rows where a row is needed by one
+# 32-particle quarter only (rows paired up within a tile visit).
+def quarter_model():
+    rng = np.random.default_rng(1)
+    N, L, R = 32768, 68.94, 15.0
+    pos = rng.random((N, 3)) * L
+    a = (64 * L**3 / N) ** (1 / 3)
+    nc0 = nc1 = max(int(round(L / a)), 1); nc2 = max(int(round(16 * L / a)), 1)
+    c = np.minimum((pos / L * [nc0, nc1, nc2]).astype(int), [nc0 - 1, nc1 - 1, nc2 - 1])
+    cx, cy, cz = c[:, 0], c[:, 1].copy(), c[:, 2].copy()
+    cy = np.where(cx & 1, nc1 - 1 - cy, cy); col = cx * nc1 + cy
+    cz = np.where(col & 1, nc2 - 1 - cz, cz)
+    P = pos[np.argsort(col * nc2 + cz, kind="stable")]
+
+    def box(g):
+        return g.min(0), g.max(0)
+    def reach(lo, hi, pts):
+        """rows (points) within R of the box, minimum image per component"""
+        cen, half = 0.5 * (lo + hi), 0.5 * (hi - lo)
+        d = pts - cen; d -= L * np.rint(d / L)
+        g = np.maximum(0.0, np.abs(d) - half)
+        return (g * g).sum(-1) <= R * R
+
+    old = new = new_union = vis = 0
+    tiles = rng.choice(N // 64, 48, replace=False)
+    for t in tiles:
+        I = P[t * 64:(t + 1) * 64]
+        lo, hi = box(I)
+        (loA, hiA), (loB, hiB) = box(I[:32]), box(I[32:])
+        H = reach(lo, hi, P).reshape(-1, 64)
+        A = reach(loA, hiA, P).reshape(-1, 64)
+        B = reach(loB, hiB, P).reshape(-1, 64)
+        for j in range(N // 64):
+            h = H[j].sum()
+            if not h:
+                continue
+            vis += 1
+            old += h
+            both = (A[j] & B[j]).sum(); xa = (A[j] & ~B[j]).sum(); xb = (B[j] & ~A[j]).sum()
+            new += both + max(xa, xb)
+            new_union += (A[j] | B[j]).sum()
+    print(f"visits per (64-half): {vis / len(tiles):.1f}; rows per visit old {old / vis:.1f}")
+    print(f"trips: old {old / len(tiles):.0f} per half-tile; union of quarters {new_union / len(tiles):.0f} "
+          f"({new_union / old:.3f}); paired {new / len(tiles):.0f} ({new / old:.3f})")
+
+
+quarter_model()
