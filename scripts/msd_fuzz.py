@@ -22,6 +22,12 @@ while time.time() < t_end:
     t_block = int(rng.choice(edges)) if rng.random() < 0.6 else int(rng.integers(2, 70000))
     n_blocks = int(rng.integers(1, 5))
     n_atoms = int(rng.integers(1, 24))
+    if rng.random() < 0.3:
+        # rows of whole 128-byte lines (16 | 3 n_atoms): pushes that start inside a line enter their chunk early
+        # (the `head` of msd_fft_cols400_fused_kernel, blocks of 32 769 ... 102 400 frames)
+        n_atoms = int(rng.choice([16, 32]))
+        if rng.random() < 0.7:
+            t_block, n_blocks = int(rng.integers(32769, 60000)), 1
     zero_dims = int(rng.choice([0, 0, 1, 2, 4, 5]))
     T = t_block * n_blocks + int(rng.integers(0, 3))
     pos = rng.uniform(0, 50, (1, n_atoms, 3)) + np.cumsum(rng.normal(0, 0.3, (T, n_atoms, 3)), axis=0)
