@@ -623,7 +623,9 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
         for (int64_t g0 = 0; g0 < nf; g0 += launch_frames) {
             a.frame0 = (int)g0;
             a.n_frames = (int)std::min<int64_t>(launch_frames, nf - g0);
-            const int64_t items_per_xcd = ceil_div(a.n_frames, 8) * tiles;
+            a.spread = a.n_frames < 8 ? 1 : 0;
+            const int64_t items_per_xcd = a.spread ? ceil_div(int64_t(a.n_frames) * tiles, 8)
+                                                   : ceil_div(a.n_frames, 8) * tiles;
             const unsigned grid = 8u * (unsigned)std::min<int64_t>(blocks_per_xcd, items_per_xcd);
             MDX_HIP(hipMemsetAsync(h->d_work.ptr, 0, CELL_WORK_BYTES, h->stream));
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, h->stream, a);

@@ -58,6 +58,10 @@ struct CellArgs {
     // 32-bit LDS bins are flushed to the 64-bit replicas before this many j tiles of 2^14 possible adds each
     // could have gone into one bin since the last flush (2^18; MDX_RDF_LDS_FLUSH_UNITS: test hook)
     unsigned flush_units;
+    // launches of fewer than eight frames (the function-level drop-in hands over ONE): the items are dealt to the
+    // XCDs one by one instead of frame by frame — with a frame per XCD seven eighths of the chip would idle, and
+    // the 0.5 MB of a frame's sorted copy read by eight L2s instead of one is nothing
+    int spread;
 };
 
 constexpr unsigned CELL_WORK_STRIDE = 32;   // words between the work counters of two XCDs (one 128-byte line each)
@@ -710,14 +714,23 @@ __global__ __launch_bounds__(256, TRI ? 4 : 7) void rdf_cell_pair_kernel(CellArg
         const unsigned xcd = cell_opaque(blockIdx.x) & 7u;
         const auto *A = cell_args();
         const unsigned tiles = unsigned(A->n1p) >> 7;                       // 128-particle i tiles of a frame
-        const unsigned nfx = unsigned(A->n_frames + 7 - int(xcd)) >> 3;
-        if (item >= nfx * tiles)
-            break;
-        // (the integer division runs on the VALU: pin its block-uniform results back into SGPRs,
-        // or every pointer derived from them costs two VGPRs)
-        const unsigned fq = __builtin_amdgcn_readfirstlane(item / tiles);
-        frame_l = int(fq * 8u + xcd);
-        I = int(item - fq * tiles);
+        if (A->spread) {
+            const unsigned g = item * 8u + xcd;                             // item of the launch, dealt one by one
+            if (g >= unsigned(A->n_frames) * tiles)
+                break;
+            const unsigned fq = __builtin_amdgcn_readfirstlane(g / tiles);
+            frame_l = int(fq);
+            I = int(g - fq * tiles);
+        } else {
+            const unsigned nfx = unsigned(A->n_frames + 7 - int(xcd)) >> 3;
+            if (item >= nfx * tiles)
+                break;
+            // (the integer division runs on the VALU: pin its block-uniform results back into SGPRs,
+            // or every pointer derived from them costs two VGPRs)
+            const unsigned fq = __builtin_amdgcn_readfirstlane(item / tiles);
+            frame_l = int(fq * 8u + xcd);
+            I = int(item - fq * tiles);
+        }
         frame_l += A->frame0;
     }
     const int frame = frame_l;

@@ -1,6 +1,6 @@
 """Latency of the function-level drop-in (one frame per call): radial_histogram at C2 size and at 4 000 atoms."""
 import sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))))
 import numpy as np
 from mdhelper_amd import _core
 from mdhelper_amd.analysis import structure
