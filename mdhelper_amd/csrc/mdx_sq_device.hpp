@@ -51,6 +51,43 @@ __device__ inline void sincos_f64(double x, double &s, double &c)
     c = ((q + 1) & 2) ? -co : co;
 }
 
+// The constants of sincos_f64 as wave-uniform values pinned to scalar registers (pin() once, outside the loops
+// that call eval()): fp64 literals are not inline constants, and left to itself the compiler keeps all sixteen of
+// them in vector registers across a whole kernel — 32 VGPRs of a register-blocked kernel that has none to spare —
+// and copies one into place before every FMA of the polynomials.  eval() is sincos_f64 operation for operation
+// (same bits); an FMA takes its constant straight from the scalar file.
+struct SinCosScalars {
+    double two_over_pi = 6.36619772367581382433e-01, p1 = 1.57079632679489655800e+00,
+           p2 = 6.12323399573676603587e-17, p3 = -1.49738490485916983e-33;
+    double s1 = -1.66666666666666324348e-01, s2 = 8.33333333332248946124e-03, s3 = -1.98412698298579493134e-04,
+           s4 = 2.75573137070700676789e-06, s5 = -2.50507602534068634195e-08, s6 = 1.58969099521155010221e-10;
+    double c1 = 4.16666666666666019037e-02, c2 = -1.38888888888741095749e-03, c3 = 2.48015872894767294178e-05,
+           c4 = -2.75573143513906633035e-07, c5 = 2.08757232129817482790e-09, c6 = -1.13596475577881948265e-11;
+    __device__ __forceinline__ void pin()
+    {
+        asm volatile("" : "+s"(two_over_pi), "+s"(p1), "+s"(p2), "+s"(p3));
+        asm volatile("" : "+s"(s1), "+s"(s2), "+s"(s3), "+s"(s4), "+s"(s5), "+s"(s6));
+        asm volatile("" : "+s"(c1), "+s"(c2), "+s"(c3), "+s"(c4), "+s"(c5), "+s"(c6));
+    }
+    __device__ __forceinline__ void eval(double x, double &s, double &c) const
+    {
+        double kd = rint(x * two_over_pi);
+        double r = fma(-kd, p1, x);
+        r = fma(-kd, p2, r);
+        r = fma(-kd, p3, r);
+        int q = (int)(long long)kd;
+        double z = r * r;
+        double ps = fma(z, fma(z, fma(z, fma(z, fma(z, s6, s5), s4), s3), s2), s1);
+        double sn = fma(z * r, ps, r);
+        double pc = fma(z, fma(z, fma(z, fma(z, fma(z, c6, c5), c4), c3), c2), c1);
+        double cs = fma(z * z, pc, fma(-0.5, z, 1.0));
+        double so = (q & 1) ? cs : sn;
+        double co = (q & 1) ? sn : cs;
+        s = (q & 2) ? -so : so;
+        c = ((q + 1) & 2) ? -co : co;
+    }
+};
+
 // rho[frame][group][split][q] (re, im)
 __global__ __launch_bounds__(SQ_THREADS) void sq_rho_kernel(
     const float *__restrict__ pos, int64_t n_atoms, const double *__restrict__ qv, int n_q,
@@ -348,6 +385,167 @@ __device__ __forceinline__ SqQuadThread sq_quad_thread(const SqQuadItem *items, 
     return t;
 }
 
+// The regular form of sq_quad_frame (RS > 0: see there).  Beyond the item shape the host guarantees a SIMPLE
+// lattice: every axis has m = 0 ... R - 1 with one R (the reference's grids, n = arange(n_points):
+// structure.py:1376-1381), and lat.tile = RS - SQ_QUAD_PAD.  That makes the table fill branch-free and the same
+// for every lane: task tt of a tile is coordinate tt of its 3 * cnt floats (one coalesced load), rows are written
+// at byte strides of ROW, and the coordinates are FETCHED A TILE AHEAD — the fill of tile n + 1 runs on values
+// loaded before tile n - 1's particle loop, so no wave waits for memory between two tiles (the general fill loads
+// its coordinate, its axis' base, mmin and R per lane and runs per-lane trip counts: ~175 instructions and one
+// memory latency per tile and thread against ~100 and none here).  E(m) is the same chain of products as in
+// sq_quad_fill (E(1) = 1 * (c, s) exactly), so both forms give the same bits.
+template <bool REAL_ONLY, int RS>
+__device__ __forceinline__ void sq_quad_frame_regular(double2 *lat_tab, const SqLattice &lat,
+                                                      const SqQuadThread &t, const float *P, const float *Pprev,
+                                                      int64_t lo, int64_t hi, double (&ar)[SQ_QCOLS][SQ_ZPT],
+                                                      double (&ai)[SQ_QCOLS][SQ_ZPT])
+{
+    constexpr int A = RS - SQ_QUAD_PAD;                                          // particles per tile
+    constexpr int NT = (3 * A + SQ_QUAD_THREADS - 1) / SQ_QUAD_THREADS;         // fill tasks per thread
+    static_assert(NT == 1, "tiles of the regular form have at most SQ_QUAD_THREADS / 3 particles");
+    constexpr int ROW = RS * 16;                                                // bytes between rows m, m + 1
+    const int tid = threadIdx.x, R = lat.R[0];
+    char *const tab = reinterpret_cast<char *>(lat_tab);
+    // a thread's fill tasks (row offset in a set, its axis' base) and read streams are formed once and pinned: left
+    // to rematerialise them inside the tile loop the compiler pairs the prefetched coordinate's register with an
+    // address product and waits for the load a tile early
+    int fo[NT];
+    double fb[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int tt = tid + SQ_QUAD_THREADS * j, a = tt / 3, k = tt - 3 * a;
+        fo[j] = (k * R * RS + a) * 16;
+        fb[j] = k == 0 ? lat.base[0] : k == 1 ? lat.base[1] : lat.base[2];
+        asm volatile("" : "+v"(fo[j]));
+        asm volatile("" : "+v"(fb[j]));
+    }
+    int px0 = t.o0[0], py0 = t.o1[0], pz0 = t.oz[0];
+    asm volatile("" : "+v"(px0), "+v"(py0), "+v"(pz0));
+    SinCosScalars sincos;
+    sincos.pin();
+    float xa[NT], xb[NT];
+    // coordinates of the tile at `base` (cnt >= 1 particles); lanes past its end re-read the last one
+    auto fetch = [&](int64_t base, int cnt) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int64_t at = base * 3 + min(tid + SQ_QUAD_THREADS * j, 3 * cnt - 1);
+            xa[j] = P[at];
+            if (Pprev)
+                xb[j] = Pprev[at];
+        }
+    };
+    auto fill = [&](int set_bytes, int cnt) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int tt = tid + SQ_QUAD_THREADS * j;
+            if (tt < 3 * cnt) {
+                double x = (double)xa[j];
+                if (Pprev)
+                    x -= (double)xb[j];
+                const double theta = fb[j] * x;
+                double s1, c1;
+                sincos.eval(theta, s1, c1);
+                char *row = tab + (set_bytes + fo[j]);
+                *reinterpret_cast<double2 *>(row) = make_double2(1.0, 0.0);
+                double er = c1, ei = s1;
+                row += ROW;
+                *reinterpret_cast<double2 *>(row) = make_double2(er, ei);
+#pragma unroll 2
+                for (int m = 2; m < R; ++m) {
+                    const double nr = fma(er, c1, -ei * s1), ni = fma(er, s1, ei * c1);
+                    er = nr;
+                    ei = ni;
+                    row += ROW;
+                    *reinterpret_cast<double2 *>(row) = make_double2(er, ei);
+                }
+            }
+        }
+    };
+    if (lo < hi) {
+        fetch(lo, (int)min<int64_t>(A, hi - lo));
+        fill(0, (int)min<int64_t>(A, hi - lo));
+        if (lo + A < hi)
+            fetch(lo + A, (int)min<int64_t>(A, hi - lo - A));
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int64_t base = lo; base < hi; base += A, cur ^= 1) {
+        const int cnt = (int)min<int64_t>(A, hi - base);
+        if (base + A < hi) {
+            fill((cur ^ 1) * t.set_len * 16, (int)min<int64_t>(A, hi - base - A));
+            if (base + 2 * A < hi)
+                fetch(base + 2 * A, (int)min<int64_t>(A, hi - base - 2 * A));
+        }
+        const int mine = max(0, min(t.chunk, cnt - t.sub * t.chunk));
+        auto at = [&](int stream_bytes, int ib) {
+            return *reinterpret_cast<const double2 *>(tab + (stream_bytes + ib));
+        };
+        // Software pipeline: the reads of the next particle's (e_x, e_y) and of the next e_z are issued before
+        // the FMAs that hide their latency (the scheduler, short of registers, otherwise waits for every read
+        // right after issuing it).  The read past a thread's last particle stays inside the allocation.
+        const int ib0 = cur * t.set_len * 16;
+        int px = px0 + ib0, py = py0 + ib0, pz = pz0 + ib0;
+        double2 ex = at(px, 0), ey[SQ_QCOLS];
+#pragma unroll
+        for (int c = 0; c < SQ_QCOLS; ++c)
+            ey[c] = at(py, c * ROW);
+        // one particle; `io` = its byte offset from the three stream addresses (an immediate of the reads)
+        auto particle = [&](int io) {
+            // the first e_z is asked for before the column products, which hide its latency; LDS answers in order,
+            // so the wait before the first terms is for this read alone
+            double2 ez = at(pz, io);
+            __builtin_amdgcn_sched_barrier(0);
+            double tr[SQ_QCOLS], ti[SQ_QCOLS];
+#pragma unroll
+            for (int c = 0; c < SQ_QCOLS; ++c) {
+                tr[c] = fma(ex.x, ey[c].x, -ex.y * ey[c].y);
+                ti[c] = fma(ex.x, ey[c].y, ex.y * ey[c].x);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            ex = at(px, io + 16);
+#pragma unroll
+            for (int c = 0; c < SQ_QCOLS; ++c)
+                ey[c] = at(py, io + 16 + c * ROW);
+#pragma unroll
+            for (int j = 0; j < SQ_ZPT; ++j) {
+                double2 ezn = ez;
+                if (j + 1 < SQ_ZPT)
+                    ezn = at(pz, io + (j + 1) * ROW);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < SQ_QCOLS; ++c) {
+                    ar[c][j] = fma(tr[c], ez.x, fma(-ti[c], ez.y, ar[c][j]));
+                    if (!REAL_ONLY)
+                        ai[c][j] = fma(tr[c], ez.y, fma(ti[c], ez.x, ai[c][j]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                ez = ezn;
+            }
+        };
+        // U particles per trip (a tile of 80 gives every thread a multiple of five, the other tiles of four):
+        // one set of address updates and one branch per U particles
+        constexpr int U = A % 5 == 0 ? 5 : 4;
+        int i = 0;
+#pragma unroll 1
+        for (; i + U <= mine; i += U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                particle(16 * u);
+            px += 16 * U;
+            py += 16 * U;
+            pz += 16 * U;
+        }
+#pragma unroll 1
+        for (; i < mine; ++i) {
+            particle(0);
+            px += 16;
+            py += 16;
+            pz += 16;
+        }
+        __syncthreads();
+    }
+}
+
 // Particles [lo, hi) of one frame (or of one pair of frames: Pprev) into the thread's 4 x 8
 // accumulators; REAL_ONLY keeps Re(E_x E_y E_z) only (two FMAs per term).  Ends on a barrier.
 // RS > 0: every item is REGULAR — its four columns share m_x and have consecutive m_y, its eight m_z are
@@ -362,6 +560,10 @@ __device__ __forceinline__ void sq_quad_frame(double2 *lat_tab, const SqLattice 
                                               int64_t lo, int64_t hi, double (&ar)[SQ_QCOLS][SQ_ZPT],
                                               double (&ai)[SQ_QCOLS][SQ_ZPT])
 {
+    if constexpr (RS > 0) {
+        sq_quad_frame_regular<REAL_ONLY, RS>(lat_tab, lat, t, P, Pprev, lo, hi, ar, ai);
+        return;
+    }
     const int tid = threadIdx.x, A = lat.tile;
     if (lo < hi)
         sq_quad_fill(lat_tab, lat, t.stride, P, Pprev, lo, (int)min<int64_t>(A, hi - lo), tid);
@@ -383,46 +585,6 @@ __device__ __forceinline__ void sq_quad_frame(double2 *lat_tab, const SqLattice 
         // otherwise waits for every read right after issuing it).  The read past a thread's
         // last particle stays inside the allocation and is discarded.
         const int ib0 = cur * t.set_len * 16;
-        if constexpr (RS > 0) {
-            constexpr int ROW = RS * 16;   // bytes between the table rows of m and m + 1
-            int px = t.o0[0] + ib0, py = t.o1[0] + ib0, pz = t.oz[0] + ib0;
-            double2 ex = at(px, 0), ey[SQ_QCOLS];
-#pragma unroll
-            for (int c = 0; c < SQ_QCOLS; ++c)
-                ey[c] = at(py, c * ROW);
-#pragma unroll 1
-            for (int i = 0; i < mine; ++i) {
-                double tr[SQ_QCOLS], ti[SQ_QCOLS];
-#pragma unroll
-                for (int c = 0; c < SQ_QCOLS; ++c) {
-                    tr[c] = fma(ex.x, ey[c].x, -ex.y * ey[c].y);
-                    ti[c] = fma(ex.x, ey[c].y, ex.y * ey[c].x);
-                }
-                double2 ez = at(pz, 0);
-                px += 16;
-                py += 16;
-                ex = at(px, 0);
-#pragma unroll
-                for (int c = 0; c < SQ_QCOLS; ++c)
-                    ey[c] = at(py, c * ROW);
-#pragma unroll
-                for (int j = 0; j < SQ_ZPT; ++j) {
-                    double2 ezn = ez;
-                    if (j + 1 < SQ_ZPT)
-                        ezn = at(pz, (j + 1) * ROW);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int c = 0; c < SQ_QCOLS; ++c) {
-                        ar[c][j] = fma(tr[c], ez.x, fma(-ti[c], ez.y, ar[c][j]));
-                        if (!REAL_ONLY)
-                            ai[c][j] = fma(tr[c], ez.y, fma(ti[c], ez.x, ai[c][j]));
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    ez = ezn;
-                }
-                pz += 16;
-            }
-        } else {
         double2 ex[SQ_QCOLS], ey[SQ_QCOLS];
 #pragma unroll
         for (int c = 0; c < SQ_QCOLS; ++c) {
@@ -459,7 +621,6 @@ __device__ __forceinline__ void sq_quad_frame(double2 *lat_tab, const SqLattice 
                 __builtin_amdgcn_sched_barrier(0);
                 ez = ezn;
             }
-        }
         }
         __syncthreads();
     }
@@ -570,8 +731,9 @@ __global__ __launch_bounds__(SQ_QUAD_THREADS, 2) void isf_incoherent_quads_kerne
                         part + ((int64_t(sp) * n_lags + lag) * n_slots + slot) * n_q);
 }
 
-// The instantiated row strides (tile + SQ_QUAD_PAD) of the regular form; 0 = general items.
-#define MDX_SQ_QUAD_STRIDES(X) X(17) X(33) X(49) X(65) X(81) X(97) X(129)
+// The instantiated row strides (tile + SQ_QUAD_PAD) of the regular form; 0 = general items.  Tiles of at most 80
+// particles: every thread has at most one fill task per tile (static_assert in sq_quad_frame_regular).
+#define MDX_SQ_QUAD_STRIDES(X) X(17) X(33) X(49) X(65) X(81)
 using SqRhoQuadsFn = void (*)(const float *, int64_t, const SqQuadItem *, int, int, int, int, SqLattice,
                               const int64_t *, int, int, double2 *);
 using IsfIncQuadsFn = void (*)(const float *, int, int64_t, const SqQuadItem *, int, int, int, int, SqLattice,
@@ -710,8 +872,10 @@ inline bool sq_quad_plan(const std::vector<short> &trip, int64_t n_q, const SqLa
     // regular items (sq_quad_frame, RS > 0): the row stride is a template argument, so the tile is taken from
     // the instantiated sizes — the largest one that fits and that the copies of an item divide
     sh.regular_stride = 0;
-    if (sq_quads_regular(items) && !getenv("MDX_SQ_NO_REGULAR")) {
-        for (int cand : {128, 96, 80, 64, 48, 32, 16})
+    const bool simple = base.mmin[0] == 0 && base.mmin[1] == 0 && base.mmin[2] == 0 && base.R[0] == base.R[1] &&
+                        base.R[1] == base.R[2];   // m = 0 ... R - 1 on every axis: sq_quad_frame_regular's fill
+    if (simple && sq_quads_regular(items) && !getenv("MDX_SQ_NO_REGULAR")) {
+        for (int cand : {80, 64, 48, 32, 16})   // 3 * tile fill tasks <= one per thread (96, 128: measured slower)
             if (cand <= tile && cand % unit == 0) {
                 tile = cand;
                 sh.regular_stride = cand + SQ_QUAD_PAD;

@@ -144,8 +144,16 @@ def sq_entry(tag):
     k = pick(res, "sq_rho_quads_kernel")
     out.update(clock_hz=res[k]["GRBM_GUI_ACTIVE"] / 8.0 / dur[k] * 1e9,
                lds_per_64_terms=res[k]["SQ_INSTS_LDS"] / terms64,
+               raw_pass2={c: res[k][c] for c in ("GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU")},
                source=f"profiles/{ROUND}_{tag}_SQ_INSTS_VALU_SQ_INSTS_VALU_FMA_F64_SQ_INST_pmc.csv, scripts/make_counters.py",
                source_digest=bench.source_digest(*bench.SQ_SOURCES))
+    # LDS side: cycles the LDS array is busy and what bank conflicts add, per 64 terms (LDS-array cycles, per CU)
+    line, res, calls, dur = run_pmc(tag, ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAIT_INST_LDS",
+                                          "SQ_WAVE_CYCLES"], args)
+    k = pick(res, "sq_rho_quads_kernel")
+    out.update(lds_idx_active_per_64_terms=res[k]["SQ_LDS_IDX_ACTIVE"] / terms64,
+               lds_bank_conflict_per_64_terms=res[k]["SQ_LDS_BANK_CONFLICT"] / terms64,
+               lds_wait_share_of_wave_cycles=res[k]["SQ_WAIT_INST_LDS"] / max(res[k]["SQ_WAVE_CYCLES"], 1.0))
     return out
 
 
