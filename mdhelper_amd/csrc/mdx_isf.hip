@@ -325,7 +325,7 @@ static int isf_accumulate(mdx_isf *h, int64_t n, int64_t n_frames, Source source
             if (h->quads)
                 hipLaunchKernelGGL(sq_rho_quads_pick(h->quad.regular_stride), dim3(rblocks, h->n_groups * rs, (unsigned)nf),
                                    dim3(SQ_QUAD_THREADS), h->quad.lds, h->stream, d_new, n,
-                                   h->d_qitems.as<SqQuadItem>(), h->quad.n_items, h->quad.items_p2,
+                                   h->d_qitems.as<SqQuadItem>(), h->quad.n_items, h->quad.ipb,
                                    h->quad.n_sub, (int)h->n_q, h->quad.lat, h->d_offsets.as<int64_t>(),
                                    h->n_groups, rs, dst);
             else if (h->lattice)
@@ -368,7 +368,7 @@ static int isf_accumulate(mdx_isf *h, int64_t n, int64_t n_frames, Source source
                 hipLaunchKernelGGL(isf_incoherent_quads_pick(h->quad.regular_stride),
                                    dim3(iblocks, h->n_slots * n_split, h->n_lags), dim3(SQ_QUAD_THREADS),
                                    h->quad.lds, h->stream, h->d_pos_ring.as<float>(), h->ring_slots, n,
-                                   h->d_qitems.as<SqQuadItem>(), h->quad.n_items, h->quad.items_p2,
+                                   h->d_qitems.as<SqQuadItem>(), h->quad.n_items, h->quad.ipb,
                                    h->quad.n_sub, (int)h->n_q, h->quad.lat, h->d_ranges.as<int64_t>(),
                                    h->n_slots, n_split, h->n_lags, f0, (int)nf, h->d_part.as<double>());
             } else if (h->lattice)

@@ -137,7 +137,7 @@ struct mdx_sq {
     size_t lat_lds = 0;
     // column form of the lattice path (mdx_sq_device.hpp): items, block size, its own tile
     bool quads = false;          // register-blocked columns (sq_rho_quads_kernel)
-    int n_qitems = 0, items_p2 = 0, n_sub = 1;
+    int n_qitems = 0, ipb = 1, n_sub = 1;
     SqLattice quad_lat{};
     size_t quad_lds = 0;
     int quad_regular = 0;        // row stride of the regular-item form of the quad kernel, 0: general items
@@ -170,7 +170,7 @@ static int sq_accumulate_points(mdx_sq *h, const float *d_pos, int64_t n, int64_
         return MDX_OK;
     MDX_REQUIRE(n >= h->n_total, "positions hold %lld particles but the groups span %lld",
                 (long long)n, (long long)h->n_total);
-    const int qblocks = h->quads     ? (int)ceil_div(int64_t(h->items_p2) * h->n_sub, SQ_QUAD_THREADS)
+    const int qblocks = h->quads     ? (int)ceil_div(int64_t(h->n_qitems), int64_t(h->ipb))
                         : h->columns ? (int)ceil_div(h->n_items, h->col_threads)
                                      : (int)ceil_div(h->n_q, SQ_QPB);
     // split the particles when frames x q-blocks x groups alone would not fill 256 CUs
@@ -196,7 +196,7 @@ static int sq_accumulate_points(mdx_sq *h, const float *d_pos, int64_t n, int64_
         if (h->quads)
             hipLaunchKernelGGL(sq_rho_quads_pick(h->quad_regular), dim3(qblocks, h->n_groups * n_split, (unsigned)nf),
                                dim3(SQ_QUAD_THREADS), h->quad_lds, h->stream, d_pos + f0 * n * 3, n,
-                               h->d_qitems.as<SqQuadItem>(), h->n_qitems, h->items_p2, h->n_sub,
+                               h->d_qitems.as<SqQuadItem>(), h->n_qitems, h->ipb, h->n_sub,
                                (int)h->n_q, h->quad_lat, h->d_offsets.as<int64_t>(), h->n_groups,
                                n_split, h->d_rho.as<double2>());
         else if (h->columns)
@@ -288,7 +288,7 @@ int mdx_sq_create(mdx_sq_t *out, int dev, const double *wavevectors, int64_t n_q
             if (!getenv("MDX_SQ_NO_COLUMNS") && !getenv("MDX_SQ_NO_QUADS") &&
                 sq_quad_plan(trip, n_q, h->lat, qitems, shape)) {
                 h->n_qitems = shape.n_items;
-                h->items_p2 = shape.items_p2;
+                h->ipb = shape.ipb;
                 h->n_sub = shape.n_sub;
                 h->quad_lat = shape.lat;
                 h->quad_lds = shape.lds;

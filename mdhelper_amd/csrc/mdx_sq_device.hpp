@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <map>
 #include <vector>
 
 namespace mdx_sq_dev {
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(256) void sq_rho_columns_kernel(
 // share a list of SQ_ZPT m_z values — a 4 x 8 block of accumulators fed by 8 + 8 table reads per
 // particle instead of 2 + 8 per column (the column kernel is bound by its LDS reads: 1.25 16-byte
 // reads per term against four fp64 FMAs).  Threads beyond the item count take further copies of
-// the items for interleaved particles (sub = thread / items_p2) and are summed at the end.
+// the items for interleaved particles (sub = thread / items per block) and are summed at the end.
 // Dynamic LDS: max(two table sets, 32 KB).
 constexpr int SQ_QCOLS = 4;
 constexpr int SQ_QUAD_THREADS = 256;
@@ -363,25 +364,28 @@ struct SqQuadThread {
 };
 
 __device__ __forceinline__ SqQuadThread sq_quad_thread(const SqQuadItem *items, int n_items,
-                                                       int items_p2, int n_sub, const SqLattice &lat)
+                                                       int ipb, int n_sub, const SqLattice &lat)
 {
+    // block b owns items [b ipb, (b + 1) ipb); thread = (copy, item of the block); threads past the last copy
+    // (ipb n_sub < 256) and past the last item idle: they get no particles and write nothing
     SqQuadThread t;
-    const int slot = blockIdx.x * SQ_QUAD_THREADS + threadIdx.x;
-    t.item = n_sub > 1 ? (slot & (items_p2 - 1)) : slot;
-    t.sub = n_sub > 1 ? slot / items_p2 : 0;
-    t.live = t.item < n_items;
+    const int local = int(threadIdx.x) % ipb;
+    t.item = blockIdx.x * ipb + local;
+    t.sub = int(threadIdx.x) / ipb;
+    t.live = t.item < n_items && t.sub < n_sub;
     t.stride = lat.tile + SQ_QUAD_PAD;
     t.set_len = (lat.R[0] + lat.R[1] + lat.R[2]) * t.stride;   // entries per table set
     t.chunk = lat.tile / n_sub;                                // particles per thread and tile
     const SqQuadItem *it = items + min(t.item, n_items - 1);
+    const int first = min(t.sub, n_sub - 1) * t.chunk;   // (idle copies read where the last copy reads)
 #pragma unroll
     for (int c = 0; c < SQ_QCOLS; ++c) {
-        t.o0[c] = (it->i0[c] * t.stride + t.sub * t.chunk) * 16;
-        t.o1[c] = ((lat.R[0] + it->i1[c]) * t.stride + t.sub * t.chunk) * 16;
+        t.o0[c] = (it->i0[c] * t.stride + first) * 16;
+        t.o1[c] = ((lat.R[0] + it->i1[c]) * t.stride + first) * 16;
     }
 #pragma unroll
     for (int j = 0; j < SQ_ZPT; ++j)
-        t.oz[j] = ((lat.R[0] + lat.R[1] + it->z[j]) * t.stride + t.sub * t.chunk) * 16;
+        t.oz[j] = ((lat.R[0] + lat.R[1] + it->z[j]) * t.stride + first) * 16;
     return t;
 }
 
@@ -476,7 +480,7 @@ __device__ __forceinline__ void sq_quad_frame_regular(double2 *lat_tab, const Sq
             if (base + 2 * A < hi)
                 fetch(base + 2 * A, (int)min<int64_t>(A, hi - base - 2 * A));
         }
-        const int mine = max(0, min(t.chunk, cnt - t.sub * t.chunk));
+        const int mine = t.live ? max(0, min(t.chunk, cnt - t.sub * t.chunk)) : 0;
         auto at = [&](int stream_bytes, int ib) {
             return *reinterpret_cast<const double2 *>(tab + (stream_bytes + ib));
         };
@@ -574,7 +578,7 @@ __device__ __forceinline__ void sq_quad_frame(double2 *lat_tab, const SqLattice 
         if (base + A < hi)
             sq_quad_fill(lat_tab + size_t(cur ^ 1) * t.set_len, lat, t.stride, P, Pprev, base + A,
                          (int)min<int64_t>(A, hi - base - A), tid);
-        const int mine = max(0, min(t.chunk, cnt - t.sub * t.chunk));
+        const int mine = t.live ? max(0, min(t.chunk, cnt - t.sub * t.chunk)) : 0;
         // byte address of a read = stream offset (per thread) + ib (set and particle)
         auto at = [&](int stream_bytes, int ib) {
             return *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(lat_tab) +
@@ -631,7 +635,7 @@ __device__ __forceinline__ void sq_quad_frame(double2 *lat_tab, const SqLattice 
 // out_r[q] (REAL_ONLY).
 template <bool REAL_ONLY>
 __device__ __forceinline__ void sq_quad_store(double2 *lat_tab, const SqQuadThread &t,
-                                              const SqQuadItem *items, int n_items, int items_p2,
+                                              const SqQuadItem *items, int n_items, int ipb,
                                               int n_sub, const double (&ar)[SQ_QCOLS][SQ_ZPT],
                                               const double (&ai)[SQ_QCOLS][SQ_ZPT], double2 *out_c,
                                               double *out_r)
@@ -660,9 +664,9 @@ __device__ __forceinline__ void sq_quad_store(double2 *lat_tab, const SqQuadThre
                     continue;
                 double re = ar[c][j], im = REAL_ONLY ? 0.0 : ai[c][j];
                 for (int s2 = 1; s2 < n_sub; ++s2) {
-                    re += red[(2 * j) * T + s2 * items_p2 + t.item];
+                    re += red[(2 * j) * T + s2 * ipb + tid];
                     if (!REAL_ONLY)
-                        im += red[(2 * j + 1) * T + s2 * items_p2 + t.item];
+                        im += red[(2 * j + 1) * T + s2 * ipb + tid];
                 }
                 if (REAL_ONLY)
                     out_r[q] = re;
@@ -676,11 +680,11 @@ __device__ __forceinline__ void sq_quad_store(double2 *lat_tab, const SqQuadThre
 template <int RS>
 __global__ __launch_bounds__(SQ_QUAD_THREADS, 2) void sq_rho_quads_kernel(
     const float *__restrict__ pos, int64_t n_atoms, const SqQuadItem *__restrict__ items,
-    int n_items, int items_p2, int n_sub, int n_q, SqLattice lat,
+    int n_items, int ipb, int n_sub, int n_q, SqLattice lat,
     const int64_t *__restrict__ group_offsets, int n_groups, int n_split, double2 *__restrict__ rho)
 {
     extern __shared__ double2 lat_tab[];
-    const SqQuadThread t = sq_quad_thread(items, n_items, items_p2, n_sub, lat);
+    const SqQuadThread t = sq_quad_thread(items, n_items, ipb, n_sub, lat);
     const int g = blockIdx.y / n_split, sp = blockIdx.y % n_split;
     const int frame = blockIdx.z;
     double ar[SQ_QCOLS][SQ_ZPT], ai[SQ_QCOLS][SQ_ZPT];
@@ -693,7 +697,7 @@ __global__ __launch_bounds__(SQ_QUAD_THREADS, 2) void sq_rho_quads_kernel(
     const int64_t per = (g_hi - g_lo + n_split - 1) / n_split;
     const int64_t lo = g_lo + sp * per, hi = min(g_hi, lo + per);
     sq_quad_frame<false, RS>(lat_tab, lat, t, pos + int64_t(frame) * n_atoms * 3, nullptr, lo, hi, ar, ai);
-    sq_quad_store<false>(lat_tab, t, items, n_items, items_p2, n_sub, ar, ai,
+    sq_quad_store<false>(lat_tab, t, items, n_items, ipb, n_sub, ar, ai,
                          rho + ((int64_t(frame) * n_groups + g) * n_split + sp) * n_q, nullptr);
 }
 
@@ -703,12 +707,12 @@ __global__ __launch_bounds__(SQ_QUAD_THREADS, 2) void sq_rho_quads_kernel(
 template <int RS>
 __global__ __launch_bounds__(SQ_QUAD_THREADS, 2) void isf_incoherent_quads_kernel(
     const float *__restrict__ pos_ring, int ring_slots, int64_t n_atoms,
-    const SqQuadItem *__restrict__ items, int n_items, int items_p2, int n_sub, int n_q,
+    const SqQuadItem *__restrict__ items, int n_items, int ipb, int n_sub, int n_q,
     SqLattice lat, const int64_t *__restrict__ ranges /*[n_slots][2]*/, int n_slots, int n_split,
     int n_lags, long long f_first, int n_new, double *__restrict__ part)
 {
     extern __shared__ double2 lat_tab[];
-    const SqQuadThread t = sq_quad_thread(items, n_items, items_p2, n_sub, lat);
+    const SqQuadThread t = sq_quad_thread(items, n_items, ipb, n_sub, lat);
     const int slot = blockIdx.y / n_split, sp = blockIdx.y % n_split;
     const int lag = blockIdx.z;
     double ar[SQ_QCOLS][SQ_ZPT], ai[SQ_QCOLS][SQ_ZPT];
@@ -727,7 +731,7 @@ __global__ __launch_bounds__(SQ_QUAD_THREADS, 2) void isf_incoherent_quads_kerne
         sq_quad_frame<true, RS>(lat_tab, lat, t, pos_ring + int64_t(f % ring_slots) * n_atoms * 3,
                             pos_ring + int64_t((f - lag) % ring_slots) * n_atoms * 3, lo, hi, ar, ai);
     }
-    sq_quad_store<true>(lat_tab, t, items, n_items, items_p2, n_sub, ar, ai, nullptr,
+    sq_quad_store<true>(lat_tab, t, items, n_items, ipb, n_sub, ar, ai, nullptr,
                         part + ((int64_t(sp) * n_lags + lag) * n_slots + slot) * n_q);
 }
 
@@ -819,22 +823,58 @@ inline bool sq_build_quads(const std::vector<short> &trip, int64_t n_q, const Sq
     return !items.empty() && double(n_q) >= 0.6 * double(items.size()) * SQ_QCOLS * SQ_ZPT;
 }
 
-// Host: true when every item is regular — four columns of one m_x and consecutive m_y, eight consecutive m_z,
-// every entry a wavevector of the set (full grids).
-inline bool sq_quads_regular(const std::vector<SqQuadItem> &items)
+// Host: REGULAR quad items — the set covered by aligned blocks of one m_x, four consecutive m_y (from a multiple of
+// four) and eight consecutive m_z (from a multiple of eight); entries of a block that are not wavevectors of the set
+// are computed and dropped (q = -1).  Needs m >= 0 on every axis (the reference's grids, n = arange(n_points),
+// structure.py:1376-1381, and their q_max-filtered subsets, structure.py:1412-1414) and no wavevector twice.  The
+// tables then run m = 0 ... R - 1 with ONE R for the three axes (`out`: the largest index, rounded up so that every
+// block's rows exist) — what sq_quad_frame_regular's fill assumes.  A full grid gives the items the general builder
+// gives it; a sphere octant uses 60-85 % of its accumulators.  `used` = that fraction.
+inline bool sq_build_quad_blocks(const std::vector<short> &trip, int64_t n_q, const SqLattice &lat,
+                                 std::vector<SqQuadItem> &items, SqLattice &out, double &used)
 {
-    for (const SqQuadItem &it : items) {
-        for (int c = 0; c < SQ_QCOLS; ++c) {
-            if (it.i0[c] != it.i0[0] || it.i1[c] != it.i1[0] + c)
-                return false;
+    if (lat.mmin[0] < 0 || lat.mmin[1] < 0 || lat.mmin[2] < 0)
+        return false;
+    const int top[3] = {lat.mmin[0] + lat.R[0], lat.mmin[1] + lat.R[1], lat.mmin[2] + lat.R[2]};   // max m + 1
+    const int r = std::max(top[0], std::max((top[1] + SQ_QCOLS - 1) / SQ_QCOLS * SQ_QCOLS,
+                                            (top[2] + SQ_ZPT - 1) / SQ_ZPT * SQ_ZPT));
+    if (r > 1024)
+        return false;
+    struct Key { int zb, mx, yb; };
+    auto less = [](const Key &a, const Key &b) {
+        return a.zb != b.zb ? a.zb < b.zb : a.mx != b.mx ? a.mx < b.mx : a.yb < b.yb;
+    };
+    std::map<Key, SqQuadItem, decltype(less)> blocks(less);
+    for (int64_t i = 0; i < n_q; ++i) {
+        const int mx = trip[4 * i], my = trip[4 * i + 1], mz = trip[4 * i + 2];
+        const Key key{mz / SQ_ZPT, mx, my / SQ_QCOLS};
+        auto found = blocks.find(key);
+        if (found == blocks.end()) {
+            SqQuadItem it{};
+            for (int c = 0; c < SQ_QCOLS; ++c) {
+                it.i0[c] = (short)mx;
+                it.i1[c] = (short)(key.yb * SQ_QCOLS + c);
+                for (int z = 0; z < SQ_ZPT; ++z)
+                    it.q[c][z] = -1;
+            }
             for (int z = 0; z < SQ_ZPT; ++z)
-                if (it.q[c][z] < 0)
-                    return false;
+                it.z[z] = (short)(key.zb * SQ_ZPT + z);
+            found = blocks.emplace(key, it).first;
         }
-        for (int z = 0; z < SQ_ZPT; ++z)
-            if (it.z[z] != it.z[0] + z)
-                return false;
+        int &slot = found->second.q[my % SQ_QCOLS][mz % SQ_ZPT];
+        if (slot >= 0)
+            return false;   // the same wavevector twice
+        slot = (int)i;
     }
+    items.clear();
+    for (auto &kv : blocks)
+        items.push_back(kv.second);
+    out = lat;
+    for (int k = 0; k < 3; ++k) {
+        out.mmin[k] = 0;
+        out.R[k] = r;
+    }
+    used = double(n_q) / (double(items.size()) * SQ_QCOLS * SQ_ZPT);
     return !items.empty();
 }
 
@@ -842,49 +882,102 @@ inline bool sq_quads_regular(const std::vector<SqQuadItem> &items)
 // block beyond the item count), table tile (two blocks per CU, two table sets per block: ~36 KB per
 // set, a multiple of the copies) and dynamic LDS.  false: the set does not suit the quad form.
 struct SqQuadShape {
-    int n_items = 0, items_p2 = 0, n_sub = 1;
+    int n_items = 0, ipb = 0, n_sub = 1;   // items, items per block, copies of an item in its block
     int regular_stride = 0;   // > 0: every item is regular and the table rows are this many entries apart
     SqLattice lat{};
     size_t lds = 0;
-    int blocks() const { return (int)((int64_t(items_p2) * n_sub + SQ_QUAD_THREADS - 1) / SQ_QUAD_THREADS); }
+    int blocks() const { return (n_items + ipb - 1) / ipb; }
 };
 
 inline bool sq_quad_plan(const std::vector<short> &trip, int64_t n_q, const SqLattice &base,
-                         std::vector<SqQuadItem> &items, SqQuadShape &sh)
+                         std::vector<SqQuadItem> &items, SqQuadShape &sh, bool allow_regular = true)
 {
-    if (!sq_build_quads(trip, n_q, base, items))
-        return false;
-    sh.n_items = (int)items.size();
-    sh.items_p2 = 1;
-    while (sh.items_p2 < sh.n_items)
-        sh.items_p2 *= 2;
-    sh.n_sub = std::max(1, SQ_QUAD_THREADS / sh.items_p2);
-    if (sh.n_sub == 1)
-        sh.items_p2 = sh.n_items;   // whole blocks of distinct items
-    const int total_r = base.R[0] + base.R[1] + base.R[2];
-    const int unit = std::max(16, sh.n_sub);
-    const size_t fit = size_t(36) * 1024 / (size_t(16) * total_r);
-    if (fit <= size_t(SQ_QUAD_PAD))
-        return false;
-    int tile = (int)(std::min<size_t>(512, fit - SQ_QUAD_PAD) / unit * unit);
-    if (tile < 16)
-        return false;
-    // regular items (sq_quad_frame, RS > 0): the row stride is a template argument, so the tile is taken from
-    // the instantiated sizes — the largest one that fits and that the copies of an item divide
-    sh.regular_stride = 0;
-    const bool simple = base.mmin[0] == 0 && base.mmin[1] == 0 && base.mmin[2] == 0 && base.R[0] == base.R[1] &&
-                        base.R[1] == base.R[2];   // m = 0 ... R - 1 on every axis: sq_quad_frame_regular's fill
-    if (simple && sq_quads_regular(items) && !getenv("MDX_SQ_NO_REGULAR")) {
-        for (int cand : {80, 64, 48, 32, 16})   // 3 * tile fill tasks <= one per thread (96, 128: measured slower)
-            if (cand <= tile && cand % unit == 0) {
-                tile = cand;
-                sh.regular_stride = cand + SQ_QUAD_PAD;
-                break;
+    // regular items (aligned blocks) where they use their accumulators about as well as the general items: the
+    // regular form of the kernel does ~1.1 x the slots per second (measured on full 10^3 / 20^3 grids and sphere
+    // octants, scripts/run/diag_sq_forms.py)
+    SqLattice lat_use = base;
+    bool regular = false;
+    {
+        std::vector<SqQuadItem> blk;
+        SqLattice bl{};
+        double used_blk = 0.0;
+        if (allow_regular && !getenv("MDX_SQ_NO_REGULAR") && sq_build_quad_blocks(trip, n_q, base, blk, bl, used_blk)) {
+            const bool general = sq_build_quads(trip, n_q, base, items);
+            const double used_gen = general ? double(n_q) / (double(items.size()) * SQ_QCOLS * SQ_ZPT) : 0.0;
+            if (used_blk >= 0.45 && used_blk >= 0.92 * used_gen) {
+                items.swap(blk);
+                lat_use = bl;
+                regular = true;
+            } else if (!general) {
+                return false;
             }
+        } else if (!sq_build_quads(trip, n_q, base, items)) {
+            return false;
+        }
     }
-    sh.lat = base;
-    sh.lat.tile = tile;
-    sh.lds = std::max<size_t>(size_t(32) * (tile + SQ_QUAD_PAD) * total_r + 256, size_t(32) * 1024);
+    sh.n_items = (int)items.size();
+    const int total_r = lat_use.R[0] + lat_use.R[1] + lat_use.R[2];
+    const size_t fit = size_t(36) * 1024 / (size_t(16) * total_r);
+    auto general_instead = [&]() {   // the padded tables of the regular items do not fit: the general items
+        if (!regular)
+            return false;
+        SqQuadShape again;
+        std::vector<SqQuadItem> gen;
+        const bool ok = sq_quad_plan(trip, n_q, base, gen, again, false);
+        if (ok) {
+            items.swap(gen);
+            sh = again;
+        }
+        return ok;
+    };
+    if (fit <= size_t(SQ_QUAD_PAD))
+        return general_instead();
+    const int tile_max = (int)std::min<size_t>(512, fit - SQ_QUAD_PAD);
+    // the tile for `c` copies of an item: a multiple of c.  Regular items (sq_quad_frame_regular): the row stride is
+    // a template argument, so the tile is one of the instantiated sizes
+    auto tile_for = [&](int c) {
+        if (regular) {
+            for (int cand : {80, 64, 48, 32, 16})   // 3 * tile fill tasks <= one per thread (96, 128: measured slower)
+                if (cand <= tile_max && cand % c == 0)
+                    return cand;
+            return 0;
+        }
+        const int t = tile_max / c * c;
+        return t >= 16 ? t : 0;
+    };
+    // Items per block and copies per item.  A block's threads run in lockstep: per tile of the particles a thread
+    // spends ~149 instructions on each of its tile / c particles (idle threads cost what busy ones do) and ~150 on
+    // the tile itself (its share of the table fill, the pipeline's prologue, the barrier) — C3's counters: 5.37
+    // instructions per 64 terms against 4.66 in the particle loop, 5 particles per tile.  Take the split of the
+    // items over blocks that minimises blocks * (149 / c + 150 / tile): e.g. 95 items with tiles of 32 go to 3
+    // blocks x 32 items x 8 copies instead of one block of 128 slots x 2 copies with 33 of them idle.
+    double best = 0.0;
+    sh.ipb = 0;
+    for (int nb = 1; nb <= sh.n_items; ++nb) {
+        const int ipb = (sh.n_items + nb - 1) / nb;
+        if (ipb > SQ_QUAD_THREADS)
+            continue;
+        const int blocks = (sh.n_items + ipb - 1) / ipb;
+        int c = SQ_QUAD_THREADS / ipb, tile = 0;
+        while (c >= 1 && !(tile = tile_for(c)))
+            --c;
+        if (c >= 1) {
+            const double cost = blocks * (149.0 / c + 150.0 / tile);
+            if (!sh.ipb || cost < best * (1.0 - 1e-9)) {
+                best = cost;
+                sh.ipb = ipb;
+                sh.n_sub = c;
+                sh.lat = lat_use;
+                sh.lat.tile = tile;
+            }
+        }
+        if (ipb == 1)
+            break;
+    }
+    if (!sh.ipb)
+        return general_instead();
+    sh.regular_stride = regular ? sh.lat.tile + SQ_QUAD_PAD : 0;
+    sh.lds = std::max<size_t>(size_t(32) * (sh.lat.tile + SQ_QUAD_PAD) * total_r + 256, size_t(32) * 1024);
     return true;
 }
 

@@ -42,6 +42,10 @@ while time.time() < t_end:
     cases += 1
     L = rng.uniform(8.0, 40.0, 3) if rng.random() < 0.6 else np.full(3, rng.uniform(8.0, 40.0))
     lo = [int(rng.integers(-12, 1)) for _ in range(3)]
+    if rng.random() < 0.45:
+        # the reference's own grids (n = arange(n_points), structure.py:1376-1381) and q_max-filtered subsets of them:
+        # m >= 0, the sets the aligned-block (regular) quad items serve
+        lo = [0, 0, 0] if rng.random() < 0.8 else [int(rng.integers(0, 4)) for _ in range(3)]
     hi = [int(l + rng.integers(1, 14)) for l in lo]
     axes = [2 * np.pi * np.arange(l, h) / x for l, h, x in zip(lo, hi, L)]
     q = np.stack(np.meshgrid(*axes, indexing="ij"), -1).reshape(-1, 3)
