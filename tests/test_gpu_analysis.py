@@ -159,6 +159,33 @@ def test_structure_factor_reference_default_grid_of_32_points():
         assert np.all(np.abs(sf.results.ssf[i] - ref["ssf"][i]) <= bound), i
 
 
+def test_structure_factor_q_max_keeps_a_sphere_octant_of_the_grid():
+    """``q_max`` (structure.py:1412-1414) keeps the grid wavevectors with |q| <= q_max — a sphere octant: the
+    regular quad items built from aligned blocks, entries outside the sphere dropped.  Element-wise against
+    oracle/fourier.py on the kept wavevectors, ``mode=None`` and ``"partial"``, raw and folded."""
+    rng = np.random.default_rng(35)
+    L = float(np.float32(29.7))
+    n1, n2 = 1500, 1100
+    frames = (rng.random((3, n1 + n2, 3)) * L).astype(np.float32)
+    u = mdhelper_amd.ArrayUniverse(frames, [L, L, L, 90, 90, 90])
+    groups = (u.atoms[:n1], u.atoms[n1:])
+    q_all = of.grid_wavevectors([L, L, L], 24)
+    q_max = 0.55 * np.linalg.norm(q_all, axis=1).max() / np.sqrt(3.0) * 1.7     # inside the cube's faces and beyond
+    q = q_all[np.linalg.norm(q_all, axis=1) <= q_max]
+    assert 1000 < len(q) < len(q_all)
+    raw_ref = of.ssf_run_ref(frames.astype(np.float64), [n1, n2], q, mode="partial", sort=False, unique=False)
+    raw = StructureFactor(groups, n_points=24, q_max=q_max, mode="partial", sort=False, unique=False).run()
+    assert np.array_equal(raw._wavevectors, q)
+    ref, got = raw_ref["ssf"], raw.results.ssf
+    for i, (j, k) in enumerate(raw_ref["pairs"]):
+        bound = (1e-6 * np.abs(ref[i]) if j == k else 1e-6 * np.sqrt(ref[0] * ref[2])) + 1e-9
+        assert np.all(np.abs(got[i] - ref[i]) <= bound), (i, float(np.abs(got[i] - ref[i]).max()))
+    ref = of.ssf_run_ref(frames.astype(np.float64), [n1 + n2], q, mode=None)
+    sf = StructureFactor(u.atoms, n_points=24, q_max=q_max).run()
+    assert np.allclose(sf.results.wavenumbers, ref["wavenumbers"], rtol=1e-12, atol=0)
+    assert np.all(np.abs(sf.results.ssf[0] - ref["ssf"][0]) <= 1e-6 * np.abs(ref["ssf"][0]) + 1e-9)
+
+
 def test_structure_factor_bragg_peaks():
     n, a = 6, 1.5
     L = n * a

@@ -641,6 +641,16 @@ def test_sq_column_form_equals_lattice_and_general_kernels(monkeypatch):
             "21 x 21 x 9 grid (more than 256 items: several blocks)":
                 np.stack(np.meshgrid(2 * np.pi * np.arange(-10, 11) / L[0], 2 * np.pi * np.arange(-10, 11) / L[1],
                                      2 * np.pi * np.arange(0, 9) / L[2], indexing="ij"), -1).reshape(-1, 3),
+            # the reference's grids and their q_max subsets (m >= 0: structure.py:1376-1381, 1412-1414): regular quad
+            # items from aligned 4 x 8 blocks, entries outside the set dropped; item counts that are no power of two
+            "full 10^3 grid (rows padded to 12 / 16)": grid_of(0, 10),
+            "octant sphere of the 12^3 grid (q_max)": (lambda g: g[np.linalg.norm(g, axis=1) <= 2.2])(grid_of(0, 12)),
+            "octant sphere of the 20^3 grid (several blocks)":
+                (lambda g: g[np.linalg.norm(g, axis=1) <= 3.4])(grid_of(0, 20)),
+            "grid from m = 2 (tables start at m = 0)": grid_of(2, 9),
+            "5 x 9 x 17 grid (95 items, unequal axes)":
+                np.stack(np.meshgrid(2 * np.pi * np.arange(0, 5) / L[0], 2 * np.pi * np.arange(0, 9) / L[1],
+                                     2 * np.pi * np.arange(0, 17) / L[2], indexing="ij"), -1).reshape(-1, 3),
             "sphere |q| < 0.5": grid[np.linalg.norm(grid, axis=1) < 0.5],
             "sphere of the 13^3 grid": big[np.linalg.norm(big, axis=1) < 1.1],
             "ragged columns": grid[rng.random(len(grid)) < 0.6]}
