@@ -392,8 +392,7 @@ __device__ __forceinline__ SqQuadThread sq_quad_thread(const SqQuadItem *items, 
 // The regular form of sq_quad_frame (RS > 0: see there).  Beyond the item shape the host guarantees a SIMPLE
 // lattice: every axis has m = 0 ... R - 1 with one R (the reference's grids, n = arange(n_points):
 // structure.py:1376-1381), and lat.tile = RS - SQ_QUAD_PAD.  That makes the table fill branch-free and the same
-// for every lane: task tt of a tile is coordinate tt of its 3 * cnt floats (one coalesced load), rows are written
-// at byte strides of ROW, and the coordinates are FETCHED A TILE AHEAD — the fill of tile n + 1 runs on values
+// for every lane: a task is one (particle, axis) of the tile, rows are written at byte strides of ROW, and the coordinates are FETCHED A TILE AHEAD — the fill of tile n + 1 runs on values
 // loaded before tile n - 1's particle loop, so no wave waits for memory between two tiles (the general fill loads
 // its coordinate, its axis' base, mmin and R per lane and runs per-lane trip counts: ~175 instructions and one
 // memory latency per tile and thread against ~100 and none here).  E(m) is the same chain of products as in
@@ -413,55 +412,48 @@ __device__ __forceinline__ void sq_quad_frame_regular(double2 *lat_tab, const Sq
     // a thread's fill tasks (row offset in a set, its axis' base) and read streams are formed once and pinned: left
     // to rematerialise them inside the tile loop the compiler pairs the prefetched coordinate's register with an
     // address product and waits for the load a tile early
-    int fo[NT];
-    double fb[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int tt = tid + SQ_QUAD_THREADS * j, a = tt / 3, k = tt - 3 * a;
-        fo[j] = (k * R * RS + a) * 16;
-        fb[j] = k == 0 ? lat.base[0] : k == 1 ? lat.base[1] : lat.base[2];
-        asm volatile("" : "+v"(fo[j]));
-        asm volatile("" : "+v"(fb[j]));
-    }
+    // the fill task of a thread: particle fa of the tile, axis fk — AXIS-major (task = fk * A + fa), so that the
+    // lanes of a ds_write_b128 group write consecutive entries of one row: particle-major tasks (fa = task / 3)
+    // put the three axes of a particle on one bank group, a three-way conflict on every write (nearly all of the
+    // 0.9 conflict cycles per 64 terms the counters showed)
+    const int fk = min(tid / A, 2), fa = tid - (tid / A) * A;
+    const bool filler = tid < 3 * A;
+    int fo = (fk * R * RS + fa) * 16;
+    double fb = fk == 0 ? lat.base[0] : fk == 1 ? lat.base[1] : lat.base[2];
+    asm volatile("" : "+v"(fo));
+    asm volatile("" : "+v"(fb));
     int px0 = t.o0[0], py0 = t.o1[0], pz0 = t.oz[0];
     asm volatile("" : "+v"(px0), "+v"(py0), "+v"(pz0));
     SinCosScalars sincos;
     sincos.pin();
-    float xa[NT], xb[NT];
-    // coordinates of the tile at `base` (cnt >= 1 particles); lanes past its end re-read the last one
+    float xa, xb = 0.0f;
+    // the thread's coordinate of the tile at `base` (cnt >= 1 particles); lanes past its end re-read the last particle
     auto fetch = [&](int64_t base, int cnt) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int64_t at = base * 3 + min(tid + SQ_QUAD_THREADS * j, 3 * cnt - 1);
-            xa[j] = P[at];
-            if (Pprev)
-                xb[j] = Pprev[at];
-        }
+        const int64_t at = (base + min(fa, cnt - 1)) * 3 + fk;
+        xa = P[at];
+        if (Pprev)
+            xb = Pprev[at];
     };
     auto fill = [&](int set_bytes, int cnt) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int tt = tid + SQ_QUAD_THREADS * j;
-            if (tt < 3 * cnt) {
-                double x = (double)xa[j];
-                if (Pprev)
-                    x -= (double)xb[j];
-                const double theta = fb[j] * x;
-                double s1, c1;
-                sincos.eval(theta, s1, c1);
-                char *row = tab + (set_bytes + fo[j]);
-                *reinterpret_cast<double2 *>(row) = make_double2(1.0, 0.0);
-                double er = c1, ei = s1;
+        if (filler && fa < cnt) {
+            double x = (double)xa;
+            if (Pprev)
+                x -= (double)xb;
+            const double theta = fb * x;
+            double s1, c1;
+            sincos.eval(theta, s1, c1);
+            char *row = tab + (set_bytes + fo);
+            *reinterpret_cast<double2 *>(row) = make_double2(1.0, 0.0);
+            double er = c1, ei = s1;
+            row += ROW;
+            *reinterpret_cast<double2 *>(row) = make_double2(er, ei);
+#pragma unroll 2
+            for (int m = 2; m < R; ++m) {
+                const double nr = fma(er, c1, -ei * s1), ni = fma(er, s1, ei * c1);
+                er = nr;
+                ei = ni;
                 row += ROW;
                 *reinterpret_cast<double2 *>(row) = make_double2(er, ei);
-#pragma unroll 2
-                for (int m = 2; m < R; ++m) {
-                    const double nr = fma(er, c1, -ei * s1), ni = fma(er, s1, ei * c1);
-                    er = nr;
-                    ei = ni;
-                    row += ROW;
-                    *reinterpret_cast<double2 *>(row) = make_double2(er, ei);
-                }
             }
         }
     };
