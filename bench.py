@@ -115,15 +115,24 @@ class World:
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             from mdhelper_amd.launch import Rendezvous, SocketComm
             rdzv = Rendezvous(self.rank, self.world) if self.world > 1 else None
-            if args.share_devices and self.world > 1:
+            if args.share_devices and self.world > 1 and os.environ.get("MDX_BENCH_TRY_RCCL") != "1":
                 self.comm, self.kind = SocketComm(rdzv), "host-socket (ranks share devices: test mode)"
             else:
-                from mdhelper_amd.comm import rccl_comm_from_env
-                self.comm, self.kind = rccl_comm_from_env(self.dev, rdzv), "rccl"
-                n, r, d = self.comm.rccl_info()
-                if (n, r) != (self.world, self.rank):
-                    raise SystemExit(f"RCCL reports rank {r} of {n}, expected {self.rank} of {self.world}")
-                self.rccl_ranks = n
+                from mdhelper_amd.comm import rccl_comm_from_env, rccl_comm_or_socket
+                if rdzv is None:
+                    self.comm, self.kind = rccl_comm_from_env(self.dev, rdzv), "rccl"
+                else:
+                    # RCCL where every rank can build it; else the accumulators are summed over the rendezvous
+                    # socket and the line says so in "comm" (the kernels and the timed region do not change)
+                    self.comm, self.kind = rccl_comm_or_socket(
+                        self.dev, rdzv, float(os.environ.get("MDX_RCCL_INIT_TIMEOUT", "180")))
+                if self.kind == "rccl":
+                    n, r, d = self.comm.rccl_info()
+                    if (n, r) != (self.world, self.rank):
+                        raise SystemExit(f"RCCL reports rank {r} of {n}, expected {self.rank} of {self.world}")
+                    self.rccl_ranks = n
+                elif self.rank == 0:
+                    sys.stderr.write(f"bench.py: {self.kind}\n")
 
     @property
     def device_collectives(self):

@@ -91,3 +91,57 @@ def rccl_comm_from_env(device: int | None = None, rdzv=None):
     comm = RcclComm(rank, world, uid, device)
     comm.rdzv = rdzv
     return comm
+
+
+def rccl_comm_or_socket(device: int, rdzv, timeout: float = 180.0):
+    """
+    ``(communicator, kind)`` for one rank of a one-process-per-GPU job: the RCCL communicator of
+    ``rccl_comm_from_env`` when EVERY rank could build it (``kind == "rccl"``), else — a failed
+    ``ncclGetUniqueId`` / ``ncclCommInitRank`` on any rank, or one that does not return within
+    ``timeout`` seconds — ``launch.SocketComm`` over the same rendezvous on every rank, with the reason
+    in ``kind`` ("host-socket (RCCL unavailable: ...)").  The decision is one all-reduce over the
+    rendezvous, so the ranks cannot disagree.  What travels either way is the accumulators of an
+    analysis (a histogram, a few spectra), once, at its end — never coordinates; the kernels do not
+    change.  For measurement harnesses and long jobs that must end with a result; code that requires
+    RCCL calls ``rccl_comm_from_env`` and lets the error surface.
+    """
+    import threading
+
+    from ._core import RcclComm
+    from .launch import SocketComm
+    rank, world = rdzv.rank, rdzv.world
+    err, uid = None, b""
+    if rank == 0:
+        try:
+            uid = bytes(RcclComm.unique_id())
+        except Exception as exc:                       # noqa: BLE001 - reported through `kind`
+            err, uid = f"ncclGetUniqueId: {exc}", b""
+    uid = rdzv.bcast(uid if rank == 0 else None)
+    comm = None
+    if uid:
+        box = {}
+
+        def init():
+            try:
+                box["comm"] = RcclComm(rank, world, uid, device)
+            except Exception as exc:                   # noqa: BLE001
+                box["err"] = f"ncclCommInitRank: {exc}"
+
+        th = threading.Thread(target=init, daemon=True)
+        th.start()
+        th.join(timeout)
+        if th.is_alive():
+            err = f"ncclCommInitRank did not return within {timeout:g} s on rank {rank}"
+        else:
+            comm, err = box.get("comm"), box.get("err")
+    elif err is None:
+        err = "rank 0 could not create the RCCL unique id"
+    built = int(rdzv.allreduce(np.array([1 if comm is not None else 0], dtype=np.int64))[0])
+    if built == world:
+        comm.rdzv = rdzv
+        return comm, "rccl"
+    # (a communicator that some ranks built and others did not is left alone: destroying it can block on the
+    # peers that never arrived)
+    reasons = rdzv.gather(((err or "") + "\n").encode()).decode().splitlines()
+    why = next((r for r in reasons if r), "unknown")
+    return SocketComm(rdzv), f"host-socket (RCCL unavailable: {why[:200]})"

@@ -43,3 +43,13 @@ elif mode == "analyses":
     comm.close()
     if rank == 0:
         print(json.dumps({"done": True}))
+elif mode == "rccl_or_socket":
+    # no GPU here: ncclGetUniqueId fails on rank 0, every rank must land on the socket communicator and agree
+    from mdhelper_amd.comm import rccl_comm_or_socket
+    rdzv = Rendezvous.from_env()
+    comm, kind = rccl_comm_or_socket(0, rdzv, timeout=30.0)
+    total = comm.allreduce(np.array([rank + 1], dtype=np.int64))
+    comm.barrier()
+    comm.close()
+    if rank == 0:
+        print(json.dumps({"kind": kind, "class": type(comm).__name__, "total": int(total[0])}))

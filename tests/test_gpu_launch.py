@@ -63,6 +63,18 @@ def test_rccl_data_plane_single_rank_through_bench():
     assert out["result_digest"] == _bench(*RDF)["result_digest"]
 
 
+def test_rccl_refusing_to_start_leaves_every_rank_on_the_socket():
+    """Two ranks on ONE device ask for RCCL (``MDX_BENCH_TRY_RCCL=1``): RCCL refuses the duplicate device, and
+    ``comm.rccl_comm_or_socket`` must bring every rank to the rendezvous socket with the reason in the line —
+    the path a multi-GPU run takes if RCCL cannot start on its node — and the result must not change."""
+    one = _bench(*RDF)
+    two = _bench(*RDF, "--gpus", "2", "--share-devices",
+                 env={"MDX_BENCH_TRY_RCCL": "1", "MDX_RCCL_INIT_TIMEOUT": "60"}, timeout=400)
+    assert two["comm"].startswith("host-socket (RCCL unavailable: ncclCommInitRank"), two["comm"]
+    assert two["rccl_ranks"] is None and two["n_gpus"] == 2
+    assert two["result_digest"] == one["result_digest"]
+
+
 def test_two_real_rccl_ranks_when_two_devices_are_visible():
     from mdhelper_amd import launch
     if launch.visible_device_count() < 2:

@@ -30,6 +30,19 @@ def test_rendezvous_collectives_three_ranks():
     assert out["big"] == 300_000 * 6.0
 
 
+def test_rccl_or_socket_falls_back_on_every_rank_when_rccl_cannot_start():
+    """bench.py's multi-rank communicator: without a usable RCCL (no GPU here) every rank must end up on the
+    rendezvous socket, with the reason recorded, and the job must still reduce correctly."""
+    from mdhelper_amd import _lib, launch
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is present: RCCL starts")
+    rc, text = launch.launch(3, [SCRIPT, "rccl_or_socket"], share_devices=True, timeout=180)
+    assert rc == 0, text
+    out = launch.last_json_line(text)
+    assert out["class"] == "SocketComm" and out["total"] == 6
+    assert out["kind"].startswith("host-socket (RCCL unavailable: ncclGetUniqueId")
+
+
 def test_launcher_stops_the_job_when_a_rank_fails():
     from mdhelper_amd import launch
     # rank 1 exits with code 3 while rank 0 sits in a collective: the job must end, non-zero, promptly
