@@ -128,6 +128,36 @@ def rdf_entry(tag, workload, frames, atoms=None):
     return out
 
 
+def rdf_requests(tag, workload, frames, atoms=None):
+    """Bytes the RDF kernels move between L2 and the fabric, from the REQUEST counters (sizes known per request:
+    no correction factor): a cross-check of the FETCH_SIZE / WRITE_SIZE figures, whose prescribed doubling of
+    FETCH_SIZE is calibrated on wide coalesced streams — not what a cell-sorted gather looks like."""
+    args = ["--workload", workload, "--frames", str(frames), "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+            "--no-extras"] + (["--atoms", str(atoms)] if atoms else [])
+    out = collections.defaultdict(dict)
+    line, res, calls, dur = run_pmc(tag + "_req", ["TCC_EA0_RDREQ", "TCC_EA0_RDREQ_32B", "TCC_EA0_RDREQ_64B",
+                                                   "TCC_EA0_RDREQ_128B"], args)
+    for k in res:
+        if "rdf_" in k:
+            r = res[k]
+            other = r["TCC_EA0_RDREQ"] - r["TCC_EA0_RDREQ_32B"] - r["TCC_EA0_RDREQ_64B"] - r["TCC_EA0_RDREQ_128B"]
+            out[k.split("(")[0][-40:]]["read_bytes_per_frame"] = (
+                32.0 * r["TCC_EA0_RDREQ_32B"] + 64.0 * (r["TCC_EA0_RDREQ_64B"] + max(other, 0.0))
+                + 128.0 * r["TCC_EA0_RDREQ_128B"]) / frames
+            out[k.split("(")[0][-40:]]["read_requests_per_frame"] = r["TCC_EA0_RDREQ"] / frames
+    line, res, calls, dur = run_pmc(tag + "_req", ["TCC_EA0_WRREQ", "TCC_EA0_WRREQ_64B"], args)
+    for k in res:
+        if "rdf_" in k:
+            r = res[k]
+            out[k.split("(")[0][-40:]]["write_bytes_per_frame"] = (
+                64.0 * r["TCC_EA0_WRREQ_64B"] + 32.0 * (r["TCC_EA0_WRREQ"] - r["TCC_EA0_WRREQ_64B"])) / frames
+            out[k.split("(")[0][-40:]]["write_requests_per_frame"] = r["TCC_EA0_WRREQ"] / frames
+    total = sum(v.get("read_bytes_per_frame", 0.0) + v.get("write_bytes_per_frame", 0.0) for v in out.values())
+    return dict(by_kernel=dict(out), bytes_per_frame=total,
+                source=f"profiles/{ROUND}_{tag}_req_TCC_EA0_*_pmc.csv: 32 / 64 / 128-byte read requests, 64-byte and "
+                       f"partial (counted as 32-byte) write requests at the L2 - fabric interface")
+
+
 def sq_entry(tag):
     """fp64 instruction mix of the S(q) kernel per 64 phase terms, and the clock it ran at."""
     args = ["--workload", "sq", "--steps", "2", "--warmup", "0", "--no-cpu-baseline"]
@@ -208,7 +238,7 @@ def msd_entry(tag):
 
 
 def main():
-    which = sys.argv[1:] or ["rdf_c2", "rdf_wide", "rdf_c5", "rdf_c1", "sq_c3", "msd_c4", "msd_tcc", "stats"]
+    which = sys.argv[1:] or ["rdf_c2", "rdf_wide", "rdf_c5", "rdf_c1", "rdf_req", "sq_c3", "msd_c4", "msd_tcc", "stats"]
     path = os.path.join(OUT, "counters.json")
     data = {}
     if os.path.exists(os.path.join(ROOT, "profiles", "counters.json")):
@@ -225,6 +255,8 @@ def main():
         data["rdf_c5"] = rdf_entry("rdf_c5", "rdf", 250, atoms=131072)
     if "rdf_c1" in which:                          # C1-like: 1 000 atoms, range (0, L/2): the brute-force tile kernel
         data["rdf_c1"] = rdf_entry("rdf_c1", "rdf_wide", 20000, atoms=1000)
+    if "rdf_req" in which and "rdf_c2" in data:   # request-level cross-check of the C2(i) traffic figure
+        data["rdf_c2"]["hbm_requests"] = rdf_requests("rdf_c2", "rdf", 2000)
     if "sq_c3" in which:
         data["sq_c3"] = sq_entry("sq_c3")
     if "msd_c4" in which:
