@@ -161,13 +161,22 @@ struct StagePipeline {
     void destroy();
     // fill(b, f0, nf): queue on copy_stream what brings items [f0, f0+nf) into staging set b;
     // consume(b, f0, nf): queue on `compute` the kernels that read staging set b.
+    // ramp > 1: the first slabs are slab / 4 and slab / 2 items, rounded down to multiples of `ramp` — the first
+    // fill is the one nothing hides, and large slabs (which the consumer wants: fewer, longer launches) make it long
     template <typename Fill, typename Consume>
-    int run(hipStream_t compute, int64_t n_items, int64_t slab, Fill fill, Consume consume)
+    int run(hipStream_t compute, int64_t n_items, int64_t slab, Fill fill, Consume consume, int64_t ramp = 0)
     {
         MDX_TRY(ensure());
         slab = slab < 1 ? 1 : slab;
-        for (int64_t f0 = 0, k = 0; f0 < n_items; f0 += slab, ++k) {
-            const int64_t nf = n_items - f0 < slab ? n_items - f0 : slab;
+        int64_t step = slab;
+        for (int64_t f0 = 0, k = 0; f0 < n_items; f0 += step, ++k) {
+            step = slab;
+            if (ramp > 1 && k < 2) {
+                const int64_t part = (slab >> (2 - k)) / ramp * ramp;
+                if (part >= ramp)
+                    step = part;
+            }
+            const int64_t nf = n_items - f0 < step ? n_items - f0 : step;
             const int b = int(k & 1);
             if (busy[b]) {
                 MDX_HIP(hipEventSynchronize(ev_consumed[b]));

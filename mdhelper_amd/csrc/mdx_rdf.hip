@@ -461,10 +461,15 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
     const int64_t slab_bytes = slab_env ? std::max<int64_t>(1, atoll(slab_env)) : (int64_t(1) << 30);
     int64_t slab = std::max<int64_t>(1, slab_bytes / per_frame);
     slab = std::min<int64_t>(std::min<int64_t>(slab, 32768), n_frames);
-    // two sets of the sorted copies when there is more than one slab: the sort of the next slab runs beside
-    // the pair kernel of this one (MDX_RDF_NO_OVERLAP=1: one set, one stream).  Sizes in float4 elements.
-    const bool no_overlap = getenv("MDX_RDF_NO_OVERLAP") != nullptr;
-    const int n_sets = (!no_overlap && slab < n_frames) ? 2 : 1;
+    // One set of the sorted copies, sort and pair kernel on one stream.  MDX_RDF_OVERLAP=1: two sets when there
+    // is more than one slab, the sort of the next slab on a stream of its own beside the pair kernel of this one —
+    // the default of round 2 (+1 % then).  With PERSISTENT pair blocks it loses: the pair kernel holds every wave
+    // slot of the chip until its last items, so the sort's 1 024-thread blocks trickle in behind retiring blocks
+    // and the next pair kernel waits for them anyway; C2(i): pair kernel 17.12 ms per launch alone + 0.62 ms of sort
+    // against 17.89 ms with the sort beside it (45.4 k against 44.1 k frames/s on one box, round 3).  Sizes in
+    // float4 elements.
+    const bool overlap = getenv("MDX_RDF_OVERLAP") != nullptr && getenv("MDX_RDF_NO_OVERLAP") == nullptr;
+    const int n_sets = (overlap && slab < n_frames) ? 2 : 1;
     // exclusion 0 or 1: a particle's tag is its row, and the exact path reads the frames as they came in —
     // no sorted copy of the original coordinates (half of the sort kernel's scattered stores)
     const bool lazy_orig = !tri && h->excl1 <= 1 && h->excl2 <= 1 && !getenv("MDX_RDF_SORTED_ORIGINALS");
@@ -1001,10 +1006,13 @@ template <typename Fill, typename Prepare>
 static int accumulate_pipelined(mdx_rdf *h, int64_t n1, int64_t n2, bool same, const float *boxes,
                                 int64_t n_frames, int64_t source_bytes_per_frame, Fill fill, Prepare prepare)
 {
-    // slabs of ~128 MiB: each slab is one sort + one pair launch on the compute stream, and the sort (one block per
-    // frame, latency-bound, ~0.5 ms per round of 512 frames) cannot run beside the persistent pair kernel, so
-    // small slabs pay it again and again; a multiple of 8 frames, so that every XCD gets the same number
-    int64_t slab = std::max<int64_t>(1, (int64_t(128) << 20) / source_bytes_per_frame);
+    // slabs of ~256 MiB (MDX_RDF_PIPE_MB), the first two a quarter and a half of that: each slab is one sort + one
+    // pair launch on the compute stream; the persistent pair kernel ends on a tail of about one item per block
+    // (2 % of a launch of 336 frames at C2, 0.7 % of one of 1 000) and the sort cannot run beside it, so longer
+    // launches are worth more than finer overlap; a multiple of 8 frames, so that every XCD gets the same number
+    const char *mb_env = getenv("MDX_RDF_PIPE_MB");
+    const int64_t pipe_mb = mb_env ? std::min<long long>(std::max<long long>(atoll(mb_env), 1), 4096) : 256;
+    int64_t slab = std::max<int64_t>(1, (pipe_mb << 20) / source_bytes_per_frame);
     if (slab >= 8)
         slab -= slab % 8;
     slab = std::min<int64_t>(n_frames, slab);
@@ -1028,7 +1036,8 @@ static int accumulate_pipelined(mdx_rdf *h, int64_t n1, int64_t n2, bool same, c
                                      same ? nullptr : h->d_stage2[b].as<float>(), n2,
                                      boxes ? h->d_boxes[b].as<float>() : nullptr,
                                      boxes ? boxes + f0 * 6 : nullptr, nf);
-        });
+        },
+        8);
 }
 
 extern "C" {

@@ -8,13 +8,14 @@ O=gpurun_out/final
 timeout -k 10 700 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1
 rc=$?; tail -3 $O/pytest_gpu.log; echo "pytest rc=$rc"
 if [ $rc -ne 0 ]; then exit $rc; fi
-timeout -k 10 1100 python scripts/make_counters.py > $O/make_counters.log 2>&1 || { tail -20 $O/make_counters.log; exit 1; }
+timeout -k 10 1150 python scripts/make_counters.py > $O/make_counters.log 2>&1 || { tail -20 $O/make_counters.log; exit 1; }
 cp gpurun_out/counters/counters.json profiles/counters.json
 echo counters done
 timeout -k 10 300 python bench.py > $O/bench_final.json 2> $O/bench_final.err || { tail -5 $O/bench_final.err; exit 1; }
 timeout -k 10 200 python bench.py --workload msd --steps 20 --no-cpu-baseline > $O/bench_msd_20steps.json 2>/dev/null || exit 1
 timeout -k 10 200 python bench.py --workload msd --blocks 8 --steps 10 --no-cpu-baseline > $O/bench_msd8.json 2>/dev/null || exit 1
 timeout -k 10 200 python bench.py --workload isf > $O/bench_isf.json 2>/dev/null || exit 1
+timeout -k 10 200 python bench.py --workload sq --steps 10 --warmup 2 > $O/bench_sq_c3.json 2>/dev/null || exit 1
 timeout -k 10 200 python bench.py --workload sq --n-points 32 --frames 200 --steps 3 > $O/bench_sq_default_grid.json 2>/dev/null || exit 1
 timeout -k 10 300 python bench.py --atoms 131072 --frames 1000 --steps 2 --no-extras > $O/bench_c5size.json 2>/dev/null || exit 1
 timeout -k 10 200 python bench.py --workload rdf_wide --atoms 1000 --frames 20000 --steps 3 --no-extras > $O/bench_c1like.json 2>/dev/null || exit 1
