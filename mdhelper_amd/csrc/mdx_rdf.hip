@@ -458,9 +458,14 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
     const int64_t per_frame = (32 + 1 + CHUNK_BOX_BYTES) * (n1p + (self ? 0 : n2p));
     // (MDX_RDF_SLAB_BYTES: test hook, so that small inputs run through several slabs and both sets)
     const char *slab_env = getenv("MDX_RDF_SLAB_BYTES");
-    const int64_t slab_bytes = slab_env ? std::max<int64_t>(1, atoll(slab_env)) : (int64_t(1) << 30);
+    const int64_t slab_bytes = slab_env ? std::max<int64_t>(1, atoll(slab_env)) : (int64_t(5) << 28);   // 1.25 GiB
     int64_t slab = std::max<int64_t>(1, slab_bytes / per_frame);
-    slab = std::min<int64_t>(std::min<int64_t>(slab, 32768), n_frames);
+    slab = std::min<int64_t>(slab, 32768);
+    // whole rounds of the sort kernel: one 1 024-thread block per frame, one (gather form) or two blocks per CU —
+    // 993 frames were 3.9 rounds of 256 CUs and took 4
+    if (slab >= 256)
+        slab -= slab % 256;
+    slab = std::min<int64_t>(slab, n_frames);
     // One set of the sorted copies, sort and pair kernel on one stream.  MDX_RDF_OVERLAP=1: two sets when there
     // is more than one slab, the sort of the next slab on a stream of its own beside the pair kernel of this one —
     // the default of round 2 (+1 % then).  With PERSISTENT pair blocks it loses: the pair kernel holds every wave
@@ -569,13 +574,20 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
         {
             if (n_sets == 2 && k_slab >= 2)   // the pair kernel that read this set two slabs ago
                 MDX_HIP(hipStreamWaitEvent(s_sort, h->ev_paired[set], 0));
-            auto sort = tri ? rdf_cell_sort_kernel<true> : rdf_cell_sort_kernel<false>;
+            // frames of at most SORT_PERM_MAX particles: the gather form (rows written as whole lines);
+            // MDX_RDF_SORT_SCATTER=1 keeps the scatter form for them too
+            const bool scatter_only = getenv("MDX_RDF_SORT_SCATTER") != nullptr;
+            auto sort_of = [&](int64_t n) {
+                if (n <= SORT_PERM_MAX && !scatter_only)
+                    return tri ? rdf_cell_sort_gather_kernel<true> : rdf_cell_sort_gather_kernel<false>;
+                return tri ? rdf_cell_sort_kernel<true> : rdf_cell_sort_kernel<false>;
+            };
             const float *cells = tri ? d_tri + f0 * 9 : d_boxes + f0 * 6;
-            hipLaunchKernelGGL(sort, dim3((unsigned)nf), dim3(SORT_THREADS), 0, s_sort,
+            hipLaunchKernelGGL(sort_of(n1), dim3((unsigned)nf), dim3(SORT_THREADS), 0, s_sort,
                                d_pos1 + f0 * n1 * 3, cells, (int)n1, (int)n1p, excl ? h->excl1 : 0,
                                pw1, po1, bb1, bc1, d_maxabs);
             if (!self)
-                hipLaunchKernelGGL(sort, dim3((unsigned)nf), dim3(SORT_THREADS), 0, s_sort,
+                hipLaunchKernelGGL(sort_of(n2), dim3((unsigned)nf), dim3(SORT_THREADS), 0, s_sort,
                                    d_pos2 + f0 * n2 * 3, cells, (int)n2, (int)n2p,
                                    excl ? h->excl2 : 0, pw2, po2, bb2, bc2, d_maxabs);
             if (n_sets == 2) {
