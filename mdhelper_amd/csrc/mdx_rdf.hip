@@ -461,7 +461,7 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
     const int64_t slab_bytes = slab_env ? std::max<int64_t>(1, atoll(slab_env)) : (int64_t(5) << 28);   // 1.25 GiB
     int64_t slab = std::max<int64_t>(1, slab_bytes / per_frame);
     slab = std::min<int64_t>(slab, 32768);
-    // whole rounds of the sort kernel: one 1 024-thread block per frame, one (gather form) or two blocks per CU —
+    // whole rounds of the sort kernel: one 1 024-thread block per frame, one block per CU (65 VGPRs) —
     // 993 frames were 3.9 rounds of 256 CUs and took 4
     if (slab >= 256)
         slab -= slab % 256;
@@ -574,20 +574,20 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
         {
             if (n_sets == 2 && k_slab >= 2)   // the pair kernel that read this set two slabs ago
                 MDX_HIP(hipStreamWaitEvent(s_sort, h->ev_paired[set], 0));
-            // frames of at most SORT_PERM_MAX particles: the gather form (rows written as whole lines);
-            // MDX_RDF_SORT_SCATTER=1 keeps the scatter form for them too
-            const bool scatter_only = getenv("MDX_RDF_SORT_SCATTER") != nullptr;
-            auto sort_of = [&](int64_t n) {
-                if (n <= SORT_PERM_MAX && !scatter_only)
-                    return tri ? rdf_cell_sort_gather_kernel<true> : rdf_cell_sort_gather_kernel<false>;
-                return tri ? rdf_cell_sort_kernel<true> : rdf_cell_sort_kernel<false>;
-            };
+            // (Measured and dropped, round 3: the sort as a GATHER — slots noted per particle in LDS, rows written
+            // in slot order as whole lines — 0.66 ms per 1 000 frames against 0.74–0.82, +0.5 % on the step, but its
+            // 12-byte reads scattered over frames that are no longer in L2 fetch 4.0 MB per frame where the scatter's
+            // partial-sector stores cost 1.1: 6.5 MB per frame in all against 4.4.  Neither two blocks per CU (the
+            // kernel sits at 65 VGPRs: one over), float32 cell keys, a DPP box reduction nor a two-barrier scan moved
+            // the kernel's time: all 256 blocks of a round read, then write, in step — 25 µs counting from HBM, 81 µs
+            // writing rows — and the memory system sets the pace.)
+            auto sort = tri ? rdf_cell_sort_kernel<true> : rdf_cell_sort_kernel<false>;
             const float *cells = tri ? d_tri + f0 * 9 : d_boxes + f0 * 6;
-            hipLaunchKernelGGL(sort_of(n1), dim3((unsigned)nf), dim3(SORT_THREADS), 0, s_sort,
+            hipLaunchKernelGGL(sort, dim3((unsigned)nf), dim3(SORT_THREADS), 0, s_sort,
                                d_pos1 + f0 * n1 * 3, cells, (int)n1, (int)n1p, excl ? h->excl1 : 0,
                                pw1, po1, bb1, bc1, d_maxabs);
             if (!self)
-                hipLaunchKernelGGL(sort_of(n2), dim3((unsigned)nf), dim3(SORT_THREADS), 0, s_sort,
+                hipLaunchKernelGGL(sort, dim3((unsigned)nf), dim3(SORT_THREADS), 0, s_sort,
                                    d_pos2 + f0 * n2 * 3, cells, (int)n2, (int)n2p,
                                    excl ? h->excl2 : 0, pw2, po2, bb2, bc2, d_maxabs);
             if (n_sets == 2) {

@@ -127,15 +127,6 @@ struct CellGrid {
         c = min(max((int)(wd * invLd[k] * nc[k]), 0), nc[k] - 1);
         return w;
     }
-    // The cell of a coordinate in float32 arithmetic: which cell a particle is counted in only decides its place in
-    // the sorted order (the boxes come from the wrapped coordinates themselves), so the two passes that need the
-    // cell alone — count and slot — can do without the exact fp64 wrap, as long as they agree with each other.
-    __device__ inline int cell_f32(float x, int k) const
-    {
-        float u = x * (1.0f / Lf[k]);
-        u -= floorf(u);
-        return min(max((int)(u * (float)nc[k]), 0), nc[k] - 1);
-    }
     __device__ inline int key(int cx, int cy, int cz) const
     {
         // columns in a serpentine (boustrophedon) path through x, y; the layers of a column run up or down in
@@ -196,10 +187,8 @@ struct TriCell {
     }
 };
 
-// (eight waves per SIMD = two blocks per CU, which the 68 KB of LDS allow: at 65 VGPRs — one over — the kernel ran
-// one block per CU, 256 frames per round of the chip instead of 512)
 template <bool TRI>
-__global__ __launch_bounds__(SORT_THREADS, 8) void rdf_cell_sort_kernel(
+__global__ __launch_bounds__(SORT_THREADS) void rdf_cell_sort_kernel(
     const float *__restrict__ pos, const float *__restrict__ boxes, int n, int n_pad, int64_t excl,
     float4 *__restrict__ pw, float4 *__restrict__ po, float4 *__restrict__ bb,
     float4 *__restrict__ bb16, unsigned *maxabs_bits)
@@ -342,211 +331,6 @@ __global__ __launch_bounds__(SORT_THREADS, 8) void rdf_cell_sort_kernel(
         if (lane == 0) {
             BB[2 * t] = make_float4(lo[0], lo[1], lo[2], 0.f);
             BB[2 * t + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
-        }
-    }
-}
-
-// The same sort for frames of at most SORT_PERM_MAX particles, written as a GATHER: the counting pass and the scan are
-// those of rdf_cell_sort_kernel; the second pass hands out the slots and only notes, per slot, which particle goes
-// there (perm[], 2 bytes per slot in LDS; both passes find the cell in float32, CellGrid::cell_f32 — the exact fp64
-// wrap is done once per particle, when its row is written); the third pass walks the SLOTS — thread s reads particle perm[s] (a 12-byte
-// read scattered over a frame that sits in L2 by then), wraps it and writes row s.  Rows leave as whole lines: the
-// scatter's 16-byte stores, each to a line of its own, were 1.13 MB written per frame for 0.52 MB of rows and what
-// bounded that kernel (its time did not change between one and two resident blocks per CU).  A wave's 64 slots are
-// one tile, so its bounding box is a reduction over the values in registers — nothing is read back.  Particles take
-// the same slots as in the scatter form (the order inside a cell is the order of the atomics in both).
-constexpr int SORT_PERM_MAX = 40960;
-
-// min or max over the 64 lanes of a wave, valid in lane 63, by DPP (row shifts inside the rows of 16 lanes, then the
-// two row broadcasts of GFX9): six VALU instructions per value and nothing through the LDS pipe — the bounding boxes of
-// a frame are 3 072 such reductions, and as __shfl_xor butterflies (ds_bpermute) they were the largest single cost
-// of the sort kernel.
-template <bool MAX> __device__ __forceinline__ float cell_wave_reduce_to_lane63(float v)
-{
-#define MDX_DPP_STEP(CTRL, ROWS, BANKS)                                                                       \
-    {                                                                                                         \
-        const float t = __int_as_float(                                                                       \
-            __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROWS, BANKS, false));     \
-        v = MAX ? fmaxf(v, t) : fminf(v, t);                                                                  \
-    }
-    MDX_DPP_STEP(0x111, 0xf, 0xf)   // row_shr:1
-    MDX_DPP_STEP(0x112, 0xf, 0xf)   // row_shr:2
-    MDX_DPP_STEP(0x114, 0xf, 0xf)   // row_shr:4
-    MDX_DPP_STEP(0x118, 0xf, 0xf)   // row_shr:8   -> lane 15 of a row holds the row
-    MDX_DPP_STEP(0x142, 0xa, 0xf)   // row_bcast:15 into rows 1 and 3
-    MDX_DPP_STEP(0x143, 0xc, 0xf)   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave
-#undef MDX_DPP_STEP
-    return v;
-}
-
-template <bool TRI>
-__global__ __launch_bounds__(SORT_THREADS) void rdf_cell_sort_gather_kernel(
-    const float *__restrict__ pos, const float *__restrict__ boxes, int n, int n_pad, int64_t excl,
-    float4 *__restrict__ pw, float4 *__restrict__ po, float4 *__restrict__ bb,
-    float4 *__restrict__ bb16, unsigned *maxabs_bits)
-{
-    __shared__ unsigned cnt[CELL_MAX];
-    __shared__ unsigned part[SORT_THREADS];
-    __shared__ unsigned short perm[SORT_PERM_MAX];
-    const int tid = threadIdx.x;
-    const int frame = blockIdx.x;
-    const float *P = pos + int64_t(frame) * n * 3;
-    float4 *PW = pw + int64_t(frame) * n_pad;
-    float4 *PO = po + int64_t(frame) * n_pad;
-    CellGrid g;
-    TriCell tc;
-    if (TRI) {
-        tc.init(boxes + int64_t(frame) * 9);
-        const float hb[3] = {(float)tc.h[0], (float)tc.h[1], (float)tc.h[2]};
-        g.init(hb, n);
-    } else {
-        g.init(boxes + int64_t(frame) * 6, n);
-    }
-    const int ncell = g.n_cells();
-    for (int c = tid; c < ncell; c += SORT_THREADS)
-        cnt[c] = 0u;
-    __syncthreads();
-
-    // wrapped position and cell key of particle a
-    auto place = [&](int a, float &wx, float &wy, float &wz, float &ox, float &oy, float &oz) {
-        float x = P[3 * a], y = P[3 * a + 1], z = P[3 * a + 2];
-        int cx, cy, cz;
-        if (TRI) {
-            tc.wrap(x, y, z, wx, wy, wz);
-            tc.cell(wx, wy, wz, g.nc, cx, cy, cz);
-            ox = wx, oy = wy, oz = wz;   // the contract evaluates the wrapped positions
-        } else {
-            wx = g.wrap(x, 0, cx), wy = g.wrap(y, 1, cy), wz = g.wrap(z, 2, cz);
-            ox = x, oy = y, oz = z;
-        }
-        return g.key(cx, cy, cz);
-    };
-
-    // the cell key alone (count and slot passes): float32 for rectangular cells, the exact path for triclinic ones;
-    // (ox, oy, oz) = the coordinates the filter's bound is taken on
-    auto key_of = [&](int a, float &ox, float &oy, float &oz) {
-        if (TRI) {
-            float wx, wy, wz;
-            return place(a, wx, wy, wz, ox, oy, oz);
-        }
-        ox = P[3 * a], oy = P[3 * a + 1], oz = P[3 * a + 2];
-        return g.key(g.cell_f32(ox, 0), g.cell_f32(oy, 1), g.cell_f32(oz, 2));
-    };
-
-    float m = 0.0f;
-#pragma unroll 4
-    for (int a = tid; a < n; a += SORT_THREADS) {
-        float ox, oy, oz;
-        const int key = key_of(a, ox, oy, oz);
-        atomicAdd(&cnt[key], 1u);
-        // (the bound is on the coordinates the filter sees: as they came in, or wrapped for triclinic frames)
-        float am = fmaxf(fabsf(ox), fmaxf(fabsf(oy), fabsf(oz)));
-        m = fmaxf(m, am == am ? am : __int_as_float(0x7f800000));
-    }
-    {
-        unsigned bits = __float_as_uint(m);
-        for (int off = 32; off > 0; off >>= 1)
-            bits = max(bits, (unsigned)__shfl_xor((int)bits, off));
-        if ((tid & 63) == 0)
-            part[tid >> 6] = bits;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        unsigned bits = 0u;
-        for (int w = 0; w < SORT_THREADS / 64; ++w)
-            bits = max(bits, part[w]);
-        if (bits)
-            atomicMax(maxabs_bits, bits);
-    }
-    __syncthreads();
-
-    // exclusive scan of cnt[0..ncell): each thread owns a contiguous run
-    const int per = (ncell + SORT_THREADS - 1) / SORT_THREADS;
-    const int c0 = tid * per, c1 = min(c0 + per, ncell);
-    unsigned local = 0;
-    for (int c = c0; c < c1; ++c)
-        local += cnt[c];
-    // scan of the threads' sums: inside the wave by lane shifts, across the sixteen waves through part[] — two
-    // barriers where the doubling scan over 1 024 threads had twenty
-    unsigned incl = local;
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned v = (unsigned)__shfl_up((int)incl, off);
-        if ((tid & 63) >= off)
-            incl += v;
-    }
-    if ((tid & 63) == 63)
-        part[tid >> 6] = incl;
-    __syncthreads();
-    unsigned before = 0;
-    for (int w = 0; w < (tid >> 6); ++w)
-        before += part[w];
-    unsigned run = before + incl - local;
-    for (int c = c0; c < c1; ++c) {
-        unsigned v = cnt[c];
-        cnt[c] = run;
-        run += v;
-    }
-    __syncthreads();
-
-    // slots: the cursor of a cell hands them out; the slot remembers its particle
-#pragma unroll 4
-    for (int a = tid; a < n; a += SORT_THREADS) {
-        float ox, oy, oz;
-        const int key = key_of(a, ox, oy, oz);
-        perm[atomicAdd(&cnt[key], 1u)] = (unsigned short)a;
-    }
-    __syncthreads();
-
-    // rows in slot order; a wave's 64 slots are one tile
-    const int lane = tid & 63;
-    const int n_tiles = n_pad / 64;
-    float4 *BB = bb + int64_t(frame) * n_tiles * 2;
-    const float qnan = __int_as_float(0x7fc00000), inf = __int_as_float(0x7f800000);
-#pragma unroll 2
-    for (int s = tid; s < n_pad; s += SORT_THREADS) {
-        float4 w = make_float4(qnan, qnan, qnan, __int_as_float(-1)), o = w;
-        if (s < n) {
-            const int a = perm[s];
-            float wx, wy, wz, ox, oy, oz;
-            (void)place(a, wx, wy, wz, ox, oy, oz);
-            const float tag = __int_as_float(excl > 0 ? int(int64_t(a) / excl) : a);
-            w = make_float4(wx, wy, wz, tag);
-            o = make_float4(ox, oy, oz, tag);
-        }
-        PW[s] = w;
-        if (po)
-            PO[s] = o;
-        const bool ok = s < n;
-        float lo[3] = {ok ? w.x : inf, ok ? w.y : inf, ok ? w.z : inf};
-        float hi[3] = {ok ? w.x : -inf, ok ? w.y : -inf, ok ? w.z : -inf};
-        if (CELL_CHUNK >= 4) {
-            for (int off = 1; off < 64; off <<= 1) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
-                    hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
-                }
-                if (off == CELL_CHUNK / 2 && (lane & (CELL_CHUNK - 1)) == 0) {
-                    float4 *BB16 = bb16 + int64_t(frame) * n_tiles * 2 * CELL_NCHUNK;
-                    const int c = (s / 64) * CELL_NCHUNK + lane / CELL_CHUNK;
-                    BB16[c * 2] = make_float4(lo[0], lo[1], lo[2], 0.f);
-                    BB16[c * 2 + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
-                }
-            }
-            if (lane == 0) {
-                BB[2 * (s / 64)] = make_float4(lo[0], lo[1], lo[2], 0.f);
-                BB[2 * (s / 64) + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                lo[k] = cell_wave_reduce_to_lane63<false>(lo[k]);
-                hi[k] = cell_wave_reduce_to_lane63<true>(hi[k]);
-            }
-            if (lane == 63) {
-                BB[2 * (s / 64)] = make_float4(lo[0], lo[1], lo[2], 0.f);
-                BB[2 * (s / 64) + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
-            }
         }
     }
 }
