@@ -81,6 +81,37 @@ def test_rdf_from_file_universe_bit_exact(tmp_path, kind):
     assert np.array_equal(a.results.counts, b.results.counts)
 
 
+def test_rdf_host_and_file_pipelines_through_ramped_slabs(tmp_path, monkeypatch):
+    """The staging pipeline of mdx_rdf_accumulate / mdx_rdf_accumulate_traj with slabs of 1 MiB: 300 frames of
+    1 100 atoms go through slabs of 16, 32, 72, 72, 72 and 36 frames (the first two a quarter and a half of a slab:
+    StagePipeline::run's ramp), alternating between the two staging sets; counts equal those of plain calls."""
+    monkeypatch.setenv("MDX_RDF_PIPE_MB", "1")
+    F, N, L = 300, 1100, 22.0
+    pos = _frames(F, N, L, 31)
+    lengths = np.full((F, 3), L, dtype=np.float32)
+    dims = np.hstack([lengths, np.full((F, 3), 90.0, dtype=np.float32)])
+    edges = np.linspace(0.0, 9.0, 91)
+    eng = _core.RdfEngine(edges, (1, 1))
+    eng.accumulate(pos[:7], None, dims[:7])            # one small call first: the ring and the sets exist
+    eng.reset()
+    eng.accumulate(pos, None, dims)                    # host pipeline, six slabs
+    host_counts = eng.counts()
+    eng.close()
+    monkeypatch.delenv("MDX_RDF_PIPE_MB")
+    eng = _core.RdfEngine(edges, (1, 1))
+    for f0 in range(0, F, 100):                        # three plain calls (one slab each)
+        eng.accumulate(pos[f0:f0 + 100], None, dims[f0:f0 + 100])
+    want = eng.counts()
+    eng.close()
+    assert want.sum() > 0 and np.array_equal(host_counts, want)
+    monkeypatch.setenv("MDX_RDF_PIPE_MB", "1")
+    path = tmp_path / "ramp.nc"
+    write_amber_netcdf(path, pos, lengths)
+    uf = mdhelper_amd.FileUniverse(path)
+    got = RadialDistributionFunction(uf.atoms, n_bins=90, range=(0.0, 9.0), exclusion=(1, 1)).run()
+    assert np.array_equal(got.results.counts, want)
+
+
 def test_structure_factor_and_isf_from_file_universe(tmp_path):
     from mdhelper_amd.analysis import IntermediateScatteringFunction, StructureFactor
     from oracle import fourier as of
