@@ -458,7 +458,9 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
     const int64_t per_frame = (32 + 1 + CHUNK_BOX_BYTES) * (n1p + (self ? 0 : n2p));
     // (MDX_RDF_SLAB_BYTES: test hook, so that small inputs run through several slabs and both sets)
     const char *slab_env = getenv("MDX_RDF_SLAB_BYTES");
-    const int64_t slab_bytes = slab_env ? std::max<int64_t>(1, atoll(slab_env)) : (int64_t(5) << 28);   // 1.25 GiB
+    // (2.5 GiB = 2 048 frames at C2: the persistent kernel ends on a tail of about one item per block and the sort
+    // between two launches is serial, so long launches pay: 1 024 frames 45.3 k, 2 048 45.6–45.8 k, 4 096 45.7 k frames/s)
+    const int64_t slab_bytes = slab_env ? std::max<int64_t>(1, atoll(slab_env)) : (int64_t(5) << 29);
     int64_t slab = std::max<int64_t>(1, slab_bytes / per_frame);
     slab = std::min<int64_t>(slab, 32768);
     // whole rounds of the sort kernel: one 1 024-thread block per frame, one block per CU (65 VGPRs) —
