@@ -698,14 +698,18 @@ def bench_isf(args, world):
         "config": {"workload": f"ISF {N} atoms, {len(q)} wavevectors, 2 groups (partial), {n_lags} lags, "
                                f"coherent + incoherent, {F} frames/GPU/step" + (" from host memory" if args.host_path else "")},
         "frames_per_sec": args.steps * F * world.world / dt,
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "isf_incoherent_quads_kernel + sq_rho_quads_kernel + isf_coherent_kernel",
-                     "note": "fp64 VALU bound like S(q): two FMAs per displacement term, four per rho term",
-                     "valu": {"evaluations_per_sec_kernel": per_step / max(kernel_s, 1e-9),
-                              # 2.5 v_fma_f64-class wave-instructions per 64 displacement terms
-                              "fp64_issue_bound_frac_est": per_step / max(kernel_s, 1e-9) * 2.5 / 64 * 4.76
-                                                           / (1024 * 2.4e9)}},
+        # fp64 VALU bound like S(q): 2.5 FMA-class wave-instructions per 64 displacement terms (two FMAs per term,
+        # half a column product), 4.5 per 64 rho terms; a wave64 fp64 instruction takes 4 cycles on a SIMD
+        "roofline": (lambda issue: {
+            "bound": "valu", "unit": "G SIMD issue cycles/s", "achieved": issue / 1e9, "peak": 1024 * 2.4,
+            "frac": issue / (1024 * 2.4e9), "traffic": None,
+            "kernel": "isf_incoherent_quads_kernel + sq_rho_quads_kernel + isf_coherent_kernel",
+            "definition": "(displacement terms x 2.5 + rho terms x 4.5) / 64 fp64 wave-instructions x 4 cycles per "
+                          "second of kernel time / (1024 SIMDs x 2.4 GHz nominal)",
+            "evaluations_per_sec_kernel": per_step / max(kernel_s, 1e-9),
+            "hbm": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_step": alg}})(
+            float(N) * len(q) * (lagged * 2.5 + F * 4.5) / 64.0 * 4.0 / max(kernel_s, 1e-9)),
         "checksum": float(cisf.sum() + iisf.sum()),
     }
     if world.rank == 0 and world.world == 1 and not args.no_cpu_baseline:
