@@ -57,6 +57,15 @@ int mdx_free(int dev, void *dptr);
 int mdx_memcpy_h2d(int dev, void *dst, const void *src, size_t bytes);
 int mdx_memcpy_d2h(int dev, void *dst, const void *src, size_t bytes);
 int mdx_memset(int dev, void *dst, int value, size_t bytes);
+/* Host memory -> HBM at the rate of the host-buffer entry points: page-locked / registered memory by one DMA
+ * where it lies, pageable memory through the library's pinned ring with its copy threads (mdx_memcpy_h2d is
+ * the runtime's own single-threaded staging).  Returns when the data is in HBM. */
+int mdx_upload(int dev, void *d_dst, const void *src, size_t bytes);
+/* Destroyed handles leave their device blocks in a per-device cache (at most 4 GiB, blocks up to 512 MiB) so
+ * that an analysis object per call does not pay hipMalloc / hipFree each time; the cache is given back
+ * automatically when an allocation of the library fails (handles' buffers, mdx_malloc) and here on request
+ * (e.g. before another library allocates).  freed_bytes may be NULL. */
+int mdx_trim_cache(int dev, size_t *freed_bytes);
 int mdx_device_synchronize(int dev);
 /* Page-lock a caller buffer (e.g. the float32[n_frames][n][3] array an MDAnalysis memory reader
  * holds — what `universe.trajectory[frame].positions` views, reference structure.py:753,796) so
@@ -350,6 +359,16 @@ int mdx_msd_push_f64(mdx_msd_t h, int group, const double *pos, int64_t n_frames
                      int unwrap, const double *dims, int zero_dims, const double *shift);
 int mdx_msd_system_com_f64(mdx_msd_t h, const double *pos, int64_t n_frames, int64_t n_sel,
                            const double *masses, int unwrap, const double *dims, int wrap, double *out);
+/* ... and for frames already resident in HBM (a GPU MD engine's output, or a host / file trajectory uploaded
+ * once for several groups: mdx_upload, mdx_traj_load_device): d_pos float32 (elem_bytes 4) or float64 (8)
+ * [n_frames][n_total][3]; index: host int32[n_index] rows of the selection in analysis order, or NULL for
+ * the first n_index rows (<= 0: all).  Nothing is staged or copied: the frame-preparation kernels gather. */
+int mdx_msd_push_frames_device(mdx_msd_t h, int group, const void *d_pos, int elem_bytes, int64_t n_frames,
+                               int64_t n_total, const int32_t *index, int64_t n_index, int unwrap,
+                               const double *dims, int zero_dims, const double *shift);
+int mdx_msd_system_com_device(mdx_msd_t h, const void *d_pos, int elem_bytes, int64_t n_frames,
+                              int64_t n_total, const int32_t *index, int64_t n_index, const double *masses,
+                              int unwrap, const double *dims, int wrap, double *out);
 /* With a grouping declared (mdx_msd_set_grouping) both mdx_msd_system_com_* variants return the
  * centre of mass of the molecules' CENTRES (wrapped into the box first when wrap != 0), each
  * weighted with its molecule's mass: Onsager(center=True, center_atom=False, center_wrap=True)

@@ -38,6 +38,19 @@ class DeviceArray:
         check(lib().mdx_memcpy_h2d(dev, out.ptr, _ptr(arr), arr.nbytes))
         return out
 
+    @classmethod
+    def upload(cls, arr, dev: int = 0):
+        """Large host arrays: through the library's pinned ring and its copy threads, or by one DMA
+        when the array is page-locked (``mdx_upload``)."""
+        arr = np.ascontiguousarray(arr)
+        out = cls(arr.shape, arr.dtype, dev)
+        try:
+            check(lib().mdx_upload(dev, out.ptr, _ptr(arr), arr.nbytes))
+        except Exception:
+            out.free()
+            raise
+        return out
+
     def to_host(self, first: int = 0, count: int | None = None):
         """Copy rows [first, first+count) of the leading axis back to the host."""
         n0 = self.shape[0]
@@ -53,6 +66,19 @@ class DeviceArray:
         row = self.nbytes // max(self.shape[0], 1)
         return c_void_p(self.ptr.value + first * row)
 
+    def rows(self, first: int, count: int):
+        """Rows [first, first+count) of the leading axis as a DeviceArray that does not own its memory
+        (valid as long as this one is)."""
+        if not 0 <= first <= first + count <= self.shape[0]:
+            raise IndexError("rows out of range")
+        view = object.__new__(_DeviceView)
+        view.shape = (int(count),) + self.shape[1:]
+        view.dtype, view.dev = self.dtype, self.dev
+        view.nbytes = self.nbytes // max(self.shape[0], 1) * int(count)
+        view.ptr = self.offset(first)
+        view.base = self
+        return view
+
     def free(self):
         if getattr(self, "ptr", None) is not None and self.ptr.value:
             lib().mdx_free(self.dev, self.ptr)
@@ -63,6 +89,13 @@ class DeviceArray:
             self.free()
         except Exception:
             pass
+
+
+class _DeviceView(DeviceArray):
+    """Non-owning window into a DeviceArray (``DeviceArray.rows``)."""
+
+    def free(self):
+        self.ptr = c_void_p()
 
 
 def device_info(dev: int = 0):
@@ -426,6 +459,7 @@ class MsdEngine(_Engine):
         self.handle = h
         self.dev = dev
         self.t_block, self.n_blocks, self.n_groups = int(n_frames_block), int(n_blocks), int(n_groups)
+        self.has_grouping = False
         if timing:
             check(lib().mdx_msd_enable_timing(h, 1))
 
@@ -449,6 +483,7 @@ class MsdEngine(_Engine):
         """Rows of the following ``push_traj`` calls are particles of molecules
         ``[offsets[g], offsets[g+1])``; the engine receives their float64 centres of mass.
         ``offsets=None`` removes the grouping (``mdx_msd_set_grouping``)."""
+        self.has_grouping = offsets is not None
         if offsets is None:
             check(lib().mdx_msd_set_grouping(self.handle, 0, None, None))
             return
@@ -491,6 +526,30 @@ class MsdEngine(_Engine):
         fn = lib().mdx_msd_system_com_f64 if f64 else lib().mdx_msd_system_com_f32
         check(fn(self.handle, _ptr(p), p.shape[0], p.shape[1], _ptr(m), 0 if unwrap_dims is None else 1,
                  _ptr(d), 0 if wrap_dims is None else 1, _ptr(out)))
+        return out
+
+    def push_frames_device(self, group, d_pos, n_total, index=None, *, unwrap_dims=None, zero_dims=0,
+                           shift=None):
+        """A group's positions out of frames resident in HBM (``DeviceArray`` float32 / float64
+        ``[T, n_total, 3]``): rows ``index`` (None: all) gathered by the frame-preparation kernels
+        (``mdx_msd_push_frames_device``)."""
+        i = None if index is None else np.ascontiguousarray(index, dtype=np.int32)
+        d = None if unwrap_dims is None else np.ascontiguousarray(unwrap_dims, dtype=np.float64)[:3]
+        sh = None if shift is None else np.ascontiguousarray(shift, dtype=np.float64)
+        check(lib().mdx_msd_push_frames_device(
+            self.handle, group, d_pos.ptr, d_pos.dtype.itemsize, d_pos.shape[0], int(n_total), _ptr(i),
+            0 if i is None else len(i), 0 if d is None else 1, _ptr(d), zero_dims, _ptr(sh)))
+
+    def system_com_device(self, d_pos, n_total, index, masses, *, unwrap_dims=None, wrap_dims=None):
+        """float64[T, 3] system centre of mass per frame of HBM-resident frames."""
+        i = None if index is None else np.ascontiguousarray(index, dtype=np.int32)
+        m = np.ascontiguousarray(masses, dtype=np.float64)
+        dims = unwrap_dims if unwrap_dims is not None else wrap_dims
+        d = None if dims is None else np.ascontiguousarray(dims, dtype=np.float64)[:3]
+        out = np.empty((d_pos.shape[0], 3), dtype=np.float64)
+        check(lib().mdx_msd_system_com_device(
+            self.handle, d_pos.ptr, d_pos.dtype.itemsize, d_pos.shape[0], int(n_total), _ptr(i), len(m),
+            _ptr(m), 0 if unwrap_dims is None else 1, _ptr(d), 0 if wrap_dims is None else 1, _ptr(out)))
         return out
 
     def system_com_traj(self, traj_file, frames, index, masses, *, unwrap_dims=None, wrap_dims=None):

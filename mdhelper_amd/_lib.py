@@ -42,6 +42,8 @@ _SIGNATURES = {
     "mdx_memcpy_h2d": (c_int, [c_int, _vp, _vp, c_size_t]),
     "mdx_memcpy_d2h": (c_int, [c_int, _vp, _vp, c_size_t]),
     "mdx_memset": (c_int, [c_int, _vp, c_int, c_size_t]),
+    "mdx_upload": (c_int, [c_int, _vp, _vp, c_size_t]),
+    "mdx_trim_cache": (c_int, [c_int, POINTER(c_size_t)]),
     "mdx_device_synchronize": (c_int, [c_int]),
     "mdx_host_register": (c_int, [c_int, _vp, c_size_t]),
     "mdx_host_unregister": (c_int, [c_int, _vp]),
@@ -128,6 +130,10 @@ _SIGNATURES = {
     "mdx_msd_set_initial_images": (c_int, [_vp, _vp, c_int64]),
     "mdx_msd_result_acf": (c_int, [_vp, _vp]),
     "mdx_msd_system_com_traj": (c_int, [_vp, _vp, _vp, c_int64, _vp, c_int64, _vp, c_int, _vp, c_int, _vp]),
+    "mdx_msd_push_frames_device": (c_int, [_vp, c_int, _vp, c_int, c_int64, c_int64, _vp, c_int64, c_int, _vp,
+                                           c_int, _vp]),
+    "mdx_msd_system_com_device": (c_int, [_vp, _vp, c_int, c_int64, c_int64, _vp, c_int64, _vp, c_int, _vp,
+                                          c_int, _vp]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

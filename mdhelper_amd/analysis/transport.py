@@ -363,12 +363,33 @@ class Onsager(SerialAnalysisBase):
         if self._fft:
             eng = _core.MsdEngine(Tb, B, self._n_groups, dev=self._device)
             if self._from_file:
-                # frames stream file -> pinned memory -> HBM; unwrapping and the float64
-                # widening happen on the device (mdx_msd_push_traj)
+                # The analysed frames are brought into HBM ONCE (trajectory file -> pinned ring -> HBM;
+                # host memory through the ring's copy threads, or by DMA where it is page-locked; a
+                # DeviceTrajectory is there already) and every group, and the system centre of mass, is
+                # prepared from them on the device: particle gather, unwrapping, float64 widening,
+                # molecule centres, shift (mdx_msd_push_frames_device).  Frames that would not leave room
+                # for the engine stream group by group instead (mdx_msd_push_traj / _f32).
                 numbers = self._frame_numbers()[:self._n_frames]
                 native = getattr(self._trajectory, "native", None)
                 unwrap_dims = self._dimensions if self._unwrap else None
-                if native is not None:
+                resident = self._resident_frames(numbers, native)
+                if resident is not None:
+                    n_total = resident.shape[1]
+
+                    def system_com(rows, masses, **kw):
+                        return eng.system_com_device(resident, n_total, rows, masses, **kw)
+
+                    def push(g, rows, **kw):
+                        if (resident.dtype == np.float64 and not eng.has_grouping and kw.get("shift") is None
+                                and kw.get("unwrap_dims") is None and len(rows)
+                                and np.array_equal(rows, np.arange(rows[0], rows[0] + len(rows)))):
+                            # float64 frames in HBM, a contiguous range of particles, nothing to prepare:
+                            # the correlation kernels read them where they lie
+                            eng.push_device(g, resident.ptr, n_total, int(rows[0]), len(rows),
+                                            kw.get("zero_dims", 0))
+                        else:
+                            eng.push_frames_device(g, resident, n_total, rows, **kw)
+                elif native is not None:
                     def system_com(rows, masses, **kw):
                         return eng.system_com_traj(native, numbers, rows, masses, **kw)
 
@@ -385,9 +406,12 @@ class Onsager(SerialAnalysisBase):
                         eng.push_f32(g, block[:, rows], **kw)
                 def start_images(rows):
                     # image flags the rows start from (molecules made whole in the first frame)
+                    # (the reference's first unwrap call moves a flag by sign(x - x_whole) only, reference
+                    # topology.py:366-376: a particle k >= 2 images away from its made-whole place starts at
+                    # +-1 like the host path's, not at k)
                     if self._unwrap:
                         eng.set_initial_images(None if self._images0 is None else
-                                               self._images0 if rows is None else self._images0[rows])
+                                               np.sign(self._images0 if rows is None else self._images0[rows]))
 
                 shift = None
                 if self._center:
@@ -435,6 +459,9 @@ class Onsager(SerialAnalysisBase):
                         rows = idx[off[lo]:off[hi]]
                     start_images(rows)
                     push(g, rows, unwrap_dims=unwrap_dims, zero_dims=zero_mask, shift=shift)
+                if resident is not None and getattr(resident, "base", None) is None:
+                    _core.synchronize(self._device)
+                    resident.free()
             for g, own in enumerate(self._own_slices):
                 if own.stop > own.start and not self._from_file:
                     eng.push(g, self._positions, own.start, own.stop - own.start, zero_mask)
@@ -480,6 +507,33 @@ class Onsager(SerialAnalysisBase):
         self.results.msd_cross /= D
         self.results.msd_self /= D
 
+    _hbm_share = 0.3    # of the free HBM the analysed float32 frames may take to be kept whole
+
+    def _resident_frames(self, numbers, native):
+        """The analysed frames as ONE device array ``[T, n_atoms, 3]`` (float32, or the float64 of a
+        DeviceTrajectory), or None when they would take more than 30 % of the free HBM (or particles
+        shard across ranks from host memory: a rank then stages its own rows only)."""
+        traj = self._trajectory
+        dev = self._device
+        if hasattr(traj, "device_block"):
+            view = traj.device_block(numbers)
+            if view is not None:
+                return view
+        elif self._comm.world_size > 1:
+            return None
+        need = len(numbers) * traj.n_atoms * 12
+        if self._hbm_share <= 0 or need > self._hbm_share * _core.device_info(dev)["hbm_free_bytes"]:
+            return None
+        if native is not None:
+            out = _core.DeviceArray((len(numbers), traj.n_atoms, 3), np.float32, dev)
+            try:
+                native.load_device(numbers, out.ptr, dev=dev)
+            except Exception:
+                out.free()
+                raise
+            return out
+        return _core.DeviceArray.upload(traj.frame_block(numbers), dev)
+
     # in-memory trajectories, plain atom groups: copy the positions in one vectorised step
     def run(self, start=None, stop=None, step=None, frames=None, n_jobs: int = 1, verbose=None,
             **kwargs):
@@ -489,15 +543,11 @@ class Onsager(SerialAnalysisBase):
         # of mass and the removal of the system centre of mass (of atoms, of group particles, or of
         # the wrapped molecule centres) happen on the device
         native = getattr(traj, "native", None) is not None
-        # ... and in-memory float32 frames (what an MDAnalysis reader delivers) or float64 frames take
-        # the same device stages whenever there is something to prepare
-        stored = getattr(traj, "_positions", None)
-        f32_array = (not native and hasattr(traj, "frame_block") and stored is not None
-                     and stored.dtype in (np.float32, np.float64)
-                     and (self._unwrap or self._center or not atoms_only))
-        self._from_file = bool(self._fft and (native or f32_array))
-        fast = hasattr(traj, "frame_block") and (self._from_file or (
-            atoms_only and not (self._unwrap or self._center)))
+        # ... and so do in-memory frames (what an MDAnalysis memory reader holds) and frames resident in HBM
+        batched = hasattr(traj, "frame_block") or hasattr(traj, "device_block")
+        self._from_file = bool(self._fft and (native or batched))
+        fast = self._from_file or (hasattr(traj, "frame_block") and atoms_only
+                                   and not (self._unwrap or self._center))
         if not fast:
             return super().run(start=start, stop=stop, step=step, frames=frames, n_jobs=n_jobs,
                                verbose=verbose, **kwargs)

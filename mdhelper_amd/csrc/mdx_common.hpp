@@ -169,25 +169,35 @@ struct StagePipeline {
         MDX_TRY(ensure());
         slab = slab < 1 ? 1 : slab;
         int64_t step = slab;
-        for (int64_t f0 = 0, k = 0; f0 < n_items; f0 += step, ++k) {
-            step = slab;
-            if (ramp > 1 && k < 2) {
-                const int64_t part = (slab >> (2 - k)) / ramp * ramp;
-                if (part >= ramp)
-                    step = part;
+        // an error exit waits for the copy stream too: a DMA out of caller memory queued by an earlier fill
+        // must not be in flight after the call has returned
+        auto body = [&]() -> int {
+            for (int64_t f0 = 0, k = 0; f0 < n_items; f0 += step, ++k) {
+                step = slab;
+                if (ramp > 1 && k < 2) {
+                    const int64_t part = (slab >> (2 - k)) / ramp * ramp;
+                    if (part >= ramp)
+                        step = part;
+                }
+                const int64_t nf = n_items - f0 < step ? n_items - f0 : step;
+                const int b = int(k & 1);
+                if (busy[b]) {
+                    MDX_HIP(hipEventSynchronize(ev_consumed[b]));
+                    busy[b] = false;
+                }
+                MDX_TRY(fill(b, f0, nf));
+                MDX_HIP(hipEventRecord(ev_filled[b], copy_stream));
+                MDX_HIP(hipStreamWaitEvent(compute, ev_filled[b], 0));
+                MDX_TRY(consume(b, f0, nf));
+                MDX_HIP(hipEventRecord(ev_consumed[b], compute));
+                busy[b] = true;
             }
-            const int64_t nf = n_items - f0 < step ? n_items - f0 : step;
-            const int b = int(k & 1);
-            if (busy[b]) {
-                MDX_HIP(hipEventSynchronize(ev_consumed[b]));
-                busy[b] = false;
-            }
-            MDX_TRY(fill(b, f0, nf));
-            MDX_HIP(hipEventRecord(ev_filled[b], copy_stream));
-            MDX_HIP(hipStreamWaitEvent(compute, ev_filled[b], 0));
-            MDX_TRY(consume(b, f0, nf));
-            MDX_HIP(hipEventRecord(ev_consumed[b], compute));
-            busy[b] = true;
+            return MDX_OK;
+        };
+        const int rc = body();
+        if (rc != MDX_OK) {
+            (void)hipStreamSynchronize(copy_stream);
+            return rc;
         }
         MDX_HIP(hipStreamSynchronize(copy_stream));
         return MDX_OK;

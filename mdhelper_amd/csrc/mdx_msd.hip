@@ -287,6 +287,7 @@ struct mdx_msd {
     // accumulators: power [G][B][nc] + D [G][B*T_b] contiguous (one all-reduce), traj [G][B*T_b][3]
     DeviceBuffer d_acc, d_traj, d_series, d_spec, d_stage, d_inv_in, d_inv_out;
     DeviceBuffer d_f32, d_index, d_prev, d_image;   // trajectory-file path: frames, unwrap state
+    DeviceBuffer d_xstart, d_seg;                   // ... of the segment-parallel walk (msd_launch_unwrap)
     DeviceBuffer d_masses, d_com_x, d_shift;        // system centre of mass per frame
     // trajectory-file path with groupings="residues"/"segments": rows sorted molecule by molecule
     std::vector<int64_t> mol_offsets;               // CSR over the rows of a push_traj call
@@ -399,30 +400,101 @@ static int msd_push_device(mdx_msd *h, int group, const double *d_pos, int64_t n
 // frames of the block in order; the state (x_old, image) persists between blocks.
 // In: float (what an MDAnalysis reader and the trajectory files deliver) or double (in-memory
 // float64 trajectories).
+// Source: `in` holds frames of `in_stride` coordinates; the block's coordinate e = 3 a + k is read at
+// 3 rows[a] + k when `rows` is given (frames resident in HBM, a particle selection) and at e otherwise
+// (a staged block of the selection, in_stride = n_coord).
+//
+// The only state the walk carries from frame to frame is the integer image flag (x_old is the RAW
+// previous coordinate), so the frames of a block are cut into segments of SEG frames that run in
+// parallel: (1) msd_image_delta_kernel — net flag change of every (segment, coordinate); (2)
+// msd_image_scan_kernel — running sum over the segments, from the flag the block starts with; (3)
+// msd_unwrap_widen_kernel — every segment walks its frames from its own starting flag.  Without unwrapping
+// only (3) runs.  The operations on a coordinate are the serial walk's, in its order.
+constexpr int UNWRAP_SEG = 128;
+
 template <typename In>
-__global__ __launch_bounds__(256) void msd_unwrap_widen_kernel(
-    const In *__restrict__ in, int64_t n_coord, int64_t n_frames, int first_block, int unwrap,
-    double lx, double ly, double lz, In *__restrict__ prev, int *__restrict__ image,
-    double *__restrict__ out, const double *__restrict__ shift /* [n_frames][3] or nullptr */)
+__device__ inline int image_step(In x, In x_old, double half)
+{
+    const double d = __dsub_rn((double)x, (double)x_old);
+    return fabs(d) >= half ? (d < 0.0) - (d > 0.0) : 0;
+}
+
+template <typename In>
+__global__ __launch_bounds__(256) void msd_image_delta_kernel(
+    const In *__restrict__ in, int64_t in_stride, const int *__restrict__ rows, int64_t n_coord,
+    int64_t n_frames, int first_block, double lx, double ly, double lz, const In *__restrict__ prev,
+    int *__restrict__ delta /* [n_seg][n_coord] */)
 {
     const int64_t e = blockIdx.x * int64_t(256) + threadIdx.x;
     if (e >= n_coord)
         return;
     const int k = int(e % 3);
+    const int64_t src = rows ? int64_t(rows[e / 3]) * 3 + k : e;
+    const double half = 0.5 * (k == 0 ? lx : (k == 1 ? ly : lz));
+    const int64_t f_lo = int64_t(blockIdx.y) * UNWRAP_SEG;
+    const int64_t f_hi = f_lo + UNWRAP_SEG < n_frames ? f_lo + UNWRAP_SEG : n_frames;
+    In x_old = f_lo > 0 ? in[(f_lo - 1) * in_stride + src] : (first_block ? in[src] : prev[e]);
+    int acc = 0;
+    for (int64_t f = f_lo; f < f_hi; ++f) {
+        const In x = in[f * in_stride + src];
+        acc += image_step(x, x_old, half);
+        x_old = x;
+    }
+    delta[int64_t(blockIdx.y) * n_coord + e] = acc;
+}
+
+// delta[s][e] <- flag segment s starts with; image[e] <- flag after the block; x_start[e] <- the raw
+// coordinate before the block's first frame; prev[e] <- the block's last raw coordinate
+template <typename In>
+__global__ __launch_bounds__(256) void msd_image_scan_kernel(
+    const In *__restrict__ in, int64_t in_stride, const int *__restrict__ rows, int64_t n_coord,
+    int64_t n_frames, int n_seg, int first_block, In *__restrict__ prev, In *__restrict__ x_start,
+    int *__restrict__ image, int *__restrict__ delta)
+{
+    const int64_t e = blockIdx.x * int64_t(256) + threadIdx.x;
+    if (e >= n_coord)
+        return;
+    const int64_t src = rows ? int64_t(rows[e / 3]) * 3 + int(e % 3) : e;
+    // first_block: 1 = the walk starts here without image flags; 2 = it starts here from the flags in
+    // `image` (molecules made whole in the first analysed frame, transport.py:936-941)
+    int img = first_block == 1 ? 0 : image[e];
+    for (int s = 0; s < n_seg; ++s) {
+        const int t = delta[int64_t(s) * n_coord + e];
+        delta[int64_t(s) * n_coord + e] = img;
+        img += t;
+    }
+    image[e] = img;
+    x_start[e] = first_block ? in[src] : prev[e];
+    prev[e] = in[(n_frames - 1) * in_stride + src];
+}
+
+template <typename In>
+__global__ __launch_bounds__(256) void msd_unwrap_widen_kernel(
+    const In *__restrict__ in, int64_t in_stride, const int *__restrict__ rows, int64_t n_coord,
+    int64_t n_frames, int unwrap, double lx, double ly, double lz, const In *__restrict__ x_start,
+    const int *__restrict__ seg_image /* [n_seg][n_coord] */, double *__restrict__ out,
+    const double *__restrict__ shift /* [n_frames][3] or nullptr */)
+{
+    const int64_t e = blockIdx.x * int64_t(256) + threadIdx.x;
+    if (e >= n_coord)
+        return;
+    const int k = int(e % 3);
+    const int64_t src = rows ? int64_t(rows[e / 3]) * 3 + k : e;
     const double L = k == 0 ? lx : (k == 1 ? ly : lz);
     const double half = 0.5 * L;
-    // first_block: 1 = the walk starts here without image flags; 2 = it starts here from the flags in
-    // `image` (molecules made whole in the first analysed frame, transport.py:936-941: the reference's first
-    // unwrap call finds x - x_whole = -k L and sets the flag to k; the flags are given directly here)
-    In x_old = first_block ? in[e] : prev[e];
-    int img = first_block == 1 ? 0 : image[e];
-    for (int64_t f = 0; f < n_frames; ++f) {
-        const In x = in[f * n_coord + e];
+    const int64_t f_lo = int64_t(blockIdx.y) * UNWRAP_SEG;
+    const int64_t f_hi = f_lo + UNWRAP_SEG < n_frames ? f_lo + UNWRAP_SEG : n_frames;
+    In x_old = 0;
+    int img = 0;
+    if (unwrap) {
+        x_old = f_lo > 0 ? in[(f_lo - 1) * in_stride + src] : x_start[e];
+        img = seg_image[int64_t(blockIdx.y) * n_coord + e];
+    }
+    for (int64_t f = f_lo; f < f_hi; ++f) {
+        const In x = in[f * in_stride + src];
         double v = (double)x;
         if (unwrap) {
-            const double d = __dsub_rn(v, (double)x_old);
-            if (fabs(d) >= half)
-                img -= (d > 0.0) - (d < 0.0);
+            img += image_step(x, x_old, half);
             x_old = x;
             v = __dadd_rn(v, __dmul_rn((double)img, L));
         }
@@ -430,8 +502,6 @@ __global__ __launch_bounds__(256) void msd_unwrap_widen_kernel(
             v = __dsub_rn(v, shift[3 * f + k]);
         out[f * n_coord + e] = v;
     }
-    prev[e] = x_old;
-    image[e] = img;
 }
 
 // out[f][k] = sum_a m_a x[f][a][k] / sum_a m_a; wrap != 0: coordinates outside [0, L] are first
@@ -481,12 +551,38 @@ struct FrameSource {
     virtual int elem() const { return 4; }   // bytes per staged coordinate: float32, or float64 frames
     virtual int prepare(mdx_msd *h, int64_t n_sel) = 0;
     virtual int stage(mdx_msd *h, int64_t a0, int64_t c, int64_t f0, int64_t nf, void *d_out) = 0;
+    // frames the unwrap kernel can read where they lie (HBM-resident trajectories): pointer to frame f0,
+    // coordinates per frame, rows of the selection from a0 on (device int32, or nullptr: rows a0, a0+1, ...
+    // are folded into the pointer).  nullptr: the block has to be staged.
+    virtual const void *direct(mdx_msd *, int64_t, int64_t, int64_t *, const int **) { return nullptr; }
+    virtual bool resident() const { return false; }
 };
 
+// frames per unwrap launch: ~64 MB of staged frames, or (resident sources: nothing is staged) as many as the
+// grid's second dimension takes
+static int64_t msd_frame_block(const FrameSource &src, int64_t n_frames, int64_t n_rows)
+{
+    const int64_t most = src.resident() ? int64_t(32768) * UNWRAP_SEG
+                                        : (int64_t(64) << 20) / (int64_t(3) * src.elem() * n_rows);
+    return std::max<int64_t>(1, std::min(n_frames, most));
+}
+
+static int msd_unwrap_buffers(mdx_msd *h, const FrameSource &src, int64_t n_rows, int64_t block)
+{
+    const int64_t row_bytes = int64_t(3) * src.elem();
+    MDX_TRY(h->d_prev.ensure(size_t(n_rows) * row_bytes));
+    MDX_TRY(h->d_xstart.ensure(size_t(n_rows) * row_bytes));
+    MDX_TRY(h->d_image.ensure(size_t(n_rows) * 12));
+    MDX_TRY(h->d_seg.ensure(size_t(ceil_div(block, UNWRAP_SEG)) * n_rows * 12));
+    if (!src.resident())
+        MDX_TRY(h->d_f32.ensure(size_t(block) * n_rows * row_bytes));
+    return MDX_OK;
+}
+
 // unwrap + widen (+ shift) of one staged block of frames, in the block's element type
-static void msd_launch_unwrap(mdx_msd *h, const FrameSource &src, int64_t n_coord, int64_t nf, int first,
+static void msd_launch_unwrap(mdx_msd *h, FrameSource &src, int64_t n_coord, int64_t nf, int first,
                               int unwrap, const double *dims, double *d_out, const double *d_shift,
-                              int64_t a0 = 0);
+                              int64_t a0, int64_t f0);
 
 // a trajectory file: listed frames, listed particles (gathered by the unpack kernel)
 struct TrajFrames final : FrameSource {
@@ -535,9 +631,42 @@ template <typename In> struct HostFrames final : FrameSource {
     }
 };
 
-static void msd_launch_unwrap(mdx_msd *h, const FrameSource &src, int64_t n_coord, int64_t nf, int first,
+// frames resident in HBM: float32 or float64 [n_frames][n_total][3]; selection = listed rows (host int32,
+// uploaded once) or the first n_sel rows.  Nothing is staged: the unwrap kernel gathers.
+struct DeviceFrames final : FrameSource {
+    const void *d_pos;
+    int elem_bytes;
+    int64_t n_total;
+    const int32_t *index;
+    DeviceFrames(const void *p, int eb, int64_t nt, const int32_t *i) : d_pos(p), elem_bytes(eb), n_total(nt), index(i) {}
+    int elem() const override { return elem_bytes; }
+    int prepare(mdx_msd *h, int64_t n_sel) override
+    {
+        MDX_HIP(hipStreamSynchronize(h->stream));
+        if (index) {
+            MDX_TRY(h->d_index.ensure(size_t(4) * n_sel));
+            MDX_HIP(hipMemcpy(h->d_index.ptr, index, size_t(4) * n_sel, hipMemcpyHostToDevice));
+        }
+        return MDX_OK;
+    }
+    int stage(mdx_msd *, int64_t, int64_t, int64_t, int64_t, void *) override { return MDX_OK; }
+    bool resident() const override { return true; }
+    const void *direct(mdx_msd *h, int64_t a0, int64_t f0, int64_t *stride, const int **rows) override
+    {
+        *stride = n_total * 3;
+        const char *base = static_cast<const char *>(d_pos) + size_t(f0) * n_total * 3 * elem_bytes;
+        if (index) {
+            *rows = h->d_index.as<int>() + a0;
+            return base;
+        }
+        *rows = nullptr;
+        return base + size_t(a0) * 3 * elem_bytes;
+    }
+};
+
+static void msd_launch_unwrap(mdx_msd *h, FrameSource &src, int64_t n_coord, int64_t nf, int first,
                               int unwrap, const double *dims, double *d_out, const double *d_shift,
-                              int64_t a0)
+                              int64_t a0, int64_t f0)
 {
     const dim3 grid((unsigned)ceil_div(n_coord, 256));
     const double lx = dims ? dims[0] : 0.0, ly = dims ? dims[1] : 0.0, lz = dims ? dims[2] : 0.0;
@@ -547,14 +676,34 @@ static void msd_launch_unwrap(mdx_msd *h, const FrameSource &src, int64_t n_coor
                              hipMemcpyHostToDevice, h->stream);
         first = 2;
     }
+    // frames read where they lie (HBM-resident source) or from the staged block
+    int64_t stride = n_coord;
+    const int *rows = nullptr;
+    const void *in = src.direct(h, a0, f0, &stride, &rows);
+    if (!in) {
+        in = h->d_f32.ptr;
+        stride = n_coord;
+        rows = nullptr;
+    }
+    const int n_seg = (int)ceil_div(nf, UNWRAP_SEG);
+    const dim3 grid2(grid.x, (unsigned)n_seg);
+    auto run = [&](auto zero) {
+        using In = decltype(zero);
+        const In *p = static_cast<const In *>(in);
+        if (unwrap) {
+            hipLaunchKernelGGL(msd_image_delta_kernel<In>, grid2, dim3(256), 0, h->stream, p, stride, rows, n_coord,
+                               nf, first, lx, ly, lz, h->d_prev.as<In>(), h->d_seg.as<int>());
+            hipLaunchKernelGGL(msd_image_scan_kernel<In>, grid, dim3(256), 0, h->stream, p, stride, rows, n_coord, nf,
+                               n_seg, first, h->d_prev.as<In>(), h->d_xstart.as<In>(), h->d_image.as<int>(),
+                               h->d_seg.as<int>());
+        }
+        hipLaunchKernelGGL(msd_unwrap_widen_kernel<In>, grid2, dim3(256), 0, h->stream, p, stride, rows, n_coord, nf,
+                           unwrap, lx, ly, lz, h->d_xstart.as<In>(), h->d_seg.as<int>(), d_out, d_shift);
+    };
     if (src.elem() == 8)
-        hipLaunchKernelGGL(msd_unwrap_widen_kernel<double>, grid, dim3(256), 0, h->stream,
-                           h->d_f32.as<double>(), n_coord, nf, first, unwrap, lx, ly, lz,
-                           h->d_prev.as<double>(), h->d_image.as<int>(), d_out, d_shift);
+        run(double(0));
     else
-        hipLaunchKernelGGL(msd_unwrap_widen_kernel<float>, grid, dim3(256), 0, h->stream,
-                           h->d_f32.as<float>(), n_coord, nf, first, unwrap, lx, ly, lz,
-                           h->d_prev.as<float>(), h->d_image.as<int>(), d_out, d_shift);
+        run(float(0));
 }
 
 __global__ void msd_molecule_com_kernel(const double *__restrict__ x, int64_t c, int64_t a0,
@@ -588,18 +737,15 @@ static int msd_system_com_frames(mdx_msd *h, FrameSource &src, int64_t n_frames,
     MDX_TRY(src.prepare(h, n_sel));
     MDX_TRY(h->d_masses.ensure(size_t(8) * n_sel));
     MDX_HIP(hipMemcpy(h->d_masses.ptr, masses, size_t(8) * n_sel, hipMemcpyHostToDevice));
-    const int64_t row_bytes = int64_t(3) * src.elem();
-    MDX_TRY(h->d_prev.ensure(size_t(n_sel) * row_bytes));
-    MDX_TRY(h->d_image.ensure(size_t(n_sel) * 12));
-    const int64_t block = std::max<int64_t>(1, std::min<int64_t>(n_frames, (int64_t(64) << 20) / (row_bytes * n_sel)));
-    MDX_TRY(h->d_f32.ensure(size_t(block) * n_sel * row_bytes));
+    const int64_t block = msd_frame_block(src, n_frames, n_sel);
+    MDX_TRY(msd_unwrap_buffers(h, src, n_sel, block));
     MDX_TRY(h->d_com_x.ensure(size_t(block) * n_sel * 24));
     MDX_TRY(h->d_shift.ensure(size_t(24) * n_frames));
     for (int64_t f0 = 0; f0 < n_frames; f0 += block) {
         const int64_t nf = std::min(block, n_frames - f0);
         MDX_TRY(src.stage(h, 0, n_sel, f0, nf, h->d_f32.ptr));
         msd_launch_unwrap(h, src, 3 * n_sel, nf, f0 == 0 ? 1 : 0, unwrap, dims, h->d_com_x.as<double>(),
-                          nullptr);
+                          nullptr, 0, f0);
         if (molecules) {
             MDX_TRY(h->d_mol_com.ensure(size_t(nf) * n_mol * 24));
             hipLaunchKernelGGL(msd_molecule_com_kernel, dim3((unsigned)ceil_div(n_mol * 3, 256), (unsigned)nf),
@@ -689,11 +835,8 @@ static int msd_push_frames(mdx_msd *h, int group, FrameSource &src, int64_t n_se
                 (long long)h->images0.size() / 3, (long long)n_sel);
     MDX_TRY(src.prepare(h, n_sel));
     MDX_TRY(h->d_stage.ensure(size_t(T) * chunk * 24));
-    const int64_t row_bytes = int64_t(3) * src.elem();
-    MDX_TRY(h->d_prev.ensure(size_t(chunk) * row_bytes));
-    MDX_TRY(h->d_image.ensure(size_t(chunk) * 12));
-    const int64_t block = std::max<int64_t>(1, std::min<int64_t>(T, (int64_t(64) << 20) / (row_bytes * chunk)));
-    MDX_TRY(h->d_f32.ensure(size_t(block) * chunk * row_bytes));
+    const int64_t block = msd_frame_block(src, T, chunk);
+    MDX_TRY(msd_unwrap_buffers(h, src, chunk, block));
     if (shift) {
         MDX_TRY(h->d_shift.ensure(size_t(24) * T));
         MDX_HIP(hipMemcpy(h->d_shift.ptr, shift, size_t(24) * T, hipMemcpyHostToDevice));
@@ -711,7 +854,7 @@ static int msd_push_frames(mdx_msd *h, int group, FrameSource &src, int64_t n_se
             MDX_TRY(src.stage(h, a0, c, f0, nf, h->d_f32.ptr));
             msd_launch_unwrap(h, src, 3 * c, nf, f0 == 0 ? 1 : 0, unwrap, dims,
                               h->d_stage.as<double>() + f0 * c * 3,
-                              shift_rows ? h->d_shift.as<double>() + 3 * f0 : nullptr, a0);
+                              shift_rows ? h->d_shift.as<double>() + 3 * f0 : nullptr, a0, f0);
             MDX_HIP(hipGetLastError());
         }
         if (!molecules) {
@@ -846,7 +989,7 @@ int mdx_msd_destroy(mdx_msd_t h)
     h->timer.destroy();
     h->fft.destroy();
     for (DeviceBuffer *b : {&h->d_acc, &h->d_traj, &h->d_series, &h->d_spec, &h->d_stage,
-                            &h->d_inv_in, &h->d_inv_out, &h->d_f32, &h->d_index, &h->d_prev,
+                            &h->d_inv_in, &h->d_inv_out, &h->d_f32, &h->d_index, &h->d_prev, &h->d_xstart, &h->d_seg,
                             &h->d_image, &h->d_tw, &h->d_pfull, &h->d_part, &h->d_masses, &h->d_com_x,
                             &h->d_shift, &h->d_mol_offsets, &h->d_mol_masses, &h->d_mol_total,
                             &h->d_mol_com})
@@ -1042,6 +1185,56 @@ int mdx_msd_push_f64(mdx_msd_t h, int group, const double *pos, int64_t n_frames
         return MDX_OK;
     HostFrames<double> src(pos, n_sel);
     return msd_push_frames(h, group, src, n_sel, unwrap, dims, zero_dims, shift);
+}
+
+int mdx_msd_push_frames_device(mdx_msd_t h, int group, const void *d_pos, int elem_bytes, int64_t n_frames,
+                               int64_t n_total, const int32_t *index, int64_t n_index, int unwrap,
+                               const double *dims, int zero_dims, const double *shift)
+{
+    MDX_REQUIRE(h && d_pos, "NULL argument");
+    MDX_REQUIRE(elem_bytes == 4 || elem_bytes == 8, "elem_bytes is 4 (float32) or 8 (float64)");
+    MDX_REQUIRE(group >= 0 && group < h->n_groups, "group %d out of range", group);
+    MDX_REQUIRE(zero_dims >= 0 && zero_dims < 8, "zero_dims is a 3-bit mask");
+    const int64_t T = int64_t(h->n_blocks) * h->t_block;
+    MDX_REQUIRE(n_frames >= T, "%lld frames given, the engine needs %lld", (long long)n_frames,
+                (long long)T);
+    MDX_REQUIRE(!unwrap || (dims && dims[0] > 0 && dims[1] > 0 && dims[2] > 0),
+                "unwrapping needs positive box dimensions");
+    MDX_REQUIRE(n_total > 0 && n_total < (int64_t(1) << 31) / 3, "n_total out of range");
+    const int64_t n = index ? n_index : (n_index > 0 ? n_index : n_total);
+    MDX_REQUIRE(n >= 0 && (index || n <= n_total), "selection larger than the frames");
+    for (int64_t i = 0; index && i < n; ++i)
+        if (index[i] < 0 || index[i] >= n_total)
+            return fail(MDX_ERR_INVALID_VALUE, "particle index %d out of range [0, %lld)", index[i],
+                        (long long)n_total);
+    MDX_TRY(set_device(h->dev));
+    if (n == 0)
+        return MDX_OK;
+    DeviceFrames src(d_pos, elem_bytes, n_total, index);
+    return msd_push_frames(h, group, src, n, unwrap, dims, zero_dims, shift);
+}
+
+int mdx_msd_system_com_device(mdx_msd_t h, const void *d_pos, int elem_bytes, int64_t n_frames,
+                              int64_t n_total, const int32_t *index, int64_t n_index, const double *masses,
+                              int unwrap, const double *dims, int wrap, double *out)
+{
+    MDX_REQUIRE(h && d_pos && masses && out, "NULL argument");
+    MDX_REQUIRE(elem_bytes == 4 || elem_bytes == 8, "elem_bytes is 4 (float32) or 8 (float64)");
+    MDX_REQUIRE(n_frames >= 0, "negative frame count");
+    MDX_REQUIRE((!unwrap && !wrap) || (dims && dims[0] > 0 && dims[1] > 0 && dims[2] > 0),
+                "unwrapping / wrapping needs positive box dimensions");
+    MDX_REQUIRE(n_total > 0 && n_total < (int64_t(1) << 31) / 3, "n_total out of range");
+    const int64_t n = index ? n_index : (n_index > 0 ? n_index : n_total);
+    MDX_REQUIRE(n > 0 && (index || n <= n_total), "bad selection");
+    for (int64_t i = 0; index && i < n; ++i)
+        if (index[i] < 0 || index[i] >= n_total)
+            return fail(MDX_ERR_INVALID_VALUE, "particle index %d out of range [0, %lld)", index[i],
+                        (long long)n_total);
+    MDX_TRY(set_device(h->dev));
+    if (n_frames == 0)
+        return MDX_OK;
+    DeviceFrames src(d_pos, elem_bytes, n_total, index);
+    return msd_system_com_frames(h, src, n_frames, n, masses, unwrap, dims, wrap, out);
 }
 
 int mdx_msd_push_traj(mdx_msd_t h, int group, mdx_traj_t traj, const int64_t *frames,

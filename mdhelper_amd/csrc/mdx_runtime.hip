@@ -45,6 +45,21 @@ BlockCache &block_cache()
     return *c;
 }
 constexpr size_t CACHE_BLOCK_MAX = size_t(512) << 20, CACHE_TOTAL_MAX = size_t(4) << 30;
+
+// hipFree every cached block of a device (the current one must be `dev`); returns the bytes given back
+size_t flush_block_cache(int dev)
+{
+    if (dev < 0 || dev >= 64)
+        return 0;
+    BlockCache &c = block_cache();
+    std::lock_guard<std::mutex> lk(c.m);
+    for (auto &b : c.blocks[dev])
+        (void)hipFree(b.second);
+    c.blocks[dev].clear();
+    const size_t freed = c.cached[dev];
+    c.cached[dev] = 0;
+    return freed;
+}
 }  // namespace
 
 int DeviceBuffer::ensure(size_t need)
@@ -77,16 +92,7 @@ int DeviceBuffer::ensure(size_t need)
     if (e == hipErrorOutOfMemory) {
         // give the cache back before giving up
         (void)hipGetLastError();
-        BlockCache &c = block_cache();
-        {
-            std::lock_guard<std::mutex> lk(c.m);
-            if (dev >= 0 && dev < 64) {
-                for (auto &b : c.blocks[dev])
-                    (void)hipFree(b.second);
-                c.blocks[dev].clear();
-                c.cached[dev] = 0;
-            }
-        }
+        flush_block_cache(dev);
         e = hipMalloc(&ptr, want);
     }
     if (e != hipSuccess)
@@ -451,8 +457,12 @@ int HostStager::upload(int device, hipStream_t consumer, void *d_dst, const void
     std::lock_guard<std::mutex> guard(lock);
     // memory the device can read where it lies (hipHostMalloc / hipHostRegister, e.g. through
     // mdx_host_register): one DMA, no staging copy
-    hipPointerAttribute_t attr;
-    if (hipPointerGetAttributes(&attr, src) == hipSuccess && attr.type == hipMemoryTypeHost) {
+    // (both ends are asked: a caller may have registered a shorter range than [src, src + bytes), and a DMA
+    // that runs off the registered object faults; such a buffer goes through the ring like pageable memory)
+    hipPointerAttribute_t attr, attr_end;
+    if (hipPointerGetAttributes(&attr, src) == hipSuccess && attr.type == hipMemoryTypeHost &&
+        hipPointerGetAttributes(&attr_end, static_cast<const uint8_t *>(src) + bytes - 1) == hipSuccess &&
+        attr_end.type == hipMemoryTypeHost) {
         MDX_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, consumer));
         return MDX_OK;
     }
@@ -647,7 +657,38 @@ int mdx_malloc(int dev, size_t bytes, void **dptr)
 {
     MDX_REQUIRE(dptr != nullptr, "dptr is NULL");
     MDX_TRY(set_device(dev));
-    MDX_HIP(hipMalloc(dptr, bytes ? bytes : 1));
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+    if (e == hipErrorOutOfMemory) {
+        // the handles' recycled blocks (DeviceBuffer::recycle) go back first
+        (void)hipGetLastError();
+        flush_block_cache(dev);
+        e = hipMalloc(dptr, bytes ? bytes : 1);
+    }
+    MDX_HIP(e);
+    return MDX_OK;
+}
+
+int mdx_trim_cache(int dev, size_t *freed_bytes)
+{
+    MDX_TRY(set_device(dev));
+    MDX_HIP(hipDeviceSynchronize());
+    const size_t freed = flush_block_cache(dev);
+    if (freed_bytes)
+        *freed_bytes = freed;
+    return MDX_OK;
+}
+
+int mdx_upload(int dev, void *d_dst, const void *src, size_t bytes)
+{
+    MDX_REQUIRE(d_dst && src, "NULL argument");
+    MDX_TRY(set_device(dev));
+    hipStream_t stream = nullptr;
+    MDX_TRY(stream_acquire(&stream));
+    const int rc = device_stager(dev).upload(dev, stream, d_dst, src, bytes);
+    const hipError_t e = hipStreamSynchronize(stream);   // also on an error: no copy outlives the call
+    stream_release(stream);
+    MDX_TRY(rc);
+    MDX_HIP(e);
     return MDX_OK;
 }
 

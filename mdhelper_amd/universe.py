@@ -165,6 +165,56 @@ class ArrayTrajectory:
         return self._dimensions[np.asarray(frames, dtype=int)]
 
 
+class DeviceTrajectory(ArrayTrajectory):
+    """Trajectory whose frames are resident in HBM: a ``_core.DeviceArray`` float32 or float64
+    ``[n_frames, n_atoms, 3]`` (e.g. what a GPU MD engine left there).  ``Onsager`` consumes it without
+    a host copy; single frames and host blocks are copied back on demand for everything else."""
+
+    def __init__(self, device_array, dimensions=None, dt: float = 1.0):
+        if len(device_array.shape) != 3 or device_array.shape[2] != 3:
+            raise ValueError("device positions must have shape (n_frames, n_atoms, 3).")
+        if device_array.dtype not in (np.float32, np.float64):
+            raise ValueError("device positions must be float32 or float64.")
+        self.device_array = device_array
+        self._positions = None
+        if dimensions is not None:
+            dim = np.asarray(dimensions, dtype=np.float32)
+            if dim.ndim == 1:
+                dim = dim[None]
+            if dim.shape[1] == 3:
+                dim = np.hstack((dim, np.full((dim.shape[0], 3), 90.0, dtype=np.float32)))
+            if dim.shape[1] != 6 or dim.shape[0] not in (1, device_array.shape[0]):
+                raise ValueError("dimensions must have shape (6,), (1, 6) or (n_frames, 6).")
+            dimensions = np.ascontiguousarray(dim, dtype=np.float32)
+        self._dimensions = dimensions
+        self.dt = float(dt)
+        self.ts = Timestep(self, 0)
+
+    @property
+    def n_frames(self):
+        return self.device_array.shape[0]
+
+    @property
+    def n_atoms(self):
+        return self.device_array.shape[1]
+
+    def frame_positions(self, frame):
+        return self.device_array.to_host(int(frame), 1)[0].astype(np.float32, copy=False)
+
+    def frame_block(self, frames):
+        frames = np.asarray(frames, dtype=int)
+        if len(frames) and np.all(np.diff(frames) == 1):
+            return self.device_array.to_host(int(frames[0]), len(frames))
+        return np.stack([self.device_array.to_host(int(f), 1)[0] for f in frames])
+
+    def device_block(self, frames):
+        """The listed frames as a device array without a copy, or None when they are not consecutive."""
+        frames = np.asarray(frames, dtype=int)
+        if len(frames) and np.all(np.diff(frames) == 1):
+            return self.device_array.rows(int(frames[0]), len(frames))
+        return None
+
+
 class _Level:
     """Residue / segment view of an AtomGroup (masses, charges, counts)."""
 
@@ -287,6 +337,16 @@ class ArrayUniverse:
                  charges=None, resids=None, segids=None, bonds=None):
         self.trajectory = ArrayTrajectory(positions, dimensions, dt)
         self._init_topology(masses, charges, resids, segids, bonds)
+
+    @classmethod
+    def from_device(cls, device_array, dimensions=None, dt: float = 1.0, **topology):
+        """Universe over frames resident in HBM (``_core.DeviceArray`` float32 / float64
+        ``[n_frames, n_atoms, 3]``), see :class:`DeviceTrajectory`."""
+        u = cls.__new__(cls)
+        u.trajectory = DeviceTrajectory(device_array, dimensions, dt)
+        u._init_topology(topology.get("masses"), topology.get("charges"), topology.get("resids"),
+                         topology.get("segids"), topology.get("bonds"))
+        return u
 
     def _fragment_labels(self):
         """Fragment number of every atom, fragments numbered by their first atom."""

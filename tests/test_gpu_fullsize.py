@@ -305,6 +305,115 @@ def test_c4_full_size_msd(n_blocks):
     d.free()
 
 
+def _direct_msd_sums(h, halves, t0, t_len, lag, n_threads=8):
+    """[sum over the particles of each range in `halves` and over origins of |r(t+lag) - r(t)|^2] / origins
+    within the block [t0, t0+t_len) of the host float32 trajectory h — the direct definition
+    (correlation.py:670-850) in float64, slabs of frames on a few threads."""
+    from concurrent.futures import ThreadPoolExecutor
+    n_orig = t_len - lag
+    slab = max(1, min(n_orig, (48 << 20) // (h.shape[1] * 12)))
+
+    def part(a):
+        b = min(n_orig, a + slab)
+        d = np.subtract(h[t0 + a + lag:t0 + b + lag], h[t0 + a:t0 + b], dtype=np.float64)
+        return [float(np.einsum("tak,tak->", d[:, lo:hi], d[:, lo:hi])) for lo, hi in halves]
+
+    with ThreadPoolExecutor(n_threads) as pool:
+        parts = list(pool.map(part, range(0, n_orig, slab)))
+    return np.sum(parts, axis=0) / n_orig
+
+
+@pytest.mark.parametrize("n_blocks", [1, 8])
+def test_c4_onsager_and_transport_coefficients_end_to_end(n_blocks):
+    """BASELINE C4 as worded — "MSD + Onsager transport coeffs, 10k atoms x 100k frames" — through the
+    operator surface: ``Onsager((g0, g1), temperature=1, reduced=True, charges=+-1).run()`` on the float32
+    frames an MDAnalysis memory reader would hold (12 GB of host memory, uploaded once, prepared on the
+    device), then ``calculate_transport_coefficients`` / conductivity / transference numbers
+    (reference transport.py:59-286, 912-1059).  Checked: (a) all three cross MSDs element-wise against the
+    oracle's msd_fft of the summed trajectories (summed on the host); (b) msd_self against the direct
+    definition over ALL particles at small, middle and large lags; (c) a 64-particle analysis element-wise
+    against the oracle; (d) D_i against the free walk's sigma^2 / 2 dt, L_ii_self = N_i D_i / (kBT V), the
+    symmetry of L_ij, L_ii against L_ii_self and L_01 against 0 within the statistics of ONE summed
+    trajectory, conductivity and transference numbers from L_ij."""
+    import time
+    import mdhelper_amd
+    from mdhelper_amd.analysis import Onsager
+    from oracle import correlation as oc
+    T, n, sigma, box = 100_000, 10_000, 0.1, 50.0
+    d = _core.synth_random_walk(T, n, [1.0, 1.0, 1.0], sigma, seed=4, wrap=False)     # float32, unwrapped
+    h = d.to_host()
+    d.free()
+    tb = T // n_blocks
+    u = mdhelper_amd.ArrayUniverse(h, [box, box, box, 90, 90, 90], dt=1.0,
+                                   charges=np.r_[np.ones(n // 2), -np.ones(n - n // 2)])
+    assert u.trajectory._positions is h or np.shares_memory(u.trajectory._positions, h)
+    groups = (u.atoms[:n // 2], u.atoms[n // 2:])
+    t0 = time.perf_counter()
+    ons = Onsager(groups, temperature=1, reduced=True, n_blocks=n_blocks, verbose=False).run()
+    wall = time.perf_counter() - t0
+    print(f"Onsager.run() on 12 GB of host float32, n_blocks={n_blocks}: {wall:.2f} s")
+    assert ons._from_file
+    res = ons.results
+    assert res.pairs == ((0, 0), (0, 1), (1, 1))
+    assert res.msd_self.shape == (2, n_blocks, tb) and res.msd_cross.shape == (3, n_blocks, tb)
+    assert np.array_equal(res.times, np.arange(tb, dtype=float))
+
+    # (a) cross MSDs: the oracle on the summed trajectories
+    halves = [(0, n // 2), (n // 2, n)]
+    sums = [np.concatenate([h[a:a + 2000, lo:hi].sum(axis=1, dtype=np.float64) for a in range(0, T, 2000)])
+            .reshape(n_blocks, tb, 3) for lo, hi in halves]
+    ref = {(0, 0): oc.msd_fft_ref(sums[0], axis=1) / 6, (1, 1): oc.msd_fft_ref(sums[1], axis=1) / 6,
+           (0, 1): oc.msd_fft_ref(sums[0], sums[1], axis=1) / 6}
+    scale = np.sqrt(np.abs(ref[(0, 0)] * ref[(1, 1)]))          # per lag: what a cross term is measured against
+    for i, pair in enumerate(res.pairs):
+        err = np.abs(res.msd_cross[i] - ref[pair])
+        assert np.all(err[:, 1:] <= 1e-6 * np.maximum(np.abs(ref[pair]), scale)[:, 1:]), pair
+        assert np.all(err[:, 0] <= 1e-6 * scale[:, 1]), pair     # lag 0: pure round-off
+
+    # (b) self MSDs: the direct definition, every particle
+    for b in sorted({0, n_blocks - 1}):
+        for lag in (1, 1000, tb // 2, tb - 1):
+            direct = _direct_msd_sums(h, halves, b * tb, tb, lag) / (n // 2) / 6
+            assert np.allclose(res.msd_self[:, b, lag], direct, rtol=1e-6), (b, lag)
+    assert np.all(np.abs(res.msd_self[:, :, 0]) < 1e-6 * res.msd_self[:, :, 1])
+
+    # (c) 64 particles, every lag, against the oracle's per-particle msd_fft
+    small = Onsager(u.atoms[:64], temperature=1, reduced=True, n_blocks=n_blocks, verbose=False).run()
+    p64 = h[:, :64].astype(np.float64).reshape(n_blocks, tb, 64, 3)
+    want = oc.msd_fft_ref(p64, axis=1, average=False).mean(axis=-1) / 6
+    assert np.allclose(small.results.msd_self[0][:, 1:], want[:, 1:], rtol=1e-6)
+    assert np.allclose(small.results.msd_cross[0], oc.msd_fft_ref(p64.sum(axis=2), axis=1) / 6, rtol=1e-6,
+                       atol=1e-6 * want[:, 1].max() * 64)
+
+    # (d) transport coefficients of the free walk: MSD_self / 6 = sigma^2 m / 2  =>  D = sigma^2 / (2 dt)
+    D_true, kBT, V = sigma ** 2 / 2, 1.0, box ** 3
+    ons.calculate_transport_coefficients(start=1, stop=tb // 10, scale="linear")
+    assert res.L_ij.shape == (n_blocks, 2, 2) and res.D_i.shape == (n_blocks, 2)
+    assert np.allclose(res.D_i, D_true, rtol=0.02), res.D_i
+    assert np.allclose(res.L_ii_self, (n // 2) * res.D_i / (kBT * V), rtol=1e-13)
+    assert np.array_equal(res.L_ij, res.L_ij.transpose(0, 2, 1))
+    L_self = (n // 2) * D_true / (kBT * V)
+    # one summed trajectory per (group, block): the collective slope scatters by tens of per cent
+    diag = np.stack((res.L_ij[:, 0, 0], res.L_ij[:, 1, 1]), axis=1)
+    assert np.all(np.abs(diag / L_self - 1) < 0.6), diag / L_self
+    assert abs(diag.mean() / L_self - 1) < (0.45 if n_blocks == 1 else 0.25), diag.mean() / L_self
+    assert np.all(np.abs(res.L_ij[:, 0, 1]) < 0.6 * L_self), res.L_ij[:, 0, 1] / L_self
+    ons.calculate_conductivity()
+    ons.calculate_transference_number()
+    ons.calculate_electrophoretic_mobility()
+    kappa = res.L_ij[:, 0, 0] + res.L_ij[:, 1, 1] - 2 * res.L_ij[:, 0, 1]             # z = (+1, -1)
+    assert np.allclose(res.conductivities, kappa, rtol=1e-12)
+    t_plus = (res.L_ij[:, 0, 0] - res.L_ij[:, 0, 1]) / kappa
+    assert np.allclose(res.transference_numbers, np.stack((t_plus, 1 - t_plus), axis=1), rtol=1e-10, atol=1e-12)
+    rho = (n // 2) / V
+    assert np.allclose(res.electrophoretic_mobilities[:, 0], (res.L_ij[:, 0, 0] - res.L_ij[:, 0, 1]) / rho,
+                       rtol=1e-12)
+    # the reference's default fit (log scale, slope fixed to 1, every lag from 1 on: dominated by the
+    # long, poorly sampled lags) still lands on the walk's diffusivity
+    ons.calculate_transport_coefficients()
+    assert np.allclose(res.D_i, D_true, rtol=0.10), res.D_i
+
+
 def test_c5_size_rows_against_all_atoms_equal_the_c_oracle():
     """C5 size (131 072 atoms, L = 109.4): 2 048 atoms against all atoms of one frame, two-group call,
     bit-identical with the C oracle (2.7e8 ordered pairs); default path and explicit cell."""

@@ -439,6 +439,127 @@ def test_onsager_unwrap_makes_split_molecules_whole_first(tmp_path):
     assert far > 1e-3 * np.abs(host.results.msd_self).max(), far
 
 
+@pytest.mark.parametrize("mode", ["atoms", "atoms, unwrap, center", "residues, unwrap, center_wrap",
+                                  "mixed, center_atom, zero"])
+def test_onsager_resident_streamed_and_hbm_universe_routes_agree(tmp_path, mode):
+    """The analysed frames are brought into HBM once and every group is prepared from them on the device
+    (mdx_msd_push_frames_device); frames too large for that stream group by group (mdx_msd_push_traj /
+    mdx_msd_push_f32: forced here through Onsager._hbm_share = 0); a universe over frames already in HBM
+    (ArrayUniverse.from_device, float32 and float64) stages nothing.  All of them must give the per-frame
+    host protocol's result, for every kind of frame preparation."""
+    import warnings
+    from mdhelper_amd.analysis import Onsager
+    rng = np.random.default_rng(123)
+    T, n_mol, per = 300, 36, 3            # 300 frames: three segments of the segment-parallel unwrap
+    N = n_mol * per + 7
+    L = np.array([9.0, 10.5, 8.25])
+    centres = rng.uniform(0, L, (1, n_mol, 1, 3)) + np.cumsum(rng.normal(0.02, 0.35, (T, n_mol, 1, 3)), axis=0)
+    shape = rng.normal(0, 0.4, (1, n_mol, per, 3)) + 0.02 * np.cumsum(rng.normal(size=(T, n_mol, per, 3)), axis=0)
+    loose = rng.uniform(0, L, (1, 7, 3)) + np.cumsum(rng.normal(0, 0.3, (T, 7, 3)), axis=0)
+    walk = np.concatenate([(centres + shape).reshape(T, n_mol * per, 3), loose], axis=1)
+    unwrap = "unwrap" in mode
+    stored = (np.mod(walk, L) if unwrap else walk).astype(np.float32)
+    path = tmp_path / "routes.nc"
+    write_amber_netcdf(path, stored, L, times=np.arange(T) * 0.5)
+    dims = np.array([*L, 90, 90, 90], dtype=np.float32)
+    kw_u = dict(dt=0.5, masses=rng.uniform(1.0, 30.0, N),
+                resids=np.r_[np.repeat(np.arange(n_mol), per), n_mol + np.arange(7)],
+                charges=np.where(np.arange(N) % 2 == 0, 1.0, -1.0))
+    half = (n_mol // 2) * per
+
+    def groups(u):
+        if mode.startswith("mixed"):
+            return [u.atoms[:half], u.atoms[n_mol * per:]], ["residues", "atoms"]
+        if mode.startswith("residues"):
+            return [u.atoms[:half], u.atoms[half:n_mol * per]], "residues"
+        # atoms: one contiguous range, one scattered selection
+        return [u.atoms[:half], u.select(np.arange(half + 1, N, 2))], "atoms"
+
+    kw = dict(temperature=300, n_blocks=2, verbose=False, unwrap=unwrap, center="center" in mode,
+              center_atom="center_atom" in mode, center_wrap="center_wrap" in mode,
+              dimensions=[L[0], L[1], 0.0] if "zero" in mode else None)
+
+    def run(u, share=None, route=None):
+        g, gr = groups(u)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            o = Onsager(g, gr, **kw)
+            if share is not None:
+                o._hbm_share = share
+            return (per_frame(o) if route == "per_frame" else o).run()
+
+    um = mdhelper_amd.ArrayUniverse(stored, dims, **kw_u)
+    uf = mdhelper_amd.FileUniverse(path, **kw_u)
+    d32 = _core.DeviceArray.from_host(stored)
+    d64 = _core.DeviceArray.from_host(stored.astype(np.float64))
+    ud32 = mdhelper_amd.ArrayUniverse.from_device(d32, dims, **kw_u)
+    ud64 = mdhelper_amd.ArrayUniverse.from_device(d64, dims, **kw_u)
+    want = run(um, route="per_frame")
+    assert not want._from_file
+    routes = {"memory, resident": run(um), "memory, streamed": run(um, 0.0), "file, resident": run(uf),
+              "file, streamed": run(uf, 0.0), "hbm float32": run(ud32), "hbm float64": run(ud64),
+              "hbm float64, a frame range": None}
+    # a sub-range of the HBM frames is a window, irregular frames go through the host
+    g, gr = groups(ud64)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        win = Onsager(g, gr, **kw).run(start=20, stop=260)
+        irr = Onsager(g, gr, **kw).run(frames=np.arange(20, 260, 1)[::2])
+        g, gr = groups(um)
+        win_ref = per_frame(Onsager(g, gr, **kw)).run(start=20, stop=260)
+        irr_ref = per_frame(Onsager(g, gr, **kw)).run(frames=np.arange(20, 260, 1)[::2])
+    del routes["hbm float64, a frame range"]
+    for name in ("msd_self", "msd_cross"):
+        y = want.results[name]
+        for route, got in routes.items():
+            assert got._from_file, route
+            assert np.allclose(got.results[name], y, rtol=1e-8, atol=1e-8 * np.abs(y).max()), (route, name)
+        for got, ref in ((win, win_ref), (irr, irr_ref)):
+            y = ref.results[name]
+            assert np.allclose(got.results[name], y, rtol=1e-8, atol=1e-8 * np.abs(y).max()), name
+    assert np.abs(want.results.msd_self).max() > 1.0
+    d32.free()
+    d64.free()
+
+
+def test_onsager_unwrap_of_a_chain_longer_than_two_cells_starts_like_the_reference():
+    """Reference topology.py:366-376: the first ``unwrap`` call after ``make_whole`` (transport.py:936-941)
+    moves an image flag by sign(x - x_whole) — by one — however many cells a made-whole atom lies from
+    its stored image.  A 7-bead chain with bonds of 0.4 L spans more than two cells: the device routes
+    must start from the clipped flags like the per-frame host protocol does (center=True,
+    center_wrap=True with molecule groupings is where it shows)."""
+    import warnings
+    from mdhelper_amd.algorithm.topology import make_whole_images
+    from mdhelper_amd.analysis import Onsager
+    rng = np.random.default_rng(5)
+    T, L, n_chain, beads = 60, np.array([10.0, 10.0, 10.0]), 6, 7
+    start = rng.uniform(0, L, (n_chain, 1, 3))
+    chain = start + np.arange(beads)[None, :, None] * np.array([0.4 * L[0], 0.05, -0.03])
+    true = chain.reshape(1, n_chain * beads, 3) + np.cumsum(rng.normal(0, 0.15, (T, n_chain * beads, 3)), axis=0)
+    wrapped = np.mod(true, L).astype(np.float32)
+    N = n_chain * beads
+    bonds = np.array([(c * beads + b, c * beads + b + 1) for c in range(n_chain) for b in range(beads - 1)])
+    dims = np.array([*L, 90, 90, 90], dtype=np.float32)
+    u = mdhelper_amd.ArrayUniverse(wrapped, dims, dt=1.0, masses=rng.uniform(1, 20, N),
+                                   resids=np.repeat(np.arange(n_chain), beads), bonds=bonds)
+    u.trajectory[0]
+    assert np.abs(make_whole_images(u, L.astype(float))).max() >= 2      # the case the clipping is for
+    kw = dict(temperature=300, groupings="residues", center=True, center_wrap=True, unwrap=True, verbose=False)
+    groups = [u.atoms[:3 * beads], u.atoms[3 * beads:]]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        dev = Onsager(groups, **kw).run()
+        streamed = Onsager(groups, **kw)
+        streamed._hbm_share = 0.0
+        streamed.run()
+        host = per_frame(Onsager(groups, **kw)).run()
+    assert dev._from_file and streamed._from_file and not host._from_file
+    for name in ("msd_self", "msd_cross"):
+        y = host.results[name]
+        assert np.allclose(dev.results[name], y, rtol=1e-8, atol=1e-9 * np.abs(y).max()), name
+        assert np.allclose(streamed.results[name], y, rtol=1e-8, atol=1e-9 * np.abs(y).max()), name
+
+
 def test_page_locked_caller_memory_is_read_in_place(tmp_path):
     """`mdx_host_register`: a caller buffer page-locked once is handed to the DMA engine where it lies
     (no staging copy through the pinned ring); pageable, registered and again pageable (after

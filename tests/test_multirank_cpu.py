@@ -153,6 +153,20 @@ class OracleMsdEngine:
         acf = oc.correlation_fft_ref(p, axis=1, vector=True).sum(axis=-1)       # [B, T_b], per lag mean
         self._acf[group] += acf * (self.tb - np.arange(self.tb))
 
+    # the device-side frame preparation, as far as these CPU runs reach it (plain atom groups)
+    has_grouping = False
+
+    def set_grouping(self, offsets, masses):
+        assert offsets is None
+
+    def set_initial_images(self, images):
+        pass
+
+    def push_f32(self, group, positions, *, unwrap_dims=None, zero_dims=0, shift=None):
+        assert unwrap_dims is None and shift is None
+        p = np.asarray(positions, dtype=np.float64)
+        self.push(group, p, 0, p.shape[1], zero_dims)
+
     def result(self, want_msd=True):
         return self._msd.copy(), self._traj.copy()
 
@@ -170,6 +184,8 @@ def _install_stand_ins():
     _core.RdfEngine, _core.SqEngine, _core.MsdEngine = OracleRdfEngine, OracleSqEngine, OracleMsdEngine
     _core.IsfEngine = OracleIsfEngine
     correlation.msd_fft = oc.msd_fft_ref
+    from mdhelper_amd.analysis import Onsager
+    Onsager._hbm_share = 0.0          # no device to keep frames on: the group-by-group route
 
 
 def _build_inputs():

@@ -90,7 +90,7 @@ class PerFrameTrajectory:
         self._traj = traj
 
     def __getattr__(self, name):
-        if name in ("frame_block", "box_block", "native", "_positions"):
+        if name in ("frame_block", "box_block", "native", "_positions", "device_block", "device_array"):
             raise AttributeError(name)
         return getattr(self._traj, name)
 
