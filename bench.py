@@ -70,6 +70,8 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="rdf at N=1: skip the short C3 / C4 / C2(ii) legs embedded under 'extra'")
+    ap.add_argument("--no-onsager", action="store_true",
+                    help="msd at N=1: skip the operator-surface legs (Onsager(...).run() on HBM / host / file data)")
     ap.add_argument("--host-path", action="store_true",
                     help="rdf: feed host (pageable) buffers through mdx_rdf_accumulate, i.e. the "
                          "PCIe-inclusive rate; never the headline value")
@@ -761,15 +763,16 @@ def bench_msd(args, world):
         mine.append((first + lo, hi - lo))
     n_mine = sum(c for _f, c in mine)
 
+    box = {}
+
     def step():
+        # ONE analysis: the groups' particles through the correlation kernels, the accumulators' all-reduce
+        # (N > 1), and the result — inverse transforms of the summed power spectra, the S_m recurrence and
+        # the D2H of msd / summed trajectories (what Onsager._conclude does per analysis, transport.py:1016-1059)
         eng.reset()
         for g, (first, count) in enumerate(mine):
             if count:
                 eng.push_device(g, traj.ptr, N, first, count)
-
-    box = {}
-
-    def finish():
         if world.device_collectives:
             eng.allreduce(world.comm)
         msd, tr = eng.result()
@@ -777,12 +780,23 @@ def bench_msd(args, world):
             msd, tr = world.reduce_host(msd), world.reduce_host(tr)
         box["msd"], box["traj"] = msd, tr
 
+    def finish():
+        pass
+
     for _ in range(args.warmup):     # includes the inverse-transform plan (rocFFT builds it once)
         step()
-        finish()
 
     dt, own = timed_region(world, dev, args.steps, step, finish)
     st = eng.stats()
+    # what result() costs on its own (inverse transforms + recurrence + D2H), the pushes already finished
+    eng.reset()
+    for g, (first, count) in enumerate(mine):
+        if count:
+            eng.push_device(g, traj.ptr, N, first, count)
+    _core.synchronize(dev)
+    t_r = time.perf_counter()
+    eng.result()
+    result_ms = (time.perf_counter() - t_r) * 1e3
     n_total = N if args.shard_fixed else N * world.world
     atom_frames = args.steps * float(n_total) * T
     alg_bytes = 24.0 * n_mine * T
@@ -815,6 +829,8 @@ def bench_msd(args, world):
                      "kernel_ms_per_step": st["kernel_ms"],
                      "algorithmic_bytes_per_step": alg_bytes,
                      "pipeline_bytes_model": st["bytes_moved"]},
+        "step": "reset + push of both groups + result() (inverse transforms, S_m recurrence, D2H): one analysis",
+        "result_ms": result_ms,
         "physics_check_msd_over_3sigma2m": float(msd[10] / (3 * 0.01 * 10)),
         "result_digest": [float(x) for x in box["msd"][:, 0, 1:4].ravel()],
     }
@@ -842,7 +858,128 @@ def bench_msd(args, world):
                                "deviation_metric": "max over lags 1..T-1 of |got - ref| / |ref| (element-wise)"}
     eng.close()
     traj.free()
+    if world.world == 1 and not args.shard_fixed and not getattr(args, "no_onsager", False):
+        try:
+            t0 = time.perf_counter()
+            out["onsager"] = bench_onsager(args, world, out["ms_per_step"])
+            out["onsager"]["leg_wall_s"] = time.perf_counter() - t0
+        except Exception as exc:            # never takes the engine line down
+            out["onsager"] = {"error": f"{type(exc).__name__}: {exc}"}
     return out
+
+
+def bench_onsager(args, world, engine_ms):
+    """
+    BASELINE C4 as a user of the reference runs it (N = 1 only; never the headline value):
+    ``Onsager((g0, g1), temperature=1, reduced=True).run()`` — three cross MSDs of the summed trajectories,
+    two self MSDs, ``/ 2D`` (reference transport.py:912-1059) — on 10 000 particles x 100 000 frames, fed
+
+    class_hbm_f64         float64 frames resident in HBM (what the engine line reads): class overhead alone
+    class_hbm_f32         float32 frames resident in HBM: + gather / widening on the device
+    class_host_f32        float32 frames in pageable host memory (what an MDAnalysis memory reader holds):
+                          12 GB through the pinned ring, then as above
+    class_host_f32_pinned the same array page-locked through mdx_host_register: one DMA
+    class_file            an AMBER NetCDF file in the page cache (FileUniverse)
+
+    each with ms per analysis, the ratio of the engine figure (`engine_ms`: reset + pushes + result on HBM-resident
+    float64) to it, and the phases of one profiled analysis (marks wait for the device: their sum is a little
+    above the unprofiled time); then ``calculate_transport_coefficients`` on the result.
+    """
+    import tempfile
+    import mdhelper_amd
+    from mdhelper_amd import _core, _lib
+    from mdhelper_amd.analysis import Onsager
+    from mdhelper_amd.io import FileUniverse
+    dev = world.dev
+    N, T, sigma, L = args.atoms or 10000, args.frames or 100000, 0.1, 50.0
+    B = max(1, args.blocks)
+    dims = np.array([L, L, L, 90, 90, 90], dtype=np.float32)
+    charges = np.r_[np.ones(N // 2), -np.ones(N - N // 2)]
+    gb32 = 12.0 * N * T / 1e9
+    legs = {"atoms": N, "frames": T, "n_blocks": B, "engine_ms_per_analysis": engine_ms,
+            "float32_GB": gb32}
+    keep = {}
+
+    def analysis(u, profile=False):
+        o = Onsager((u.atoms[:N // 2], u.atoms[N // 2:]), temperature=1, reduced=True, n_blocks=B,
+                    verbose=False, device=dev)
+        o._profile = profile
+        return o.run()
+
+    def leg(name, u, reps=2, **more):
+        analysis(u)                               # warm-up: plans, allocations, pinned ring, page cache
+        _core.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            o = analysis(u)
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        prof = analysis(u, profile=True)
+        legs[name] = {"ms_per_analysis": ms, "engine_over_class": engine_ms / ms,
+                      "phases_ms": {k: v * 1e3 for k, v in prof._timings.items()}, **more}
+        keep[name] = o
+        return o
+
+    d64 = _core.synth_random_walk(T, N, [1.0, 1.0, 1.0], sigma, seed=4, dev=dev, dtype=np.float64)
+    leg("class_hbm_f64", mdhelper_amd.ArrayUniverse.from_device(d64, dims, charges=charges))
+    d64.free()
+    d32 = _core.synth_random_walk(T, N, [1.0, 1.0, 1.0], sigma, seed=4, wrap=False, dev=dev)
+    leg("class_hbm_f32", mdhelper_amd.ArrayUniverse.from_device(d32, dims, charges=charges))
+    h = d32.to_host()
+    # what the link gives: the same 12 GB by one DMA out of page-locked memory, and through the pinned ring
+    _lib.check(_lib.lib().mdx_host_register(dev, h.ctypes.data, h.nbytes))
+    try:
+        t0 = time.perf_counter()
+        _lib.check(_lib.lib().mdx_upload(dev, d32.ptr, h.ctypes.data, h.nbytes))
+        legs["h2d_page_locked_GB_per_sec"] = gb32 / (time.perf_counter() - t0)
+    finally:
+        _lib.check(_lib.lib().mdx_host_unregister(dev, h.ctypes.data))
+    t0 = time.perf_counter()
+    _lib.check(_lib.lib().mdx_upload(dev, d32.ptr, h.ctypes.data, h.nbytes))
+    legs["h2d_pageable_ring_GB_per_sec"] = gb32 / (time.perf_counter() - t0)
+    legs["io_threads"] = int(os.environ.get("MDX_IO_THREADS", "8"))
+    d32.free()
+    um = mdhelper_amd.ArrayUniverse(h, dims, charges=charges)
+    leg("class_host_f32", um)
+    _lib.check(_lib.lib().mdx_host_register(dev, h.ctypes.data, h.nbytes))
+    try:
+        leg("class_host_f32_pinned", um)
+    finally:
+        _lib.check(_lib.lib().mdx_host_unregister(dev, h.ctypes.data))
+    tmp = tempfile.NamedTemporaryFile(suffix=".nc", delete=False)
+    tmp.close()
+    try:
+        t0 = time.perf_counter()
+        write_amber_netcdf_fast(tmp.name, h, dims)
+        legs["file"] = (f"AMBER NetCDF (CDF-2), {os.path.getsize(tmp.name) / 1e9:.2f} GB, written in "
+                        f"{time.perf_counter() - t0:.1f} s, read from the page cache")
+        fu = FileUniverse(tmp.name, dt=1.0, charges=charges)
+        leg("class_file", fu, reps=1)
+        fu.trajectory.file.close()
+    finally:
+        os.unlink(tmp.name)
+    del h, um
+    # every leg analysed the same numbers (float64 = the widened float32)
+    ref = keep["class_hbm_f64"].results
+    for name, o in keep.items():
+        legs[name]["max_rel_deviation_from_hbm_f64"] = max(
+            max_rel_deviation(o.results.msd_self[:, :, 1:], ref.msd_self[:, :, 1:], floor=0.0),
+            float(np.abs(o.results.msd_cross - ref.msd_cross).max() / np.abs(ref.msd_cross).max()))
+    # the fit on top (host NumPy / SciPy, transport.py:59-286)
+    o = keep["class_hbm_f64"]
+    tb = T // B
+    t0 = time.perf_counter()
+    o.calculate_transport_coefficients(start=1, stop=tb // 10, scale="linear")
+    fit_linear = time.perf_counter() - t0
+    D_i, L_ij = o.results.D_i.copy(), o.results.L_ij.copy()
+    t0 = time.perf_counter()
+    o.calculate_transport_coefficients()
+    legs["transport_coefficients"] = {
+        "fit_linear_window_ms": fit_linear * 1e3, "fit_reference_defaults_ms": (time.perf_counter() - t0) * 1e3,
+        "D_i_over_sigma2_over_2dt": [float(x) for x in (D_i / (sigma ** 2 / 2)).ravel()],
+        "L_ii_over_L_ii_self_expected": [float(L_ij[b, i, i] / ((N // 2) * sigma ** 2 / 2 / L ** 3))
+                                         for b in range(B) for i in range(2)],
+        "window": f"lags 1 .. {tb // 10}, linear scale; free walk: D = sigma^2 / 2 dt, L_ii^self = N_i D / (kBT V)"}
+    return legs
 
 
 def bench_rdf_ingest(args, world, resident_fps):

@@ -359,6 +359,11 @@ int mdx_msd_push_f64(mdx_msd_t h, int group, const double *pos, int64_t n_frames
                      int unwrap, const double *dims, int zero_dims, const double *shift);
 int mdx_msd_system_com_f64(mdx_msd_t h, const double *pos, int64_t n_frames, int64_t n_sel,
                            const double *masses, int unwrap, const double *dims, int wrap, double *out);
+/* Cross displacements between the groups' summed trajectories, out float64[n_pairs][n_blocks][n_frames_block]:
+ * msd_fft(sum_i r, sum_j r) of reference correlation.py:461-668 as Onsager._conclude calls it for every pair
+ * (transport.py:1034, 1052; pairs int32[n_pairs][2], i == j gives the collective MSD of a group), computed
+ * from the summed trajectories the pushes have left in HBM (after mdx_msd_allreduce: of all ranks). */
+int mdx_msd_cross(mdx_msd_t h, const int32_t *pairs, int64_t n_pairs, double *out);
 /* ... and for frames already resident in HBM (a GPU MD engine's output, or a host / file trajectory uploaded
  * once for several groups: mdx_upload, mdx_traj_load_device): d_pos float32 (elem_bytes 4) or float64 (8)
  * [n_frames][n_total][3]; index: host int32[n_index] rows of the selection in analysis order, or NULL for

@@ -583,6 +583,14 @@ class MsdEngine(_Engine):
         check(lib().mdx_msd_result(self.handle, _ptr(msd), _ptr(traj)))
         return msd, traj
 
+    def cross(self, pairs):
+        """float64[n_pairs, n_blocks, t_block]: ``msd_fft(sum_i r, sum_j r)`` for every pair of groups, from the
+        summed trajectories in HBM (``mdx_msd_cross``)."""
+        p = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        out = np.empty((len(p), self.n_blocks, self.t_block))
+        check(lib().mdx_msd_cross(self.handle, _ptr(p), len(p), _ptr(out)))
+        return out
+
     def result_acf(self):
         """float64[n_groups, n_blocks, t_block]: sum over the pushed entities and dimensions of
         ``sum_k x(k) x(k+m)`` (the un-normalised vector ACF; ``mdx_msd_result_acf``)."""

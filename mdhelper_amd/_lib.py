@@ -130,6 +130,7 @@ _SIGNATURES = {
     "mdx_msd_set_initial_images": (c_int, [_vp, _vp, c_int64]),
     "mdx_msd_result_acf": (c_int, [_vp, _vp]),
     "mdx_msd_system_com_traj": (c_int, [_vp, _vp, _vp, c_int64, _vp, c_int64, _vp, c_int, _vp, c_int, _vp]),
+    "mdx_msd_cross": (c_int, [_vp, _vp, c_int64, _vp]),
     "mdx_msd_push_frames_device": (c_int, [_vp, c_int, _vp, c_int, c_int64, c_int64, _vp, c_int64, c_int, _vp,
                                            c_int, _vp]),
     "mdx_msd_system_com_device": (c_int, [_vp, _vp, c_int, c_int64, c_int64, _vp, c_int64, _vp, c_int, _vp,

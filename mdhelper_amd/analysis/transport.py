@@ -21,6 +21,7 @@ Fits and unit conversions are O(N_t) host NumPy exactly as in the reference.
 from __future__ import annotations
 
 import itertools
+import time
 import warnings
 from typing import Union
 
@@ -360,8 +361,19 @@ class Onsager(SerialAnalysisBase):
         B, Tb = self._n_blocks, self._n_frames_block
         multi = self._comm.world_size > 1
 
+        # wall-clock split of one analysis for bench.py (off unless _profile is set: the marks wait for the device)
+        self._timings, mark_t = {}, [time.perf_counter()]
+
+        def mark(phase):
+            if self._profile:
+                _core.synchronize(self._device)
+                now = time.perf_counter()
+                self._timings[phase] = self._timings.get(phase, 0.0) + now - mark_t[0]
+                mark_t[0] = now
+
         if self._fft:
             eng = _core.MsdEngine(Tb, B, self._n_groups, dev=self._device)
+            mark("engine_create")
             if self._from_file:
                 # The analysed frames are brought into HBM ONCE (trajectory file -> pinned ring -> HBM;
                 # host memory through the ring's copy threads, or by DMA where it is page-locked; a
@@ -373,6 +385,7 @@ class Onsager(SerialAnalysisBase):
                 native = getattr(self._trajectory, "native", None)
                 unwrap_dims = self._dimensions if self._unwrap else None
                 resident = self._resident_frames(numbers, native)
+                mark("frames_to_hbm")
                 if resident is not None:
                     n_total = resident.shape[1]
 
@@ -465,6 +478,8 @@ class Onsager(SerialAnalysisBase):
             for g, own in enumerate(self._own_slices):
                 if own.stop > own.start and not self._from_file:
                     eng.push(g, self._positions, own.start, own.stop - own.start, zero_mask)
+            mark("prepare_and_push")
+            cross = None
             if multi and getattr(self._comm, "device_collectives", False):
                 eng.allreduce(self._comm)
                 self_sum, traj = eng.result()
@@ -473,10 +488,15 @@ class Onsager(SerialAnalysisBase):
                 if multi:
                     self_sum = self._comm.allreduce(self_sum)
                     traj = self._comm.allreduce(traj)
+            mark("result")
+            if hasattr(eng, "cross") and (not multi or getattr(self._comm, "device_collectives", False)):
+                # the summed trajectories of every rank are in HBM: all pairs in one batch
+                cross = eng.cross(self.results.pairs)
             eng.close()
             msd = correlation.msd_fft
         else:
             # direct definition: per-particle MSDs and summed trajectories on the host
+            cross = None
             self_sum = np.zeros((self._n_groups, B, Tb))
             traj = np.zeros((self._n_groups, B, Tb, 3))
             for g, own in enumerate(self._own_slices):
@@ -493,12 +513,13 @@ class Onsager(SerialAnalysisBase):
         for i, (i1, i2) in enumerate(self.results.pairs):
             if i1 == i2:
                 if self._Ns[i1]:
-                    self.results.msd_cross[i] = msd(traj[i1], axis=1)
+                    self.results.msd_cross[i] = cross[i] if cross is not None else msd(traj[i1], axis=1)
                     self.results.msd_self[i1] = self_sum[i1] / self._Ns[i1]
                 else:
                     self.results.msd_cross[i] = self.results.msd_self[i1] = np.nan
             elif self._Ns[i1] and self._Ns[i2]:
-                self.results.msd_cross[i] = msd(traj[i1], traj[i2], axis=1)
+                self.results.msd_cross[i] = (cross[i] if cross is not None
+                                             else msd(traj[i1], traj[i2], axis=1))
             else:
                 self.results.msd_cross[i] = np.nan
 
@@ -506,7 +527,9 @@ class Onsager(SerialAnalysisBase):
         D = 2 * (~delete_dimensions).sum()
         self.results.msd_cross /= D
         self.results.msd_self /= D
+        mark("cross_msds")
 
+    _profile = False    # bench.py: split one analysis into phases (self._timings)
     _hbm_share = 0.3    # of the free HBM the analysed float32 frames may take to be kept whole
 
     def _resident_frames(self, numbers, native):

@@ -59,11 +59,16 @@ struct DeviceBuffer {
     void release();            // hipFree (waits for the device: safe while kernels may still read the block)
     // Hands the block to the per-device cache instead of freeing it — ONLY after every stream that may have
     // touched it has been synchronised (the destroy paths).  An analysis object per call, the reference's
-    // usage, otherwise pays ~10 ms of hipMalloc / hipFree per object; the cache is bounded (4 GiB, blocks
-    // up to 512 MiB) and lives as long as the process.
+    // usage, otherwise pays ~10 ms of hipMalloc / hipFree per object — and, for the multi-GB blocks of the
+    // MSD engine, now and then seconds inside hipMalloc; the cache is bounded (a quarter of the device's
+    // memory, MDX_CACHE_GB), is given back when an allocation fails or on mdx_trim_cache, and lives as long
+    // as the process.
     void recycle();
     template <typename T> T *as() const { return static_cast<T *>(ptr); }
 };
+
+// bytes the cache of `dev` holds: memory hipMemGetInfo reports as used but an allocation of the library can have
+size_t cached_device_bytes(int dev);
 
 // Non-blocking streams are handed out from a per-device pool and go back to it when a handle is destroyed
 // (after they have been synchronised): creating and destroying a stream costs about a millisecond each way,

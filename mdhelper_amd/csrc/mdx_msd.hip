@@ -28,6 +28,7 @@
 
 #include <map>
 #include <mutex>
+#include <tuple>
 
 using namespace mdx;
 
@@ -71,17 +72,35 @@ struct FftPlan {
     size_t work_bytes = 0;
 };
 
+// Plans are kept for the life of the process, per (device, length, direction, batch): creating the plans of a
+// 204 800-point transform costs ~10 - 25 ms each time (seconds the first time, while rocFFT compiles its
+// kernels) — per analysis object, when every Onsager(...).run() and every msd_fft() call made its own.  A plan
+// is not tied to a stream (the execution info is), so handles on different streams share it; rocFFT plans
+// may be executed concurrently.
+struct PlanStore {
+    std::mutex m;
+    std::map<std::tuple<int, int64_t, int, int64_t>, FftPlan> plans;
+};
+PlanStore &plan_store()
+{
+    static PlanStore *p = new PlanStore();   // never destroyed: rocFFT may be gone at exit
+    return *p;
+}
+
 struct FftCache {
-    std::map<std::pair<int, int64_t>, FftPlan> plans;   // (direction, batch)
     rocfft_execution_info info = nullptr;
     DeviceBuffer work;
     int64_t n_fft = 0;
 
-    int get(int inverse, int64_t batch, FftPlan **out)
+    int get(int inverse, int64_t batch, FftPlan *out)
     {
-        auto key = std::make_pair(inverse, batch);
-        auto it = plans.find(key);
-        if (it == plans.end()) {
+        int dev = 0;
+        MDX_HIP(hipGetDevice(&dev));
+        PlanStore &store = plan_store();
+        std::lock_guard<std::mutex> lk(store.m);
+        auto key = std::make_tuple(dev, n_fft, inverse, batch);
+        auto it = store.plans.find(key);
+        if (it == store.plans.end()) {
             FftPlan p;
             size_t len = (size_t)n_fft;
             rocfft_plan_description desc = nullptr;
@@ -106,42 +125,39 @@ struct FftCache {
                 return fail(MDX_ERR_ROCFFT, "rocfft_plan_create(n=%lld, batch=%lld) failed (%d)",
                             (long long)n_fft, (long long)batch, (int)s);
             MDX_FFT(rocfft_plan_get_work_buffer_size(p.plan, &p.work_bytes));
-            it = plans.emplace(key, p).first;
+            it = store.plans.emplace(key, p).first;
         }
-        *out = &it->second;
+        *out = it->second;
         return MDX_OK;
     }
 
     int exec(int inverse, int64_t batch, void *in, void *out, hipStream_t stream)
     {
-        FftPlan *p = nullptr;
+        FftPlan p;
         MDX_TRY(get(inverse, batch, &p));
         if (!info)
             MDX_FFT(rocfft_execution_info_create(&info));
         MDX_FFT(rocfft_execution_info_set_stream(info, stream));
-        if (p->work_bytes) {
-            if (p->work_bytes > work.bytes) {
+        if (p.work_bytes) {
+            if (p.work_bytes > work.bytes) {
                 // the previous work buffer may still be in use on the stream
                 MDX_HIP(hipStreamSynchronize(stream));
-                MDX_TRY(work.ensure(p->work_bytes));
+                MDX_TRY(work.ensure(p.work_bytes));
             }
-            MDX_FFT(rocfft_execution_info_set_work_buffer(info, work.ptr, p->work_bytes));
+            MDX_FFT(rocfft_execution_info_set_work_buffer(info, work.ptr, p.work_bytes));
         }
         void *ib[1] = {in}, *ob[1] = {out};
-        MDX_FFT(rocfft_execute(p->plan, ib, ob, info));
+        MDX_FFT(rocfft_execute(p.plan, ib, ob, info));
         return MDX_OK;
     }
 
+    // the caller has synchronised the streams the transforms ran on
     void destroy()
     {
-        for (auto &kv : plans)
-            if (kv.second.plan)
-                rocfft_plan_destroy(kv.second.plan);
-        plans.clear();
         if (info)
             rocfft_execution_info_destroy(info);
         info = nullptr;
-        work.release();
+        work.recycle();
     }
 };
 
@@ -276,6 +292,39 @@ __global__ void corr_product_kernel(const double2 *__restrict__ A, const double2
     }
 }
 
+// summed trajectories [G][B * T_b][3] -> zero-padded series X[((g * B + b) * 3 + k)][n_fft]
+__global__ void cross_pad_kernel(const double *__restrict__ traj, int64_t n_rows /* G * B */, int64_t t_block,
+                                 int64_t n_fft, double *__restrict__ X)
+{
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n_rows * 3 * n_fft)
+        return;
+    const int64_t s = i / n_fft, t = i - s * n_fft;
+    const int64_t row = s / 3;
+    const int k = int(s - 3 * row);
+    X[i] = t < t_block ? traj[(row * t_block + t) * 3 + k] : 0.0;
+}
+
+// Q[p * B + b][f] = sum_k 2 Re(conj(F_i) F_j): the spectrum of corr(a, b)(m) + corr(b, a)(m), summed over xyz
+__global__ void cross_product_kernel(const double2 *__restrict__ F, const int *__restrict__ pairs, int n_blocks,
+                                     int64_t nc, double2 *__restrict__ Q)
+{
+    const int64_t f = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (f >= nc)
+        return;
+    const int p = blockIdx.y / n_blocks, b = blockIdx.y - p * n_blocks;
+    const int gi = pairs[2 * p], gj = pairs[2 * p + 1];
+    const double2 *A = F + (int64_t(gi) * n_blocks + b) * 3 * nc + f;
+    const double2 *Bv = F + (int64_t(gj) * n_blocks + b) * 3 * nc + f;
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double2 a = A[k * nc], c = Bv[k * nc];
+        acc += a.x * c.x + a.y * c.y;
+    }
+    Q[int64_t(blockIdx.y) * nc + f] = make_double2(2.0 * acc, 0.0);
+}
+
 }  // namespace
 
 struct mdx_msd {
@@ -287,6 +336,7 @@ struct mdx_msd {
     // accumulators: power [G][B][nc] + D [G][B*T_b] contiguous (one all-reduce), traj [G][B*T_b][3]
     DeviceBuffer d_acc, d_traj, d_series, d_spec, d_stage, d_inv_in, d_inv_out;
     DeviceBuffer d_f32, d_index, d_prev, d_image;   // trajectory-file path: frames, unwrap state
+    DeviceBuffer d_cross_f;                         // spectra of the summed trajectories (mdx_msd_cross)
     DeviceBuffer d_xstart, d_seg;                   // ... of the segment-parallel walk (msd_launch_unwrap)
     DeviceBuffer d_masses, d_com_x, d_shift;        // system centre of mass per frame
     // trajectory-file path with groupings="residues"/"segments": rows sorted molecule by molecule
@@ -321,7 +371,7 @@ static int msd_push_device(mdx_msd *h, int group, const double *d_pos, int64_t n
     // chunk the particles so that series + spectrum stay within ~40% of free HBM
     size_t free_b = 0, total_b = 0;
     MDX_HIP(hipMemGetInfo(&free_b, &total_b));
-    free_b += h->d_series.bytes + h->d_spec.bytes;
+    free_b += h->d_series.bytes + h->d_spec.bytes + cached_device_bytes(h->dev);
     const int64_t per_atom = h->own_fft ? 3 * B * h->n_fft * 8   // Y: one complex per two reals
                                         : 3 * B * (h->n_fft * 8 + h->nc * 16);
     int64_t chunk = std::max<int64_t>(1, int64_t(double(free_b) * 0.4) / per_atom);
@@ -810,7 +860,7 @@ static int msd_push_frames(mdx_msd *h, int group, FrameSource &src, int64_t n_se
     // their centres need a second, smaller block)
     size_t free_b = 0, total_b = 0;
     MDX_HIP(hipMemGetInfo(&free_b, &total_b));
-    free_b += h->d_stage.bytes + h->d_mol_com.bytes;
+    free_b += h->d_stage.bytes + h->d_mol_com.bytes + cached_device_bytes(h->dev);
     int64_t chunk = std::max<int64_t>(1, int64_t(double(free_b) * (molecules ? 0.2 : 0.3)) / (T * 24));
     chunk = std::min(chunk, n_sel);
     chunk = ceil_div(n_sel, ceil_div(n_sel, chunk));
@@ -929,10 +979,7 @@ int mdx_msd_create(mdx_msd_t *out, int dev, int64_t n_frames_block, int n_blocks
     h->fft.n_fft = h->n_fft;
     int rc = MDX_OK;
     do {
-        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
-            rc = fail(MDX_ERR_HIP, "hipStreamCreate failed");
-            break;
-        }
+        if ((rc = stream_acquire(&h->stream)) != MDX_OK) break;
         h->timer.stream = h->stream;
         if ((rc = h->d_acc.ensure(size_t(8) * h->acc_len())) != MDX_OK) break;
         if ((rc = h->d_traj.ensure(size_t(8) * h->traj_len())) != MDX_OK) break;
@@ -988,14 +1035,15 @@ int mdx_msd_destroy(mdx_msd_t h)
         (void)hipStreamSynchronize(h->stream);
     h->timer.destroy();
     h->fft.destroy();
+    // (the stream has been synchronised: the blocks and the stream go back to the per-device pools)
     for (DeviceBuffer *b : {&h->d_acc, &h->d_traj, &h->d_series, &h->d_spec, &h->d_stage,
                             &h->d_inv_in, &h->d_inv_out, &h->d_f32, &h->d_index, &h->d_prev, &h->d_xstart, &h->d_seg,
                             &h->d_image, &h->d_tw, &h->d_pfull, &h->d_part, &h->d_masses, &h->d_com_x,
                             &h->d_shift, &h->d_mol_offsets, &h->d_mol_masses, &h->d_mol_total,
-                            &h->d_mol_com})
-        b->release();
+                            &h->d_mol_com, &h->d_cross_f})
+        b->recycle();
     if (h->stream)
-        (void)hipStreamDestroy(h->stream);
+        stream_release(h->stream);
     delete h;
     return MDX_OK;
 }
@@ -1277,6 +1325,62 @@ int mdx_msd_result_acf(mdx_msd_t h, double *acf_sum)
     return msd_result(h, nullptr, acf_sum, nullptr);
 }
 
+// Cross displacements of the groups' summed trajectories, MSD_m = S_m - 2 A_m with r1 = sum of group i, r2 = sum of
+// group j (reference correlation.py:621-668 as transport.py:1034, 1052 call it): everything from the
+// accumulators that are already in HBM — one batched forward transform of the G * B * 3 series, one spectrum
+// product and one inverse per (pair, block), the S_m recurrence on the host.
+int mdx_msd_cross(mdx_msd_t h, const int32_t *pairs, int64_t n_pairs, double *out)
+{
+    MDX_REQUIRE(h && pairs && out, "NULL argument");
+    MDX_REQUIRE(n_pairs >= 1 && n_pairs <= 65535 / h->n_blocks, "pair count out of range");
+    for (int64_t p = 0; p < 2 * n_pairs; ++p)
+        MDX_REQUIRE(pairs[p] >= 0 && pairs[p] < h->n_groups, "group %d out of range", pairs[p]);
+    MDX_TRY(set_device(h->dev));
+    const int B = h->n_blocks;
+    const int64_t Tb = h->t_block, GB = int64_t(h->n_groups) * B, PB = n_pairs * B;
+    MDX_TRY(h->d_series.ensure(size_t(8) * GB * 3 * h->n_fft));
+    MDX_TRY(h->d_inv_in.ensure(size_t(16) * std::max(GB * 3, PB) * h->nc));
+    MDX_TRY(h->d_inv_out.ensure(size_t(8) * std::max(GB, PB) * h->n_fft));
+    MDX_TRY(h->d_cross_f.ensure(size_t(16) * GB * 3 * h->nc));
+    MDX_TRY(h->d_index.ensure(size_t(8) * n_pairs));
+    MDX_HIP(hipMemcpyAsync(h->d_index.ptr, pairs, size_t(8) * n_pairs, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(cross_pad_kernel, dim3((unsigned)ceil_div(GB * 3 * h->n_fft, 256)), dim3(256), 0, h->stream,
+                       h->d_traj.as<double>(), GB, Tb, h->n_fft, h->d_series.as<double>());
+    MDX_TRY(h->fft.exec(0, GB * 3, h->d_series.ptr, h->d_cross_f.ptr, h->stream));
+    hipLaunchKernelGGL(cross_product_kernel, dim3((unsigned)ceil_div(h->nc, 256), (unsigned)PB), dim3(256), 0,
+                       h->stream, h->d_cross_f.as<double2>(), h->d_index.as<int>(), B, h->nc,
+                       h->d_inv_in.as<double2>());
+    MDX_TRY(h->fft.exec(1, PB, h->d_inv_in.ptr, h->d_inv_out.ptr, h->stream));
+    MDX_HIP(hipGetLastError());
+    std::vector<double> corr(size_t(PB) * Tb), tr(size_t(h->traj_len()));
+    MDX_HIP(hipMemcpy2DAsync(corr.data(), size_t(Tb) * 8, h->d_inv_out.ptr, size_t(h->n_fft) * 8,
+                             size_t(Tb) * 8, (size_t)PB, hipMemcpyDeviceToHost, h->stream));
+    MDX_HIP(hipMemcpyAsync(tr.data(), h->d_traj.ptr, size_t(8) * h->traj_len(), hipMemcpyDeviceToHost, h->stream));
+    MDX_HIP(hipStreamSynchronize(h->stream));
+    const double inv_n = 1.0 / double(h->n_fft);
+    std::vector<double> d((size_t)Tb);
+    for (int64_t p = 0; p < n_pairs; ++p)
+        for (int b = 0; b < B; ++b) {
+            const double *a = tr.data() + (int64_t(pairs[2 * p]) * B + b) * Tb * 3;
+            const double *c = tr.data() + (int64_t(pairs[2 * p + 1]) * B + b) * Tb * 3;
+            double total = 0.0;
+            for (int64_t t = 0; t < Tb; ++t) {
+                d[size_t(t)] = (a[3 * t] * c[3 * t] + a[3 * t + 1] * c[3 * t + 1]) + a[3 * t + 2] * c[3 * t + 2];
+                total += d[size_t(t)];
+            }
+            const double *r = corr.data() + (p * B + b) * Tb;
+            double *o = out + (p * B + b) * Tb;
+            double run = 0.0;
+            for (int64_t m = 0; m < Tb; ++m) {
+                if (m > 0)
+                    run += d[size_t(m - 1)] + d[size_t(Tb - m)];
+                const double w = double(Tb - m);
+                o[m] = (2.0 * total - run) / w - (r[m] * inv_n) / w;
+            }
+        }
+    return MDX_OK;
+}
+
 static int msd_result(mdx_msd_t h, double *msd_self_sum, double *acf_sum, double *sum_traj)
 {
     MDX_TRY(set_device(h->dev));
@@ -1417,11 +1521,12 @@ int mdx_correlate(int dev, const double *a, const double *b, int64_t n_series, i
         return MDX_OK;
     };
     rc = run();
+    (void)hipDeviceSynchronize();
     fft.destroy();
-    d_in.release();
-    d_pad.release();
-    d_fa.release();
-    d_fb.release();
+    d_in.recycle();
+    d_pad.recycle();
+    d_fa.recycle();
+    d_fb.recycle();
     return rc;
 }
 

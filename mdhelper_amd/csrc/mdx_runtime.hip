@@ -2,6 +2,8 @@
 // stream timers and the synthetic-trajectory generator used by bench.py/tests.
 #include "mdx_common.hpp"
 
+#include <unordered_map>
+
 namespace mdx {
 
 char *error_buffer()
@@ -34,17 +36,59 @@ int set_device(int dev)
 }
 
 namespace {
+// Device blocks of destroyed handles and freed DeviceArrays, kept for the next analysis object.  Measured on
+// MI355X / ROCm 7.2 (scripts/diag/onsager_stalls.py): an Onsager(...).run() per call at C4 size returned ~50 GB
+// to the driver at the end of every analysis, and every other analysis then waited 1.1 - 3.3 s inside the
+// hipMalloc of its 24.6 GB block; creating and freeing the small buffers cost another ~10 ms per object.
 struct BlockCache {
     std::mutex m;
     std::vector<std::pair<size_t, void *>> blocks[64];   // per device: (bytes, pointer)
     size_t cached[64] = {};
+    size_t limit[64] = {};                               // 0: not asked yet
+    std::unordered_map<void *, size_t> live[64];         // blocks handed out by mdx_malloc
 };
 BlockCache &block_cache()
 {
     static BlockCache *c = new BlockCache();   // never destroyed: the HIP runtime may be gone at exit
     return *c;
 }
-constexpr size_t CACHE_BLOCK_MAX = size_t(512) << 20, CACHE_TOTAL_MAX = size_t(4) << 30;
+
+// at most a quarter of the device's memory (and at least 4 GiB) stays cached; MDX_CACHE_GB overrides
+size_t cache_limit(BlockCache &c, int dev)
+{
+    if (c.limit[dev] == 0) {
+        size_t lim = size_t(4) << 30;
+        if (const char *e = getenv("MDX_CACHE_GB")) {
+            lim = size_t(atoll(e) < 0 ? 0 : atoll(e)) << 30;
+        } else {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b / 4 > lim)
+                lim = total_b / 4;
+            else
+                (void)hipGetLastError();
+        }
+        c.limit[dev] = lim ? lim : 1;
+    }
+    return c.limit[dev];
+}
+
+// smallest cached block of `dev` that fits `want` without wasting more than half of itself (lock held)
+bool take_cached(BlockCache &c, int dev, size_t want, void **ptr, size_t *bytes)
+{
+    auto &v = c.blocks[dev];
+    size_t best = v.size();
+    for (size_t i = 0; i < v.size(); ++i)
+        if (v[i].first >= want && v[i].first <= 2 * want && (best == v.size() || v[i].first < v[best].first))
+            best = i;
+    if (best == v.size())
+        return false;
+    *ptr = v[best].second;
+    *bytes = v[best].first;
+    c.cached[dev] -= v[best].first;
+    v[best] = v.back();
+    v.pop_back();
+    return true;
+}
 
 // hipFree every cached block of a device (the current one must be `dev`); returns the bytes given back
 size_t flush_block_cache(int dev)
@@ -62,6 +106,15 @@ size_t flush_block_cache(int dev)
 }
 }  // namespace
 
+size_t cached_device_bytes(int dev)
+{
+    if (dev < 0 || dev >= 64)
+        return 0;
+    BlockCache &c = block_cache();
+    std::lock_guard<std::mutex> lk(c.m);
+    return c.cached[dev];
+}
+
 int DeviceBuffer::ensure(size_t need)
 {
     if (need <= bytes)
@@ -73,20 +126,8 @@ int DeviceBuffer::ensure(size_t need)
     if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
         BlockCache &c = block_cache();
         std::lock_guard<std::mutex> lk(c.m);
-        auto &v = c.blocks[dev];
-        // smallest cached block that fits without wasting more than half of itself
-        size_t best = v.size();
-        for (size_t i = 0; i < v.size(); ++i)
-            if (v[i].first >= want && v[i].first <= 2 * want && (best == v.size() || v[i].first < v[best].first))
-                best = i;
-        if (best != v.size()) {
-            ptr = v[best].second;
-            bytes = v[best].first;
-            c.cached[dev] -= bytes;
-            v[best] = v.back();
-            v.pop_back();
+        if (take_cached(c, dev, want, &ptr, &bytes))
             return MDX_OK;
-        }
     }
     hipError_t e = hipMalloc(&ptr, want);
     if (e == hipErrorOutOfMemory) {
@@ -115,10 +156,10 @@ void DeviceBuffer::recycle()
     if (!ptr)
         return;
     int dev = -1;
-    if (bytes <= CACHE_BLOCK_MAX && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
         BlockCache &c = block_cache();
         std::lock_guard<std::mutex> lk(c.m);
-        if (c.cached[dev] + bytes <= CACHE_TOTAL_MAX) {
+        if (c.cached[dev] + bytes <= cache_limit(c, dev)) {
             c.blocks[dev].emplace_back(bytes, ptr);
             c.cached[dev] += bytes;
             ptr = nullptr;
@@ -657,14 +698,59 @@ int mdx_malloc(int dev, size_t bytes, void **dptr)
 {
     MDX_REQUIRE(dptr != nullptr, "dptr is NULL");
     MDX_TRY(set_device(dev));
-    hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+    // blocks of a MiB and more come out of (and go back to, mdx_free) the per-device cache
+    const bool large = bytes >= (size_t(1) << 20) && dev < 64;
+    const size_t want = large ? (bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1) : (bytes ? bytes : 1);
+    BlockCache &c = block_cache();
+    if (large) {
+        std::lock_guard<std::mutex> lk(c.m);
+        size_t got = 0;
+        if (take_cached(c, dev, want, dptr, &got)) {
+            c.live[dev][*dptr] = got;
+            return MDX_OK;
+        }
+    }
+    hipError_t e = hipMalloc(dptr, want);
     if (e == hipErrorOutOfMemory) {
-        // the handles' recycled blocks (DeviceBuffer::recycle) go back first
+        // the recycled blocks go back first
         (void)hipGetLastError();
         flush_block_cache(dev);
-        e = hipMalloc(dptr, bytes ? bytes : 1);
+        e = hipMalloc(dptr, want);
     }
     MDX_HIP(e);
+    if (large) {
+        std::lock_guard<std::mutex> lk(c.m);
+        c.live[dev][*dptr] = want;
+    }
+    return MDX_OK;
+}
+
+int mdx_free(int dev, void *dptr)
+{
+    MDX_TRY(set_device(dev));
+    if (!dptr)
+        return MDX_OK;
+    BlockCache &c = block_cache();
+    size_t bytes = 0;
+    if (dev < 64) {
+        std::lock_guard<std::mutex> lk(c.m);
+        auto it = c.live[dev].find(dptr);
+        if (it != c.live[dev].end()) {
+            bytes = it->second;
+            c.live[dev].erase(it);
+        }
+    }
+    if (bytes) {
+        // like hipFree: nothing queued may still touch the block when it changes hands
+        MDX_HIP(hipDeviceSynchronize());
+        std::lock_guard<std::mutex> lk(c.m);
+        if (c.cached[dev] + bytes <= cache_limit(c, dev)) {
+            c.blocks[dev].emplace_back(bytes, dptr);
+            c.cached[dev] += bytes;
+            return MDX_OK;
+        }
+    }
+    MDX_HIP(hipFree(dptr));
     return MDX_OK;
 }
 
@@ -689,14 +775,6 @@ int mdx_upload(int dev, void *d_dst, const void *src, size_t bytes)
     stream_release(stream);
     MDX_TRY(rc);
     MDX_HIP(e);
-    return MDX_OK;
-}
-
-int mdx_free(int dev, void *dptr)
-{
-    MDX_TRY(set_device(dev));
-    if (dptr)
-        MDX_HIP(hipFree(dptr));
     return MDX_OK;
 }
 
