@@ -970,6 +970,10 @@ int mdx_msd_create(mdx_msd_t *out, int dev, int64_t n_frames_block, int n_blocks
         // shorter than the power of two: 32 769 .. 102 400 frames (MDX_MSD_NFFT=pow2 keeps 2^18)
         if (own_len == (int64_t(1) << 18) && 2 * n_frames_block <= 204800 && !force_pow2)
             own_len = 204800;
+        // ... and 25 600 = 400 x 64 for blocks of 8 193 .. 12 800 frames (C4 with eight blocks: 2^15 would pad the
+        // half-transformed block by 28 %)
+        if (own_len == (int64_t(1) << 15) && 2 * n_frames_block <= 25600 && !force_pow2)
+            own_len = 25600;
         if (own_len && msdfft::shape_for(own_len).r1 && !force_ref)
             h->n_fft = own_len;
         else if (force_pow2 || (!force_ref && 2 * p <= 3 * h->n_fft))

@@ -1147,6 +1147,83 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_rows512_power_kernel(
     *pout = accumulate ? *pout + total : total;
 }
 
+// Pass B for 64-point rows (n_fft = 25 600 = 400 x 64: blocks of 8 193 .. 12 800 frames — C4 with eight blocks, whose
+// half-transformed block is then as large as with one block; padded to 2^15 it was 28 % larger).
+// A (k1, pair group) run of Y is 64 n2 x 8 pairs = 8 KB, eight consecutive pair groups are 64 KB contiguous.  Wave g of
+// a block streams pair groups g, g + 8, ... of the block's share on its own: lane (pair p = lane & 7, j = lane >> 3)
+// loads n2 = j + 8 r, r < 8 — a wave instruction reads 1 KB contiguous, and the eight values ARE butterfly j of the
+// first radix-8 stage.  Stage 1 on those registers, outputs times W_64^(j ka) (seven per-thread constants) into the
+// wave's own 8 x 64 slots, stage 2 back into registers: lane (p, ka) holds X[ka + 8 kb] of pair p and adds |X|^2 to
+// eight running sums.  Nothing in the loop is shared between waves: no block barrier until the sums meet at the end.
+template <int R1>
+__global__ __launch_bounds__(THREADS, 4) void msd_fft_rows64_power_kernel(
+    const double2 *__restrict__ Y, int p_pad, const double2 *__restrict__ tw_r2,
+    double *__restrict__ Pfull, int accumulate)
+{
+    constexpr int R2 = 64, ZS = R2 + 1;
+    __shared__ double2 zb[PG][PG][ZS];            // [wave][pair][point]
+    const int k1 = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_all = p_pad / PG, n_parts = gridDim.z, part = blockIdx.z;
+    const int n_groups = (n_all - part + n_parts - 1) / n_parts;      // groups part, part + n_parts, ... of the block
+    double *pout = Pfull + ((int64_t(part) * gridDim.y + b) * R1 + k1) * R2 + tid;
+    const int n_mine = (n_groups - wave + PG - 1) / PG;               // ... of which this wave takes wave, wave + 8, ...
+    const int p = lane & 7, j = lane >> 3;
+    // W_64^(j r), r = 1 .. 7, from the half table exp(-2 pi i m / 64), m < 32
+    double2 w[8];
+#pragma unroll
+    for (int r = 1; r < 8; ++r)
+        w[r] = tw_at<R2>(tw_r2, j * r);
+    double acc[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        acc[r] = 0.0;
+    if (n_mine > 0) {
+        const int64_t g_stride = int64_t(n_parts) * PG * (R2 * PG);     // this wave's next pair group
+        const double2 *src = Y + ((int64_t(b) * R1 + k1) * n_all + part + int64_t(wave) * n_parts) * (R2 * PG) + lane;
+        double2 v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            v[r] = src[64 * r];
+        double2 *z = &zb[wave][p][0];
+        for (int it = 0; it < n_mine; ++it) {
+            dft8(v);
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                z[8 * r + j] = r ? cmul(v[r], w[r]) : v[r];
+            {   // the next pair group is in flight during stage 2 (the last iteration reloads its own: no branch)
+                const int64_t off = int64_t(min(it + 1, n_mine - 1)) * g_stride;
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    v[r] = src[off + 64 * r];
+            }
+            wave_lds_fence();
+            double2 u[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                u[r] = z[8 * j + r];        // lane (p, ka = j): the eight first-stage outputs ka of butterflies r
+            dft8(u);
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                acc[r] = fma(u[r].x, u[r].x, fma(u[r].y, u[r].y, acc[r]));
+            wave_lds_fence();
+        }
+    }
+    // the sums of the 8 waves x 8 pairs, added in a fixed order: red[wave * 8 + pair][k2], k2 = ka + 8 kb
+    __syncthreads();
+    double *red = reinterpret_cast<double *>(&zb[0][0][0]);      // 64 x 64 doubles
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        red[(wave * PG + p) * R2 + j + 8 * r] = acc[r];
+    __syncthreads();
+    if (tid < R2) {
+        double total = 0.0;
+        for (int i = 0; i < PG * PG; ++i)
+            total += red[i * R2 + tid];
+        *pout = accumulate ? *pout + total : total;
+    }
+}
+
 // P[b][k] += sum over the parts of (Pfull[part][b][k] + Pfull[part][b][N - k]) / 2 for the half
 // spectrum k <= N/2, with Pfull stored as [k1][k2], k = k1 + R1 k2.
 __global__ __launch_bounds__(256) void msd_power_fold_kernel(const double *__restrict__ Pfull,
@@ -1185,6 +1262,8 @@ inline Shape shape_for(int64_t n_fft)
         s.r1 = 64, s.r2 = 512;
     else if (n_fft == (int64_t(1) << 16))
         s.r1 = 64, s.r2 = 1024;
+    else if (n_fft == 25600)
+        s.r1 = 400, s.r2 = 64;
     else if (n_fft == 204800)
         s.r1 = 400, s.r2 = 512;
     else if (n_fft == (int64_t(1) << 18))
@@ -1316,15 +1395,24 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
     } else if (sh.r1 == 400 && part) {
         // per-frame sums fused into pass A: super groups of SG pair groups, >= ~1024 blocks
         const int n_sg = fused_super_groups(p_pad);
-        const int fsplit = slots_split(int64_t(n_sg) * n_blocks, 8, 64);
-        hipLaunchKernelGGL((msd_fft_cols400_fused_kernel<512>), dim3((unsigned)n_sg, (unsigned)fsplit, (unsigned)n_blocks),
-                           dim3(THREADS), 0, stream, pos, n_total, first, n_elem, t_block, zero_dims, p_pad,
-                           tw_r1, twN, Y, part, head);
+        const int fsplit = slots_split(int64_t(n_sg) * n_blocks, 8, std::min(64, sh.r2));
+        if (sh.r2 == 64)
+            hipLaunchKernelGGL((msd_fft_cols400_fused_kernel<64>), dim3((unsigned)n_sg, (unsigned)fsplit, (unsigned)n_blocks),
+                               dim3(THREADS), 0, stream, pos, n_total, first, n_elem, t_block, zero_dims, p_pad,
+                               tw_r1, twN, Y, part, head);
+        else
+            hipLaunchKernelGGL((msd_fft_cols400_fused_kernel<512>), dim3((unsigned)n_sg, (unsigned)fsplit, (unsigned)n_blocks),
+                               dim3(THREADS), 0, stream, pos, n_total, first, n_elem, t_block, zero_dims, p_pad,
+                               tw_r1, twN, Y, part, head);
         hipLaunchKernelGGL(msd_partials_reduce_kernel,
                            dim3((unsigned)((int64_t(sh.r2) * SUMS_ROWS + 255) / 256), (unsigned)n_blocks), dim3(256), 0,
                            stream, part, n_sg, sh.r2, 1, SUMS_ROWS, t_block, traj, dsq);
-        hipLaunchKernelGGL((msd_fft_rows512_power_kernel<400>), gb, dim3(THREADS), 0, stream, Y, p_pad,
-                           tw_r2, Pfull, accumulate);
+        if (sh.r2 == 64)
+            hipLaunchKernelGGL((msd_fft_rows64_power_kernel<400>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,
+                               Pfull, accumulate);
+        else
+            hipLaunchKernelGGL((msd_fft_rows512_power_kernel<400>), gb, dim3(THREADS), 0, stream, Y, p_pad,
+                               tw_r2, Pfull, accumulate);
     } else if (sh.r1 == 400) {
         hipLaunchKernelGGL((msd_fft_cols400_kernel<512>), ga, dim3(THREADS), 0, stream, pos, n_total, first,
                            n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y);
