@@ -70,6 +70,9 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="rdf at N=1: skip the short C3 / C4 / C2(ii) legs embedded under 'extra'")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="walk the N-rank control plane without touching a GPU: launcher, rendezvous, the 128-byte id "
+                         "broadcast, the shard plan of the workload, one host all-reduce; prints the plan")
     ap.add_argument("--no-onsager", action="store_true",
                     help="msd at N=1: skip the operator-surface legs (Onsager(...).run() on HBM / host / file data)")
     ap.add_argument("--host-path", action="store_true",
@@ -167,7 +170,9 @@ class World:
         return arr if self.comm is None else self.comm.allreduce(arr, op="sum")
 
     def describe(self):
-        return {"comm": self.kind, "rccl_ranks": self.rccl_ranks}
+        # "rccl": the accumulators of this run met in an RCCL all-reduce (false at N = 1 — nothing to reduce —
+        # and on the host-socket route, which earns no multi-GPU credit)
+        return {"comm": self.kind, "rccl_ranks": self.rccl_ranks, "rccl": self.kind == "rccl"}
 
     def close(self):
         if self.comm is not None:
@@ -1130,13 +1135,59 @@ def run_ingest(args, world, resident_fps):
         return {"error": f"{type(exc).__name__}: {exc}"}
 
 
+def dry_run(args):
+    """One rank of ``bench.py --gpus N --dry-run``: everything an N-rank run does around the kernels, with the
+    engines left out and no HIP call — rendezvous (rank 0 hosts it), the broadcast of a 128-byte id (what
+    ncclGetUniqueId's travels as), the shard plan of the workload (frames for rdf / sq / isf, particles for msd:
+    comm.shard_range, the plan the engines receive), one host all-reduce of per-rank work counts and a barrier.
+    What it leaves untested on a real node is RCCL itself."""
+    from mdhelper_amd.comm import shard_range
+    from mdhelper_amd.launch import Rendezvous
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    rdzv = Rendezvous(rank, world) if world > 1 else None
+    token = bytes((7 * i + 1) & 255 for i in range(128))
+    got = rdzv.bcast(token if rank == 0 else None) if rdzv else token
+    if args.workload == "msd":
+        n, unit = args.atoms or 10000, "particles"
+        groups = [(0, n // 2), (n // 2, n - n // 2)]
+        mine = [[first + lo, first + hi] for first, count in groups
+                for lo, hi in [shard_range(count, rank, world) if args.shard_fixed else (0, count)]]
+        work = sum(hi - lo for lo, hi in mine)
+        total = n if args.shard_fixed else n * world
+    else:
+        n, unit = args.frames or (1000 if args.workload in ("sq", "isf", "rdf_wide") else 10000), "frames"
+        lo, hi = shard_range(n, rank, world) if args.shard_fixed else (0, n)
+        mine, work = [[lo, hi]], hi - lo
+        total = n if args.shard_fixed else n * world
+    plans = [None] * world
+    if rdzv:
+        blob = rdzv.gather((json.dumps({"rank": rank, "device": local, unit: mine}) + "\n").encode()).decode()
+        plans = [json.loads(x) for x in blob.splitlines()]
+        summed = int(rdzv.allreduce(np.array([work], dtype=np.int64))[0])
+        rdzv.barrier()
+        rdzv.close()
+    else:
+        plans, summed = [{"rank": 0, "device": 0, unit: mine}], work
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "workload": args.workload, "n_gpus": world,
+                          "scaling": "strong" if args.shard_fixed else "weak",
+                          "id_broadcast_ok": got == token, "ranks_in_plan": sorted(p["rank"] for p in plans),
+                          "devices": [p["device"] for p in plans], "plan": plans, "unit": unit,
+                          "work_all_ranks": summed, "work_expected": total, "plan_covers_the_work": summed == total,
+                          "rccl": False, "comm": "not started (dry run: control plane only)"}), flush=True)
+    return 0
+
+
 def launch_ranks(args):
     """``python bench.py --gpus N`` outside any launcher: start N fresh ranks of this script (one per
     GPU) from this process, which never touches the GPU, and relay rank 0's line."""
     from mdhelper_amd import launch
     try:
         rc, text = launch.launch(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:],
-                                 share_devices=args.share_devices)
+                                 share_devices=args.share_devices, check_devices=not args.dry_run)
     except RuntimeError as exc:
         sys.stderr.write(f"bench.py: {exc}\n")
         return 2
@@ -1165,6 +1216,8 @@ def main():
     library = product_library()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
+    if args.dry_run:
+        sys.exit(dry_run(args))
     # Libraries underneath (RCCL) print banners on stdout; keep stdout clean for the
     # one JSON line by pointing fd 1 at stderr until the result is ready.
     sys.stdout.flush()

@@ -259,7 +259,7 @@ def visible_device_count(timeout: float = 300.0) -> int:
 
 
 def launch(n: int, argv: list[str], *, env: dict | None = None, share_devices: bool = False,
-           timeout: float | None = None, poll: float = 0.05):
+           timeout: float | None = None, poll: float = 0.05, check_devices: bool = True):
     """
     Start ``n`` ranks of ``argv`` (run with this interpreter) and wait for them.
 
@@ -267,10 +267,12 @@ def launch(n: int, argv: list[str], *, env: dict | None = None, share_devices: b
     children (exactly the pids started here) are terminated and its return code is reported.
     ``share_devices``: allow more ranks than devices (rank r uses device ``r % devices``; the ranks
     then need a ``SocketComm`` — RCCL cannot put two ranks on one GPU); otherwise fewer visible
-    devices than ranks is an error naming the count.
+    devices than ranks is an error naming the count.  ``check_devices=False`` skips the count (and the
+    child process that takes it) for ranks that do not use a GPU.
     """
     n = int(n)
-    n_dev = visible_device_count()
+    # (check_devices=False: ranks that touch no GPU — bench.py --dry-run — are started without counting any)
+    n_dev = visible_device_count() if check_devices else n
     if n_dev < n and not share_devices:
         raise RuntimeError(f"{n} ranks requested but only {n_dev} HIP device(s) are visible "
                            f"(one process per GPU; HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES apply)")

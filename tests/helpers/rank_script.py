@@ -53,3 +53,26 @@ elif mode == "rccl_or_socket":
     comm.close()
     if rank == 0:
         print(json.dumps({"kind": kind, "class": type(comm).__name__, "total": int(total[0])}))
+elif mode == "rccl_stuck":
+    # ncclCommInitRank that never returns on rank 1 (a stand-in that sleeps): every rank must print the reason and
+    # leave with comm.RCCL_TIMEOUT_EXIT — never carry on over the socket beside a thread blocked in RCCL
+    import time
+    from mdhelper_amd import _core, comm as mcomm
+
+    class FakeRccl:
+        device_collectives = True
+
+        def __init__(self, r, w, uid, dev):
+            if r == 1:
+                time.sleep(3600)
+
+        @staticmethod
+        def unique_id():
+            return bytes(128)
+
+    _core.RcclComm = FakeRccl
+    rdzv = Rendezvous.from_env()
+    mcomm.rccl_comm_or_socket(0, rdzv, timeout=2.0)
+    print(json.dumps({"continued": True}))          # must not be reached
+elif mode == "dry_run":
+    pass

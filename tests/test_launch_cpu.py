@@ -43,6 +43,61 @@ def test_rccl_or_socket_falls_back_on_every_rank_when_rccl_cannot_start():
     assert out["kind"].startswith("host-socket (RCCL unavailable: ncclGetUniqueId")
 
 
+def test_rccl_init_that_never_returns_ends_the_job_with_its_exit_code():
+    """A rank whose ncclCommInitRank does not return has a thread inside RCCL on its device: the job must
+    end — every rank, with the reason on stderr and comm.RCCL_TIMEOUT_EXIT — instead of continuing over the
+    socket."""
+    from mdhelper_amd import comm
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from mdhelper_amd import launch\n"
+            "rc, text = launch.launch(3, [%r, 'rccl_stuck'], share_devices=True, timeout=120)\n"
+            "print('RC', rc); print(text)\n") % (ROOT, SCRIPT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=e)
+    assert f"RC {comm.RCCL_TIMEOUT_EXIT}" in out.stdout, out.stdout + out.stderr
+    assert "continued" not in out.stdout
+    assert "ncclCommInitRank did not return within 2 s on rank 1" in out.stderr
+    assert "leaving with exit code" in out.stderr
+
+
+@pytest.mark.parametrize("flags", [[], ["--workload", "msd", "--shard-fixed"], ["--workload", "sq", "--shard-fixed"]])
+def test_bench_dry_run_walks_the_eight_rank_control_plane(flags):
+    """``bench.py --gpus 8 --dry-run``: launcher, rendezvous, id broadcast, shard plan and a host all-reduce for
+    the rank count the driver's scaling run uses, engines left out, no GPU touched — what stays untested on
+    the real node is RCCL itself."""
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", *flags],
+                         capture_output=True, text=True, timeout=300, env=e)
+    assert out.returncode == 0, out.stderr
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["dry_run"] and line["n_gpus"] == 8 and line["rccl"] is False
+    assert line["id_broadcast_ok"] and line["plan_covers_the_work"]
+    assert line["ranks_in_plan"] == list(range(8)) and line["devices"] == list(range(8))
+    unit = line["unit"]
+    spans = [tuple(x) for p in line["plan"] for x in p[unit]]
+    if "--shard-fixed" in flags:
+        # contiguous, disjoint, balanced shares
+        sizes = [sum(hi - lo for lo, hi in p[unit]) for p in line["plan"]]
+        assert max(sizes) - min(sizes) <= (2 if unit == "particles" else 1)
+        assert len(set(spans)) == len(spans)
+    else:
+        assert len(set(spans)) == 1                      # weak scaling: every rank its own full batch
+    assert line["launcher"].startswith("bench.py")
+
+
+def test_bench_dry_run_under_torch_distributed_run():
+    """The driver's launch line (torch.distributed.run, one rank per GPU) reaches the same rendezvous."""
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29631", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--dry-run", "--shard-fixed"],
+                         capture_output=True, text=True, timeout=600, env=e)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["plan_covers_the_work"] and line["id_broadcast_ok"]
+    assert [p["frames"] for p in line["plan"]] == [[[0, 5000]], [[5000, 10000]]]
+
+
 def test_launcher_stops_the_job_when_a_rank_fails():
     from mdhelper_amd import launch
     # rank 1 exits with code 3 while rank 0 sits in a collective: the job must end, non-zero, promptly
