@@ -70,6 +70,8 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="rdf at N=1: skip the short C3 / C4 / C2(ii) legs embedded under 'extra'")
+    ap.add_argument("--no-ingest", action="store_true",
+                    help="sq / isf at N=1: skip the host-memory / file / operator-surface legs under 'ingest'")
     ap.add_argument("--dry-run", action="store_true",
                     help="walk the N-rank control plane without touching a GPU: launcher, rendezvous, the 128-byte id "
                          "broadcast, the shard plan of the workload, one host all-reduce; prints the plan")
@@ -657,6 +659,13 @@ def bench_sq(args, world):
                                                    "entries below 1e-9 of the largest left out)"}
     eng.close()
     traj.free()
+    if world.world == 1 and len(q) == 512 and N == 32768 and not args.shard_fixed and not args.no_ingest:
+        try:
+            t0 = time.perf_counter()
+            out["ingest"] = bench_fourier_ingest(args, world, "sq", out["frames_per_sec"])
+            out["ingest"]["leg_wall_s"] = time.perf_counter() - t0
+        except Exception as exc:            # never takes the resident line down
+            out["ingest"] = {"error": f"{type(exc).__name__}: {exc}"}
     return out
 
 
@@ -746,6 +755,13 @@ def bench_isf(args, world):
                                "gpu_max_rel_deviation_on_sample": err}
     eng.close()
     traj.free()
+    if world.world == 1 and N == 32768 and not args.host_path and not args.no_ingest:
+        try:
+            t0 = time.perf_counter()
+            out["ingest"] = bench_fourier_ingest(args, world, "isf", out["frames_per_sec"])
+            out["ingest"]["leg_wall_s"] = time.perf_counter() - t0
+        except Exception as exc:
+            out["ingest"] = {"error": f"{type(exc).__name__}: {exc}"}
     return out
 
 
@@ -984,6 +1000,128 @@ def bench_onsager(args, world, engine_ms):
         "L_ii_over_L_ii_self_expected": [float(L_ij[b, i, i] / ((N // 2) * sigma ** 2 / 2 / L ** 3))
                                          for b in range(B) for i in range(2)],
         "window": f"lags 1 .. {tb // 10}, linear scale; free walk: D = sigma^2 / 2 dt, L_ii^self = N_i D / (kBT V)"}
+    return legs
+
+
+def bench_fourier_ingest(args, world, kind, resident_fps):
+    """
+    The drop-in path of S(q) (kind "sq": C3, partial, 512 wavevectors) and of the intermediate scattering function
+    (kind "isf": 64 lags, coherent + incoherent) the ways a user of the reference feeds them (N = 1 only; never
+    the headline value), each leg with frames/s, its ratio to the HBM-resident figure of this run, and — S(q) at
+    C3 consumes 393 KB per frame in 3.4 us, more than the host link delivers — its ratio to what the link gave
+    for the same bytes in this process (`h2d_*`: one DMA out of page-locked memory; pageable memory through the
+    pinned ring), i.e. how close the pipeline runs to the bound that then applies:
+
+    host          mdx_*_accumulate on pageable host memory (what ``ts.positions`` of a memory reader is)
+    host_pinned   the same array page-locked through mdx_host_register
+    file          mdx_*_accumulate_traj on an AMBER NetCDF file in the page cache
+    class_memory  StructureFactor / IntermediateScatteringFunction (..., mode="partial").run() on an in-memory
+                  universe (reference structure.py:1481-1527, 1980-1996), engine creation and result included
+    class_file    the same on a FileUniverse
+    """
+    import tempfile
+    import mdhelper_amd
+    from mdhelper_amd import _core, _lib
+    from mdhelper_amd.analysis import IntermediateScatteringFunction, StructureFactor
+    from mdhelper_amd.io import FileUniverse, TrajectoryFile
+    dev = world.dev
+    N, L = 32768, 68.94
+    F = 4000 if kind == "sq" else 512
+    n_lags = 64
+    box = np.array([L, L, L, 90, 90, 90], dtype=np.float32)
+    grid = 2 * np.pi * np.arange(8) / L
+    q = np.stack(np.meshgrid(grid, grid, grid), -1).reshape(-1, 3)
+    sizes, pairs = [N // 2, N - N // 2], ((0, 0), (0, 1), (1, 1))
+    d_traj = _core.synth_random_walk(F, N, box[:3], 0.3, seed=2, dev=dev)
+    h_traj = d_traj.to_host()
+    gb = F * 12.0 * N / 1e9
+    legs = {"frames": F, "atoms": N, "wavevectors": len(q), "coordinate_bytes_per_frame": 12 * N,
+            "resident_frames_per_sec": resident_fps, "io_threads": int(os.environ.get("MDX_IO_THREADS", "8"))}
+    # what the host link gives for these bytes (best of 3)
+    def h2d():
+        t0 = time.perf_counter()
+        _lib.check(_lib.lib().mdx_upload(dev, d_traj.ptr, h_traj.ctypes.data, h_traj.nbytes))
+        return gb / (time.perf_counter() - t0)
+    legs["h2d_pageable_ring_GB_per_sec"] = max(h2d() for _ in range(3))
+    _lib.check(_lib.lib().mdx_host_register(dev, h_traj.ctypes.data, h_traj.nbytes))
+    try:
+        legs["h2d_page_locked_GB_per_sec"] = max(h2d() for _ in range(3))
+    finally:
+        _lib.check(_lib.lib().mdx_host_unregister(dev, h_traj.ctypes.data))
+    d_traj.free()
+    link = {"host": legs["h2d_pageable_ring_GB_per_sec"], "host_pinned": legs["h2d_page_locked_GB_per_sec"]}
+    tmp = tempfile.NamedTemporaryFile(suffix=".nc", delete=False)
+    tmp.close()
+    write_amber_netcdf_fast(tmp.name, h_traj, box)
+
+    def make():
+        return (_core.SqEngine(q, sizes, pairs, dev=dev) if kind == "sq"
+                else _core.IsfEngine(q, sizes, pairs, n_lags, True, dev=dev))
+
+    def timed(fn, reps=3):
+        fn()
+        _core.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        _core.synchronize(dev)
+        return (time.perf_counter() - t0) / reps
+
+    def leg(name, seconds, result=None, link_gbs=None):
+        fps = F / seconds
+        legs[name] = {"frames_per_sec": fps, "GB_per_sec": gb / seconds, "ratio_to_resident": fps / resident_fps}
+        if link_gbs:
+            bound = min(resident_fps, link_gbs * 1e9 / (12.0 * N))       # kernel-bound or link-bound, whichever is lower
+            legs[name]["bound_frames_per_sec"] = bound
+            legs[name]["ratio_to_bound"] = fps / bound
+        if result is not None:
+            legs[name]["checksum"] = float(np.sum(result[0] if isinstance(result, tuple) else result))
+
+    try:
+        eng = make()
+
+        def host():
+            eng.reset()
+            eng.accumulate(h_traj)
+            box_["r"] = eng.result()
+        box_ = {}
+        leg("host", timed(host), box_["r"], link["host"])
+        _lib.check(_lib.lib().mdx_host_register(dev, h_traj.ctypes.data, h_traj.nbytes))
+        try:
+            leg("host_pinned", timed(host), box_["r"], link["host_pinned"])
+        finally:
+            _lib.check(_lib.lib().mdx_host_unregister(dev, h_traj.ctypes.data))
+        tf = TrajectoryFile(tmp.name)
+        frames = np.arange(F)
+
+        def from_file():
+            eng.reset()
+            eng.accumulate_traj(tf, frames)
+            box_["r"] = eng.result()
+        leg("file", timed(from_file), box_["r"])
+        eng.close()
+        tf.close()
+        cls = StructureFactor if kind == "sq" else IntermediateScatteringFunction
+        kw = dict(mode="partial", n_points=8, verbose=False, device=dev)      # sort / unique: the reference's defaults
+        if kind == "isf":
+            kw.update(n_lags=n_lags, incoherent=True)
+        res = {}
+        um = mdhelper_amd.ArrayUniverse(h_traj, box)
+
+        def cls_mem():
+            res["m"] = cls((um.atoms[:N // 2], um.atoms[N // 2:]), **kw).run()
+        leg("class_memory", timed(cls_mem, reps=2), link_gbs=link["host"])
+        fu = FileUniverse(tmp.name)
+
+        def cls_file():
+            res["f"] = cls((fu.atoms[:N // 2], fu.atoms[N // 2:]), **kw).run()
+        leg("class_file", timed(cls_file, reps=2))
+        fu.trajectory.file.close()
+        a = res["m"].results.ssf if kind == "sq" else res["m"].results.cisf
+        b = res["f"].results.ssf if kind == "sq" else res["f"].results.cisf
+        legs["class_memory_vs_class_file_max_rel_deviation"] = float(np.abs(a - b).max() / np.abs(a).max())
+    finally:
+        os.unlink(tmp.name)
     return legs
 
 

@@ -404,6 +404,34 @@ class RadialDistributionFunction(DynamicAnalysisBase):
             formalism=formalism)
 
 
+def _mean_over_equal_wavenumbers(x, wavenumbers, unique) -> np.ndarray:
+    """
+    ``x[..., N_q] -> [..., N_unique]``: column ``u`` is the mean of the columns whose wavenumber is
+    ``numpy.isclose`` to ``unique[u]`` — the reference's ``_conclude`` (structure.py:1536-1541,
+    2116-2127), which evaluates ``isclose`` once per unique wavenumber over all columns (minutes of
+    host time at the default 32 768-wavevector grid).  Here every column finds its unique
+    wavenumber(s) by bisection; where each column belongs to exactly one (any grid), the means are
+    one segmented sum.  Otherwise the reference's loop runs as it stands.
+    """
+    w = np.asarray(wavenumbers, dtype=float)
+    q = np.asarray(unique, dtype=float)
+    order_q = np.argsort(q, kind="stable")
+    qs = q[order_q]
+    tol = 1e-8 + 1e-5 * np.abs(w)                       # isclose(q, w): |q - w| <= atol + rtol |w|
+    lo = np.searchsorted(qs, w - tol, side="left")
+    hi = np.searchsorted(qs, w + tol, side="right")
+    # bisection brackets candidates; the comparison itself is isclose's
+    single = (hi - lo == 1)
+    if single.all() and np.all(np.abs(qs[lo] - w) <= tol):
+        member = order_q[lo]                            # unique index of every column
+        cols = np.argsort(member, kind="stable")
+        counts = np.bincount(member, minlength=len(q))
+        if np.all(counts > 0):
+            starts = np.concatenate(([0], np.cumsum(counts)[:-1]))
+            return np.add.reduceat(np.take(x, cols, axis=-1), starts, axis=-1) / counts
+    return np.stack([x[..., np.isclose(v, w)].mean(axis=-1) for v in q], axis=-1)
+
+
 class StructureFactor(NumbaAnalysisBase):
     r"""
     Static / partial structure factor from particle positions (reference
@@ -596,9 +624,8 @@ class StructureFactor(NumbaAnalysisBase):
         # normalise by particles and frames (reference :1533; N = all particles of all groups)
         self.results.ssf = ssf / (self.n_frames * self._N)
         if self._unique:
-            self.results.ssf = np.hstack(
-                [self.results.ssf[:, np.isclose(q, self._wavenumbers)].mean(axis=1, keepdims=True)
-                 for q in self.results.wavenumbers])
+            self.results.ssf = _mean_over_equal_wavenumbers(self.results.ssf, self._wavenumbers,
+                                                            self.results.wavenumbers)
         if self._sort:
             order = np.argsort(self.results.wavenumbers)
             self.results.wavenumbers = self.results.wavenumbers[order]
@@ -709,12 +736,11 @@ class IntermediateScatteringFunction(StructureFactor):
         if self._incoherent:
             self.results.iisf = iisf / normalization
         if self._unique:
-            def combine(x):
-                return np.stack([x[:, :, np.isclose(q, self._wavenumbers)].mean(axis=2)
-                                 for q in self.results.wavenumbers], axis=-1)
-            self.results.cisf = combine(self.results.cisf)
+            self.results.cisf = _mean_over_equal_wavenumbers(self.results.cisf, self._wavenumbers,
+                                                             self.results.wavenumbers)
             if self._incoherent:
-                self.results.iisf = combine(self.results.iisf)
+                self.results.iisf = _mean_over_equal_wavenumbers(self.results.iisf, self._wavenumbers,
+                                                                 self.results.wavenumbers)
         if self._sort:
             order = np.argsort(self.results.wavenumbers)
             self.results.wavenumbers = self.results.wavenumbers[order]

@@ -261,6 +261,8 @@ struct mdx_isf {
     SqQuadShape quad{};
     DeviceBuffer d_qitems;
     StreamTimer timer;
+    StagePipeline pipe;             // host-buffer / trajectory-file entry points: slab k+1 is staged while slab k runs
+    DeviceBuffer d_stage[2];
 };
 
 // Frames must arrive in analysis order; consecutive calls continue the same series.
@@ -391,8 +393,9 @@ static int isf_accumulate(mdx_isf *h, int64_t n, int64_t n_frames, Source source
         }
         h->timer.end(ev);
         MDX_HIP(hipGetLastError());
-        // the host buffer may be reused by the caller; the staging copy must have left it
-        MDX_HIP(hipStreamSynchronize(h->stream));
+        // (no wait here: no source reads caller memory on this stream any more — host and file frames are staged
+        // by the pipeline, whose events guard the staging sets, and device frames follow the *_device contract —
+        // so the chunks queue back to back and the next slab's copy runs beside them)
         h->frames_seen += nf;
         done += nf;
     }
@@ -412,14 +415,40 @@ int mdx_isf_set_grouping(mdx_isf_t h, int64_t n_molecules, const int64_t *offset
     return h->mol.set(n_molecules, offsets, masses);
 }
 
+// frames per staged slab: ~64 MB of coordinates, a whole number of n_lags chunks
+static int64_t isf_slab_frames(const mdx_isf *h, int64_t n_rows)
+{
+    const int64_t by_bytes = (int64_t(64) << 20) / (12 * std::max<int64_t>(n_rows, 1));
+    return std::max<int64_t>(1, by_bytes / h->n_lags) * h->n_lags;
+}
+
 int mdx_isf_accumulate(mdx_isf_t h, const float *pos, int64_t n, int64_t n_frames)
 {
     MDX_REQUIRE(h && pos, "NULL argument");
-    return isf_accumulate(h, n, n_frames, [&](float *d_dst, int64_t done, int64_t nf) -> int {
-        MDX_HIP(hipMemcpyAsync(d_dst, pos + done * n * 3, size_t(12) * n * nf,
-                               hipMemcpyHostToDevice, h->stream));
-        return MDX_OK;
-    });
+    MDX_REQUIRE(n > 0 && n_frames >= 0, "bad size");
+    MDX_TRY(set_device(h->dev));
+    // Slabs of frames travel host -> pinned ring -> HBM on the pipeline's copy stream while the kernels of the
+    // slab before run (a pageable hipMemcpyAsync on the compute stream, the first form of this entry point, sat
+    // between the kernels: 0.87 of the resident rate at 32 768 particles x 64 lags); the frames then enter the
+    // position / rho rings by a device copy, as for mdx_isf_accumulate_device.
+    // (whole multiples of n_lags: the kernels take the frames in chunks of n_lags, and a ragged last chunk per
+    // slab is a launch of its own over a fraction of the work)
+    const int64_t slab = std::min<int64_t>(std::max<int64_t>(n_frames, 1), isf_slab_frames(h, n));
+    return h->pipe.run(
+        h->stream, n_frames, slab,
+        [&](int b, int64_t f0, int64_t nf) -> int {
+            MDX_TRY(h->d_stage[b].ensure(size_t(12) * n * slab));
+            return device_stager(h->dev).upload(h->dev, h->pipe.copy_stream, h->d_stage[b].ptr,
+                                                pos + f0 * n * 3, size_t(12) * n * nf);
+        },
+        [&](int b, int64_t, int64_t nf) -> int {
+            const float *d_pos = h->d_stage[b].as<float>();
+            return isf_accumulate(h, n, nf, [&](float *d_dst, int64_t done, int64_t m) -> int {
+                MDX_HIP(hipMemcpyAsync(d_dst, d_pos + done * n * 3, size_t(12) * n * m, hipMemcpyDeviceToDevice,
+                                       h->stream));
+                return MDX_OK;
+            });
+        });
 }
 
 int mdx_isf_accumulate_device(mdx_isf_t h, const float *d_pos, int64_t n, int64_t n_frames)
@@ -454,10 +483,25 @@ int mdx_isf_accumulate_traj(mdx_isf_t h, mdx_traj_t traj, const int64_t *frames,
         MDX_HIP(hipMemcpy(h->d_index.ptr, index, size_t(4) * n, hipMemcpyHostToDevice));
         d_index = h->d_index.as<int>();
     }
-    return isf_accumulate(h, n, n_frames, [&](float *d_dst, int64_t done, int64_t nf) -> int {
-        TrajSelection sel{d_index, n, d_dst};
-        return t->stage_async(h->dev, h->stream, frames + done, nf, &sel, 1);
-    });
+    if (n_frames == 0)
+        return MDX_OK;
+    // file -> pinned ring -> HBM on the copy stream, a slab ahead of the kernels
+    const int64_t slab = std::min<int64_t>(n_frames, isf_slab_frames(h, t->n_atoms));
+    return h->pipe.run(
+        h->stream, n_frames, slab,
+        [&](int b, int64_t f0, int64_t nf) -> int {
+            MDX_TRY(h->d_stage[b].ensure(size_t(12) * n * slab));
+            TrajSelection sel{d_index, n, h->d_stage[b].as<float>()};
+            return t->stage_async(h->dev, h->pipe.copy_stream, frames + f0, nf, &sel, 1);
+        },
+        [&](int b, int64_t, int64_t nf) -> int {
+            const float *d_pos = h->d_stage[b].as<float>();
+            return isf_accumulate(h, n, nf, [&](float *d_dst, int64_t done, int64_t m) -> int {
+                MDX_HIP(hipMemcpyAsync(d_dst, d_pos + done * n * 3, size_t(12) * n * m, hipMemcpyDeviceToDevice,
+                                       h->stream));
+                return MDX_OK;
+            });
+        });
 }
 
 int mdx_isf_create(mdx_isf_t *out, int dev, const double *wavevectors, int64_t n_q,
@@ -506,10 +550,8 @@ int mdx_isf_create(mdx_isf_t *out, int dev, const double *wavevectors, int64_t n
     }
     int rc = MDX_OK;
     do {
-        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
-            rc = fail(MDX_ERR_HIP, "hipStreamCreate failed");
+        if ((rc = stream_acquire(&h->stream)) != MDX_OK)
             break;
-        }
         h->timer.stream = h->stream;
         if ((rc = h->d_q.ensure(size_t(24) * n_q)) != MDX_OK) break;
         if ((rc = h->d_offsets.ensure(size_t(8) * (n_groups + 1))) != MDX_OK) break;
@@ -572,13 +614,15 @@ int mdx_isf_destroy(mdx_isf_t h)
     if (h->stream)
         (void)hipStreamSynchronize(h->stream);
     h->timer.destroy();
+    h->pipe.destroy();      // waits for its copy stream
     for (DeviceBuffer *b : {&h->d_q, &h->d_offsets, &h->d_pairs, &h->d_ranges, &h->d_rho_ring,
                             &h->d_pos_ring, &h->d_cisf, &h->d_iisf, &h->d_part, &h->d_pos_stage,
-                            &h->d_index, &h->d_mtrip, &h->d_row_stage, &h->d_qitems, &h->d_rho_parts})
-        b->release();
-    h->mol.release();
+                            &h->d_index, &h->d_mtrip, &h->d_row_stage, &h->d_qitems, &h->d_rho_parts,
+                            &h->d_stage[0], &h->d_stage[1]})
+        b->recycle();
+    h->mol.recycle();
     if (h->stream)
-        (void)hipStreamDestroy(h->stream);
+        stream_release(h->stream);
     delete h;
     return MDX_OK;
 }

@@ -96,6 +96,12 @@ struct MoleculeStage {
         for (DeviceBuffer *b : {&d_offsets, &d_masses, &d_total, &d_com})
             b->release();
     }
+    // destroy paths, after the handle's streams have been synchronised: the blocks go to the per-device cache
+    void recycle()
+    {
+        for (DeviceBuffer *b : {&d_offsets, &d_masses, &d_total, &d_com})
+            b->recycle();
+    }
 };
 
 }  // namespace mdx

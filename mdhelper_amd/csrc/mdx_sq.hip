@@ -253,10 +253,8 @@ int mdx_sq_create(mdx_sq_t *out, int dev, const double *wavevectors, int64_t n_q
     h->n_total = group_offsets[n_groups];
     int rc = MDX_OK;
     do {
-        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
-            rc = fail(MDX_ERR_HIP, "hipStreamCreate failed");
+        if ((rc = stream_acquire(&h->stream)) != MDX_OK)
             break;
-        }
         h->timer.stream = h->stream;
         if ((rc = h->d_q.ensure(size_t(24) * n_q)) != MDX_OK) break;
         if ((rc = h->d_offsets.ensure(size_t(8) * (n_groups + 1))) != MDX_OK) break;
@@ -344,13 +342,15 @@ int mdx_sq_destroy(mdx_sq_t h)
     if (h->stream)
         (void)hipStreamSynchronize(h->stream);
     h->timer.destroy();
-    h->pipe.destroy();
+    h->pipe.destroy();      // waits for its copy stream
+    // (every stream that touched them is idle: blocks and stream go back to the per-device pools, so that an
+    // analysis object per call does not pay hipMalloc / hipFree / stream creation each time)
     for (DeviceBuffer *b : {&h->d_q, &h->d_offsets, &h->d_pairs, &h->d_acc, &h->d_rho, &h->d_stage[0],
                             &h->d_stage[1], &h->d_index, &h->d_mtrip, &h->d_items, &h->d_qitems})
-        b->release();
-    h->mol.release();
+        b->recycle();
+    h->mol.recycle();
     if (h->stream)
-        (void)hipStreamDestroy(h->stream);
+        stream_release(h->stream);
     delete h;
     return MDX_OK;
 }
