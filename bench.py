@@ -361,7 +361,7 @@ def bench_rdf(args, world, wide=False):
     steps64 = st["pairs_computed"] / 64.0          # hot-loop trips: 64 distance evaluations each
     # this rank's own share of the reduced counts (weak scaling: every rank bins the same amount)
     binned_mine = binned / (1 if args.shard_fixed else world.world) * (F_mine / max(F, 1) if args.shard_fixed else 1.0)
-    celled = args.algo == "cell" or (args.algo == "auto" and N >= 1024)   # below 1 024: brute-force tiles
+    celled = args.algo in ("cell", "auto")      # auto: the cell-sorted kernel at every size (round 4)
     # VALU / SALU / LDS instructions per hot-loop trip and the engine clock under this kernel come from
     # SQ counters of a separate rocprofv3 pass over the SAME sources (scripts/profile_counters.sh ->
     # profiles/counters.json); dropped (None) when the kernel sources have changed since
@@ -369,8 +369,7 @@ def bench_rdf(args, world, wide=False):
     # the nearest size on the same kernel and says so — the mix per trip moves by a few per cent with N)
     ctr, ctr_atoms = None, None
     if args.algo == "auto":
-        small = N < 1024                      # below that the auto path is the brute-force tile kernel
-        names = ["rdf_c1"] if small else (["rdf_wide"] if wide else ["rdf_c2", "rdf_c5"])
+        names = ["rdf_wide", "rdf_c1"] if wide else ["rdf_c2", "rdf_c5"]
         found = [(abs(np.log(e.get("atoms", 32768) / N)), e) for e in
                  (profiled(n, *RDF_SOURCES) for n in names) if e]
         if found:

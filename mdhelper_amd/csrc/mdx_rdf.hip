@@ -674,11 +674,15 @@ static int accumulate_ortho(mdx_rdf *h, const float *d_pos1, int64_t n1, const f
     const bool self = same && (!excl || h->excl1 == h->excl2);
     MDX_REQUIRE(n1 < (int64_t(1) << 30) && n2 < (int64_t(1) << 30), "too many particles");
 
-    // AUTO: cell-sorted culled tiles whenever there is a periodic box and enough particles
-    // for tiles to be compact; otherwise the brute-force tiles with the float32 filter.
+    // AUTO: the cell-sorted kernel whenever there is a periodic box — at every size.  Below 1 024 particles the
+    // tiles cannot be culled (the cutoff spans the cell), but its hot step (13 VALU instructions + the
+    // hand-placed tail per 64 evaluations, symmetric tile pairs evaluated once) is what the brute-force tile kernel
+    // spends 48 on: measured 1.1 x (16 particles) .. 3.4 x (1 000 particles, range to L/2: 0.88 -> 3.0 M frames/s)
+    // the frames per second, counts identical (scripts/diag/rdf_small_sweep.py, round 4).  Without a box: the
+    // brute-force tiles with the float32 filter.
     int algo = h->algo;
     if (algo == MDX_RDF_ALGO_AUTO)
-        algo = (d_boxes && std::max(n1, n2) >= 1024) ? MDX_RDF_ALGO_CELL : MDX_RDF_ALGO_FILTER_F32;
+        algo = d_boxes ? MDX_RDF_ALGO_CELL : MDX_RDF_ALGO_FILTER_F32;
     if (algo == MDX_RDF_ALGO_CELL && !d_boxes)
         algo = MDX_RDF_ALGO_FILTER_F32;   // the cell grid is defined by the periodic box
     if (algo == MDX_RDF_ALGO_CELL)

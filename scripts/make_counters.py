@@ -253,7 +253,7 @@ def main():
         data["rdf_wide"] = rdf_entry("rdf_wide", "rdf_wide", 400)
     if "rdf_c5" in which:                          # C5 size on one GPU
         data["rdf_c5"] = rdf_entry("rdf_c5", "rdf", 250, atoms=131072)
-    if "rdf_c1" in which:                          # C1-like: 1 000 atoms, range (0, L/2): the brute-force tile kernel
+    if "rdf_c1" in which:                          # C1-like: 1 000 atoms, range (0, L/2)
         data["rdf_c1"] = rdf_entry("rdf_c1", "rdf_wide", 20000, atoms=1000)
     if "rdf_req" in which and "rdf_c2" in data:   # request-level cross-check of the C2(i) traffic figure
         data["rdf_c2"]["hbm_requests"] = rdf_requests("rdf_c2", "rdf", 2000)
