@@ -281,6 +281,7 @@ def write_amber_netcdf_fast(path, positions, box):
 RDF_SOURCES = ("mdx_rdf.hip", "mdx_rdf_cell.hpp", "mdx_rdf_device.hpp")
 MSD_SOURCES = ("mdx_msd.hip", "mdx_msd_fft.hpp")
 SQ_SOURCES = ("mdx_sq.hip", "mdx_sq_device.hpp")
+ISF_SOURCES = ("mdx_isf.hip", "mdx_sq_device.hpp")
 
 
 def bench_rdf(args, world, wide=False):
@@ -603,7 +604,7 @@ def bench_sq(args, world):
     # register-blocked column kernel; the measured figure and the clock come from profiles/counters.json when
     # it was taken on these sources); a wave64 fp64 instruction takes 4 cycles on a SIMD-32 (half the fp32
     # rate: 78.6 vs 157.3 TFLOP/s)
-    sq_ctr = profiled("sq_c3", *SQ_SOURCES) if len(q) == 512 else None
+    sq_ctr = profiled({8: "sq_c3", 32: "sq_default"}.get(args.n_points, ""), *SQ_SOURCES) if N == 32768 else None
     fp64_per_64 = sq_ctr["fp64_per_64_terms"] if sq_ctr else 4.5
     issue = evals_rank / max(kernel_s, 1e-9) / 64.0 * fp64_per_64 * 4.0
     out = {
@@ -620,7 +621,9 @@ def bench_sq(args, world):
         "per_rank_frames_per_sec": world.gather(args.steps * F_mine / own),
         **world.describe(),
         "roofline": {"bound": "valu", "unit": "G SIMD issue cycles/s", "achieved": issue / 1e9,
-                     "peak": SIMDS * CLOCK_HZ / 1e9, "frac": issue / (SIMDS * CLOCK_HZ), "traffic": None,
+                     "peak": SIMDS * CLOCK_HZ / 1e9, "frac": issue / (SIMDS * CLOCK_HZ),
+                     "traffic": sq_ctr["hbm_bytes_per_frame"] * F_mine if sq_ctr and "hbm_bytes_per_frame" in sq_ctr else None,
+                     "traffic_source": sq_ctr.get("traffic_source") if sq_ctr else None,
                      "kernel": "sq_rho_quads_kernel (grid wavevectors: separable phase tables in LDS, "
                                "4 columns x 8 m_z accumulators per thread)",
                      "definition": "terms/s / 64 x 4.5 fp64 FMA-class wave-instructions per 64 terms x 4 cycles "
@@ -665,6 +668,35 @@ def bench_sq(args, world):
             out["ingest"]["leg_wall_s"] = time.perf_counter() - t0
         except Exception as exc:            # never takes the resident line down
             out["ingest"] = {"error": f"{type(exc).__name__}: {exc}"}
+    return out
+
+
+def isf_roofline(N, n_q, F, lagged, kernel_s, per_step, achieved, alg):
+    """fp64 VALU bound like S(q).  Model: 2.5 FMA-class wave-instructions per 64 displacement terms (two FMAs per
+    term, half a column product), 4.5 per 64 rho terms; a wave64 fp64 instruction takes 4 cycles on a SIMD-32.
+    With a profiles/counters.json entry measured on these sources (scripts/make_counters.py isf) the count is the
+    one the SQ counters gave (FMA + MUL + ADD f64 of every ISF kernel of a step) and the clock the one the part
+    held under this load; traffic from the FETCH_SIZE / WRITE_SIZE passes."""
+    model = float(N) * n_q * (lagged * 2.5 + F * 4.5) / 64.0
+    ctr = profiled("isf", *ISF_SOURCES) if (N == 32768 and n_q == 512) else None
+    ratio = ctr["fp64_ratio_to_model"] if ctr else 1.0
+    issue = model * ratio * 4.0 / max(kernel_s, 1e-9)
+    out = {"bound": "valu", "unit": "G SIMD issue cycles/s", "achieved": issue / 1e9, "peak": SIMDS * CLOCK_HZ / 1e9,
+           "frac": issue / (SIMDS * CLOCK_HZ),
+           "traffic": ctr["hbm_bytes_per_frame"] * F if ctr else None,
+           "traffic_source": ctr.get("traffic_source") if ctr else None,
+           "kernel": "isf_incoherent_quads_kernel + sq_rho_quads_kernel + isf_coherent_kernel",
+           "definition": "fp64 wave-instructions of a step (counted: FMA + MUL + ADD f64 of the ISF kernels, "
+                         "profiles/counters.json; without an entry the model (displacement terms x 2.5 + rho terms x "
+                         "4.5) / 64) x 4 cycles per second of kernel time / (1024 SIMDs x 2.4 GHz nominal)",
+           "model_fp64_instructions_per_step": model,
+           "fp64_instructions_counted_over_model": ctr["fp64_ratio_to_model"] if ctr else None,
+           "clock_hz_under_this_kernel": ctr.get("clock_hz") if ctr else None,
+           "frac_at_measured_clock": issue / (SIMDS * ctr["clock_hz"]) if ctr else None,
+           "counters_source": ctr.get("source") if ctr else None,
+           "evaluations_per_sec_kernel": per_step / max(kernel_s, 1e-9),
+           "hbm": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_step": alg}}
     return out
 
 
@@ -713,18 +745,7 @@ def bench_isf(args, world):
         "config": {"workload": f"ISF {N} atoms, {len(q)} wavevectors, 2 groups (partial), {n_lags} lags, "
                                f"coherent + incoherent, {F} frames/GPU/step" + (" from host memory" if args.host_path else "")},
         "frames_per_sec": args.steps * F * world.world / dt,
-        # fp64 VALU bound like S(q): 2.5 FMA-class wave-instructions per 64 displacement terms (two FMAs per term,
-        # half a column product), 4.5 per 64 rho terms; a wave64 fp64 instruction takes 4 cycles on a SIMD
-        "roofline": (lambda issue: {
-            "bound": "valu", "unit": "G SIMD issue cycles/s", "achieved": issue / 1e9, "peak": 1024 * 2.4,
-            "frac": issue / (1024 * 2.4e9), "traffic": None,
-            "kernel": "isf_incoherent_quads_kernel + sq_rho_quads_kernel + isf_coherent_kernel",
-            "definition": "(displacement terms x 2.5 + rho terms x 4.5) / 64 fp64 wave-instructions x 4 cycles per "
-                          "second of kernel time / (1024 SIMDs x 2.4 GHz nominal)",
-            "evaluations_per_sec_kernel": per_step / max(kernel_s, 1e-9),
-            "hbm": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_step": alg}})(
-            float(N) * len(q) * (lagged * 2.5 + F * 4.5) / 64.0 * 4.0 / max(kernel_s, 1e-9)),
+        "roofline": isf_roofline(N, len(q), F, lagged, kernel_s, per_step, achieved, alg),
         "checksum": float(cisf.sum() + iisf.sum()),
     }
     if world.rank == 0 and world.world == 1 and not args.no_cpu_baseline:
@@ -826,8 +847,10 @@ def bench_msd(args, world):
     own_fft = (eng.n_fft in (1 << 13, 1 << 14, 25600, 1 << 15, 1 << 16, 204800, 1 << 18, 1 << 19, 1 << 20)
                and not os.environ.get("MDX_MSD_ROCFFT"))
     ctr = None
+    if N == 10000 and T == 100000 and B == 8 and own_fft and world.world == 1:
+        ctr = profiled("msd_c4_b8", *MSD_SOURCES)
     if N == 10000 and T == 100000 and B == 1 and own_fft and world.world == 1:
-        ctr = profiled({204800: "msd_c4", 262144: "msd_c4_pow2"}.get(eng.n_fft, ""), *MSD_SOURCES)
+        ctr = profiled("msd_c4", *MSD_SOURCES)
     out = {
         "metric": "MSD atom-frames/sec", "value": atom_frames / dt, "unit": "atom-frames/s",
         "n_gpus": world.world, "steps": args.steps, "warmup": args.warmup,

@@ -347,7 +347,6 @@ struct mdx_msd {
     bool own_fft = false;                           // n_fft = 2^15, 2^16, 2^18..2^20: mdx_msd_fft.hpp
     bool fused_sums = false;                        // pass A of this shape also forms the per-frame sums
     DeviceBuffer d_part;                            // its partial-sum records
-    int64_t fft_batch_atoms = 0;                    // own transform: particles per batch (0: no batching)
     msdfft::Shape shape;
     DeviceBuffer d_tw, d_pfull;                     // twiddle tables [2][512], full-spectrum sums [B][N]
     StreamTimer timer;
@@ -380,8 +379,7 @@ static int msd_push_device(mdx_msd *h, int group, const double *d_pos, int64_t n
     const int64_t n_chunks = ceil_div(count, chunk);
     chunk = ceil_div(count, n_chunks);
     if (h->own_fft) {
-        const int64_t most = h->fft_batch_atoms > 0 ? std::min(h->fft_batch_atoms, chunk) : chunk;
-        const int64_t p_pad_max = ceil_div(ceil_div(most * 3 + 15, 2), msdfft::PG) * msdfft::PG;   // (+ 15: head)
+        const int64_t p_pad_max = ceil_div(ceil_div(chunk * 3 + 15, 2), msdfft::PG) * msdfft::PG;   // (+ 15: head)
         MDX_TRY(h->d_spec.ensure(size_t(B) * h->n_fft * p_pad_max * 16));
         if (h->fused_sums)
             MDX_TRY(h->d_part.ensure(msdfft::fused_part_bytes(h->shape, (int)p_pad_max, B)));
@@ -400,26 +398,20 @@ static int msd_push_device(mdx_msd *h, int group, const double *d_pos, int64_t n
             // tables: half table of W_R1, half table of W_R2, W_N^m for m < R2
             const double2 *tw_r1 = h->d_tw.as<double2>(), *tw_r2 = tw_r1 + msdfft::tw_r1_len(h->shape.r1),
                           *twN = tw_r2 + h->shape.r2 / 2;
-            // Batches of `sub` particles whose half-transformed block Y (written by pass A, read
-            // once by pass B) fits the 256 MB memory-side cache: pass B then reads it from there,
-            // and the same addresses are reused by the next batch.
-            const int64_t sub = h->fft_batch_atoms > 0 ? std::min<int64_t>(h->fft_batch_atoms, c) : c;
-            for (int64_t s0 = 0; s0 < c; s0 += sub) {
-                // rows whose length is a multiple of 128 bytes (and positions from hipMalloc): a chunk that starts
-                // in the middle of a line is entered `head` coordinates early, so that pass A's 128-byte pieces
-                // are whole lines (msd_fft_cols400_fused_kernel); the head is staged as zeros
-                const int head = (h->fused_sums && msdfft::aligns_head(h->shape) && (n_total * 3) % 16 == 0 &&
-                                  (reinterpret_cast<uintptr_t>(d_pos) & 127u) == 0 && !getenv("MDX_MSD_NO_HEAD"))
-                                     ? int(((first + a0 + s0) * 3) % 16)
-                                     : 0;
-                const int64_t ne = std::min(sub, c - s0) * 3 + head;
-                const int p_pad = (int)(ceil_div(ceil_div(ne, 2), msdfft::PG) * msdfft::PG);
-                msdfft::launch(h->shape, h->stream, d_pos, n_total, first + a0 + s0, ne, h->t_block, B,
-                               zero_dims, p_pad, tw_r1, tw_r2, twN, h->d_spec.as<double2>(),
-                               h->d_pfull.as<double>(), s0 > 0 ? 1 : 0,
-                               h->fused_sums ? h->d_part.as<double2>() : nullptr, h->traj(group),
-                               h->dsq(group), head);
-            }
+            // (batches of particles whose half-transformed block fits the 256 MB memory-side cache were measured in
+            // rounds 1 and 2: small launches lose more than the cache returns — NOTES.md — so a chunk is one launch)
+            // rows whose length is a multiple of 128 bytes (and positions from hipMalloc): a chunk that starts
+            // in the middle of a line is entered `head` coordinates early, so that pass A's 128-byte pieces
+            // are whole lines (msd_fft_cols400_fused_kernel); the head is staged as zeros
+            const int head = (h->fused_sums && msdfft::aligns_head(h->shape) && (n_total * 3) % 16 == 0 &&
+                              (reinterpret_cast<uintptr_t>(d_pos) & 127u) == 0)
+                                 ? int(((first + a0) * 3) % 16)
+                                 : 0;
+            const int64_t ne = c * 3 + head;
+            const int p_pad = (int)(ceil_div(ceil_div(ne, 2), msdfft::PG) * msdfft::PG);
+            msdfft::launch(h->shape, h->stream, d_pos, n_total, first + a0, ne, h->t_block, B, zero_dims, p_pad,
+                           tw_r1, tw_r2, twN, h->d_spec.as<double2>(), h->d_pfull.as<double>(), 0,
+                           h->fused_sums ? h->d_part.as<double2>() : nullptr, h->traj(group), h->dsq(group), head);
             msdfft::launch_fold(h->shape, h->stream, h->d_pfull.as<double>(), B, h->nc, h->power(group));
             // positions read once (twice where the sums are a kernel of their own), Y written and read once
             h->bytes_moved += c * 3 * B * ((h->fused_sums ? 1 : 2) * h->t_block * 8 + 2 * h->n_fft * 8);
@@ -944,39 +936,31 @@ int mdx_msd_create(mdx_msd_t *out, int dev, int64_t n_frames_block, int n_blocks
     h->t_block = n_frames_block;
     h->n_blocks = n_blocks;
     h->n_groups = n_groups;
-    // Any length >= 2 N_t - 1 gives the same linear correlation up to rounding.  The reference
-    // pads to 2 * next_fast_len(N_t) (correlation.py:176-178).  rocFFT runs a power-of-two
-    // transform in fewer passes (measured at N_t = 1e5: 262144 points 15 % faster end to end
-    // than 200000), so the next power of two is taken when it is at most 1.5x the reference
-    // length.  MDX_MSD_NFFT=ref forces the reference padding, =pow2 the power of two.
+    // Any length >= 2 N_t - 1 gives the same linear correlation up to rounding.  The reference pads to
+    // 2 * next_fast_len(N_t) (correlation.py:176-178).  Here:
+    //   * blocks of more than 2 048 frames take the shortest length of the engine's own two-pass transform
+    //     (mdx_msd_fft.hpp) that covers 2 N_t: 2^13, 2^14, 25 600 = 400 x 64, 2^15, 2^16, 204 800 = 400 x 512,
+    //     2^18, 2^19, 2^20 (2^17 is served by 204 800 / 2^18).  It never materialises the padding and moves
+    //     ~4.3 MB per series at 2^18 whatever N_t is, where the rocFFT pipeline moves ~17.7 MB;
+    //   * everything else goes through rocFFT at the reference's length, or at the next power of two when that is
+    //     at most 1.5 x longer (fewer rocFFT passes: measured 15 % faster end to end at N_t = 1e5).
+    // MDX_MSD_ROCFFT=1 (test hook: tests/test_gpu_engines.py compares the two pipelines) keeps rocFFT throughout.
     h->n_fft = 2 * next_fast_len_real(n_frames_block);
     {
         int64_t p = 1;
         while (p < 2 * n_frames_block)
             p <<= 1;
-        const char *mode = getenv("MDX_MSD_NFFT");
-        const bool force_ref = mode && !strcmp(mode, "ref");
-        const bool force_pow2 = mode && !strcmp(mode, "pow2");
-        // ... and the lengths of the engine's own two-pass transform (mdx_msd_fft.hpp: 2^18, 2^19,
-        // 2^20), which never materialises the padding and moves ~4.3 MB per series at 2^18
-        // whatever N_t is — whenever the rocFFT pipeline (~17.7 MB per series at 2^18, in
-        // proportion for other lengths) would move more: from N_t = 40 000 up to 524 288
         int64_t own_len = 0;
-        // ... and 2^13 .. 2^16 (16 or 64 x 512 or 1024) for blocks of 2 049 .. 32 768 frames; 2^17
-        // is served by 2^18
-        if (!getenv("MDX_MSD_ROCFFT") && n_frames_block > 2048)
+        if (!getenv("MDX_MSD_ROCFFT") && n_frames_block > 2048) {
             own_len = p <= (int64_t(1) << 16) ? p : std::max<int64_t>(p, int64_t(1) << 18);
-        // ... and 204 800 = 400 x 512 (16 x 5 x 5 first factor) where it covers the block and is
-        // shorter than the power of two: 32 769 .. 102 400 frames (MDX_MSD_NFFT=pow2 keeps 2^18)
-        if (own_len == (int64_t(1) << 18) && 2 * n_frames_block <= 204800 && !force_pow2)
-            own_len = 204800;
-        // ... and 25 600 = 400 x 64 for blocks of 8 193 .. 12 800 frames (C4 with eight blocks: 2^15 would pad the
-        // half-transformed block by 28 %)
-        if (own_len == (int64_t(1) << 15) && 2 * n_frames_block <= 25600 && !force_pow2)
-            own_len = 25600;
-        if (own_len && msdfft::shape_for(own_len).r1 && !force_ref)
+            if (own_len == (int64_t(1) << 18) && 2 * n_frames_block <= 204800)
+                own_len = 204800;
+            if (own_len == (int64_t(1) << 15) && 2 * n_frames_block <= 25600)
+                own_len = 25600;
+        }
+        if (own_len && msdfft::shape_for(own_len).r1)
             h->n_fft = own_len;
-        else if (force_pow2 || (!force_ref && 2 * p <= 3 * h->n_fft))
+        else if (2 * p <= 3 * h->n_fft)
             h->n_fft = p;
     }
     h->nc = h->n_fft / 2 + 1;
@@ -991,7 +975,7 @@ int mdx_msd_create(mdx_msd_t *out, int dev, int64_t n_frames_block, int n_blocks
         // (MDX_MSD_ROCFFT=1 keeps rocFFT for them too)
         h->shape = msdfft::shape_for(h->n_fft);
         h->own_fft = h->shape.r1 != 0 && !getenv("MDX_MSD_ROCFFT");
-        h->fused_sums = h->own_fft && msdfft::fuses_sums(h->shape) && !getenv("MDX_MSD_NO_FUSED_SUMS");
+        h->fused_sums = h->own_fft && msdfft::fuses_sums(h->shape);
         if (h->own_fft) {
             const int r1 = h->shape.r1, r2 = h->shape.r2;
             std::vector<double> tw;
@@ -1012,14 +996,6 @@ int mdx_msd_create(mdx_msd_t *out, int dev, int64_t n_frames_block, int n_blocks
             }
             if ((rc = h->d_pfull.ensure(size_t(8) * n_blocks * h->n_fft *
                                         msdfft::rows_parts(h->shape, n_blocks))) != MDX_OK) break;
-            // batch size in MiB of Y (MDX_MSD_BATCH_MB, 0 = whole chunks), whole groups of 16
-            // particles = 3 pair groups
-            const char *env = getenv("MDX_MSD_BATCH_MB");
-            const int64_t mb = env ? atoll(env) : 0;
-            if (mb > 0) {
-                const int64_t atoms = (mb << 20) / (int64_t(3) * n_blocks * h->n_fft * 8);
-                h->fft_batch_atoms = std::max<int64_t>(16, atoms / 16 * 16);
-            }
         }
     } while (0);
     if (rc != MDX_OK) {

@@ -693,18 +693,13 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols400_fused_kernel(
         const int q_n = wrap ? 0 : q + 1;
         const int n2_n = wrap ? min(n2 + 1, n2_begin + n2_count - 1) : n2;
         cur += wrap ? (n2_n - n2) * row_stride - int64_t(n_q - 1) * 16 : 16;
-#ifndef MDX_LOADS_AFTER
         MDX_FUSED_LOAD(n2_n, q_n, cur)
-#endif
         // three stages (10, 10, 4) instead of (4, 4, 5, 5): the transform phase is bound by the LDS
         // write path (a ds_write_b128 costs 13 cycles of it per wave: in-kernel phase timers show the
         // slowest wave 59 % of an iteration in here), and a stage fewer is 28 instead of 36 writes
         dif_stage<R1, 400, 10, true>(zb[wave], s_h, lane);
         dif_stage<R1, 40, 10, false>(zb[wave], s_h, lane);
         dif_stage<R1, 4, 4, false>(zb[wave], s_h, lane);
-#ifdef MDX_LOADS_AFTER
-        MDX_FUSED_LOAD(n2_n, q_n, cur)
-#endif
         __syncthreads();
         double2 *o = out + (int64_t(pg0 + q) * R2 + n2) * PG;
 #pragma unroll

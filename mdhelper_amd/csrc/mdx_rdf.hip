@@ -386,8 +386,6 @@ struct mdx_rdf {
     DeviceBuffer d_bb16_1, d_bb16_2;                         // boxes of the CELL_CHUNK-particle chunks
     // cell path: the sort of slab k + 1 runs on its own stream beside the pair kernel of slab k (two sets of the
     // sorted copies); events hand the sets back and forth
-    hipStream_t sort_stream = nullptr;
-    hipEvent_t ev_inputs = nullptr, ev_sorted[2] = {nullptr, nullptr}, ev_paired[2] = {nullptr, nullptr};
     StreamTimer timer;
     int64_t pairs_evaluated = 0;    // ordered pair space covered: frames * n1 * n2
     int64_t pairs_bruteforce = 0;   // distance evaluations executed by the brute-force tiles
@@ -468,41 +466,29 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
     if (slab >= 256)
         slab -= slab % 256;
     slab = std::min<int64_t>(slab, n_frames);
-    // One set of the sorted copies, sort and pair kernel on one stream.  MDX_RDF_OVERLAP=1: two sets when there
-    // is more than one slab, the sort of the next slab on a stream of its own beside the pair kernel of this one —
-    // the default of round 2 (+1 % then).  With PERSISTENT pair blocks it loses: the pair kernel holds every wave
-    // slot of the chip until its last items, so the sort's 1 024-thread blocks trickle in behind retiring blocks
-    // and the next pair kernel waits for them anyway; C2(i): pair kernel 17.12 ms per launch alone + 0.62 ms of sort
-    // against 17.89 ms with the sort beside it (45.4 k against 44.1 k frames/s on one box, round 3).  Sizes in
-    // float4 elements.
-    const bool overlap = getenv("MDX_RDF_OVERLAP") != nullptr && getenv("MDX_RDF_NO_OVERLAP") == nullptr;
-    const int n_sets = (overlap && slab < n_frames) ? 2 : 1;
+    // One set of the sorted copies; sort and pair kernel follow each other on the handle's stream.  (The sort of
+    // slab k + 1 on a stream of its own beside the pair kernel of slab k — the form of round 2 — lost once the pair
+    // blocks became persistent: they hold every wave slot until their last items, the sort trickles in behind
+    // retiring blocks and the next pair kernel waits for it anyway: 44.1 k against 45.4 k frames/s at C2(i),
+    // NOTES.md round 3.  The second set, its stream and its events are gone.)
     // exclusion 0 or 1: a particle's tag is its row, and the exact path reads the frames as they came in —
     // no sorted copy of the original coordinates (half of the sort kernel's scattered stores)
-    const bool lazy_orig = !tri && h->excl1 <= 1 && h->excl2 <= 1 && !getenv("MDX_RDF_SORTED_ORIGINALS");
+    const bool lazy_orig = !tri && h->excl1 <= 1 && h->excl2 <= 1;
     const size_t e_p1 = size_t(n1p) * slab, e_b1 = size_t(n1p / 64) * 2 * slab;
     const size_t e_c1 = CELL_CHUNK >= 4 ? size_t(n1p / CELL_CHUNK) * 2 * slab : 16;
     const size_t e_p2 = size_t(n2p) * slab, e_b2 = size_t(n2p / 64) * 2 * slab;
     const size_t e_c2 = CELL_CHUNK >= 4 ? size_t(n2p / CELL_CHUNK) * 2 * slab : 16;
-    MDX_TRY(h->d_pw1.ensure(16 * e_p1 * n_sets));
+    MDX_TRY(h->d_pw1.ensure(16 * e_p1));
     if (!lazy_orig)
-        MDX_TRY(h->d_po1.ensure(16 * e_p1 * n_sets));
-    MDX_TRY(h->d_bb1.ensure(16 * e_b1 * n_sets));
-    MDX_TRY(h->d_bb16_1.ensure(16 * e_c1 * n_sets));
+        MDX_TRY(h->d_po1.ensure(16 * e_p1));
+    MDX_TRY(h->d_bb1.ensure(16 * e_b1));
+    MDX_TRY(h->d_bb16_1.ensure(16 * e_c1));
     if (!self) {
-        MDX_TRY(h->d_bb16_2.ensure(16 * e_c2 * n_sets));
-        MDX_TRY(h->d_pw2.ensure(16 * e_p2 * n_sets));
+        MDX_TRY(h->d_bb16_2.ensure(16 * e_c2));
+        MDX_TRY(h->d_pw2.ensure(16 * e_p2));
         if (!lazy_orig)
-            MDX_TRY(h->d_po2.ensure(16 * e_p2 * n_sets));
-        MDX_TRY(h->d_bb2.ensure(16 * e_b2 * n_sets));
-    }
-    if (n_sets == 2 && !h->sort_stream) {
-        MDX_TRY(stream_acquire(&h->sort_stream));
-        MDX_HIP(hipEventCreateWithFlags(&h->ev_inputs, hipEventDisableTiming));
-        for (int b = 0; b < 2; ++b) {
-            MDX_HIP(hipEventCreateWithFlags(&h->ev_sorted[b], hipEventDisableTiming));
-            MDX_HIP(hipEventCreateWithFlags(&h->ev_paired[b], hipEventDisableTiming));
-        }
+            MDX_TRY(h->d_po2.ensure(16 * e_p2));
+        MDX_TRY(h->d_bb2.ensure(16 * e_b2));
     }
     unsigned *d_misc = h->d_misc.as<unsigned>();
     if (!tri)
@@ -545,37 +531,23 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
     }
     const int64_t blocks_per_xcd = h->occ_blocks_per_xcd;
 
-    hipStream_t s_sort = n_sets == 2 ? h->sort_stream : h->stream;
-    if (n_sets == 2) {
-        // whatever produced the inputs was queued on h->stream (and so were the pair kernels of an earlier
-        // call, which read the sets)
-        MDX_HIP(hipEventRecord(h->ev_inputs, h->stream));
-        MDX_HIP(hipStreamWaitEvent(s_sort, h->ev_inputs, 0));
-    }
-    int64_t k_slab = 0;
-    for (int64_t f0 = 0; f0 < n_frames; f0 += slab, ++k_slab) {
+    hipStream_t s_sort = h->stream;
+    for (int64_t f0 = 0; f0 < n_frames; f0 += slab) {
         const int64_t nf = std::min(slab, n_frames - f0);
-        const int set = n_sets == 2 ? int(k_slab & 1) : 0;
-        float4 *pw1 = h->d_pw1.as<float4>() + set * e_p1;
-        float4 *po1 = lazy_orig ? nullptr : h->d_po1.as<float4>() + set * e_p1;
-        float4 *bb1 = h->d_bb1.as<float4>() + set * e_b1, *bc1 = h->d_bb16_1.as<float4>() + set * e_c1;
-        float4 *pw2 = self ? pw1 : h->d_pw2.as<float4>() + set * e_p2;
-        float4 *po2 = self ? po1 : (lazy_orig ? nullptr : h->d_po2.as<float4>() + set * e_p2);
-        float4 *bb2 = self ? bb1 : h->d_bb2.as<float4>() + set * e_b2;
-        float4 *bc2 = self ? bc1 : h->d_bb16_2.as<float4>() + set * e_c2;
-        // The batch's largest |coordinate| (the filter's error bound grows with it) is folded by the sort.
-        // With two sets each has a word of its own: the sort of slab k + 1 runs beside the pair kernel of
-        // slab k, and on one shared word the blocks of that kernel would see the bound move under them —
-        // harmless for the counts (it only grows), but the exact-path statistics would differ from run to
-        // run.  A set's word covers every slab sorted into that set since the last reset: conservative.
-        unsigned *d_maxabs = d_misc + (n_sets == 2 ? 4 + set : 0);
-        h->last_offset = set * e_p1;
+        float4 *pw1 = h->d_pw1.as<float4>();
+        float4 *po1 = lazy_orig ? nullptr : h->d_po1.as<float4>();
+        float4 *bb1 = h->d_bb1.as<float4>(), *bc1 = h->d_bb16_1.as<float4>();
+        float4 *pw2 = self ? pw1 : h->d_pw2.as<float4>();
+        float4 *po2 = self ? po1 : (lazy_orig ? nullptr : h->d_po2.as<float4>());
+        float4 *bb2 = self ? bb1 : h->d_bb2.as<float4>();
+        float4 *bc2 = self ? bc1 : h->d_bb16_2.as<float4>();
+        // the batch's largest |coordinate| (the filter's error bound grows with it) is folded by the sort
+        unsigned *d_maxabs = d_misc;
+        h->last_offset = 0;
         h->last_frames = nf;
         h->last_n_pad = n1p;
         h->last_lazy = lazy_orig;
         {
-            if (n_sets == 2 && k_slab >= 2)   // the pair kernel that read this set two slabs ago
-                MDX_HIP(hipStreamWaitEvent(s_sort, h->ev_paired[set], 0));
             // (Measured and dropped, round 3: the sort as a GATHER — slots noted per particle in LDS, rows written
             // in slot order as whole lines — 0.66 ms per 1 000 frames against 0.74–0.82, +0.5 % on the step, but its
             // 12-byte reads scattered over frames that are no longer in L2 fetch 4.0 MB per frame where the scatter's
@@ -592,10 +564,6 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
                 hipLaunchKernelGGL(sort, dim3((unsigned)nf), dim3(SORT_THREADS), 0, s_sort,
                                    d_pos2 + f0 * n2 * 3, cells, (int)n2, (int)n2p,
                                    excl ? h->excl2 : 0, pw2, po2, bb2, bc2, d_maxabs);
-            if (n_sets == 2) {
-                MDX_HIP(hipEventRecord(h->ev_sorted[set], s_sort));
-                MDX_HIP(hipStreamWaitEvent(h->stream, h->ev_sorted[set], 0));
-            }
         }
         CellArgs a{};
         a.pw1 = pw1;
@@ -650,8 +618,6 @@ static int accumulate_cell(mdx_rdf *h, const float *d_pos1, int64_t n1, const fl
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, h->stream, a);
         }
         h->timer.end(ev);
-        if (n_sets == 2)
-            MDX_HIP(hipEventRecord(h->ev_paired[set], h->stream));
         MDX_HIP(hipGetLastError());
     }
     h->pairs_evaluated += n_frames * n1 * n2;
@@ -1121,8 +1087,6 @@ int mdx_rdf_destroy(mdx_rdf_t h)
     // cache (DeviceBuffer::recycle), not through hipFree, which would wait for the device itself
     if (h->stream)
         (void)hipStreamSynchronize(h->stream);
-    if (h->sort_stream)
-        (void)hipStreamSynchronize(h->sort_stream);
     if (h->pipe.copy_stream)
         (void)hipStreamSynchronize(h->pipe.copy_stream);
     h->timer.destroy();
@@ -1133,16 +1097,8 @@ int mdx_rdf_destroy(mdx_rdf_t h)
                             &h->d_po1, &h->d_bb1, &h->d_pw2, &h->d_po2, &h->d_bb2, &h->d_bb16_1,
                             &h->d_bb16_2, &h->d_drop[0], &h->d_drop[1], &h->d_drop_box})
         b->recycle();
-    h->grouping[0].release();
-    h->grouping[1].release();
-    if (h->sort_stream) {
-        stream_release(h->sort_stream);
-        (void)hipEventDestroy(h->ev_inputs);
-        for (int b = 0; b < 2; ++b) {
-            (void)hipEventDestroy(h->ev_sorted[b]);
-            (void)hipEventDestroy(h->ev_paired[b]);
-        }
-    }
+    h->grouping[0].recycle();
+    h->grouping[1].recycle();
     if (h->stream)
         stream_release(h->stream);
     delete h;

@@ -177,9 +177,9 @@ static int sq_accumulate_points(mdx_sq *h, const float *d_pos, int64_t n, int64_
     int64_t max_group = 0;
     for (int g = 0; g < h->n_groups; ++g)
         max_group = std::max(max_group, h->offsets[g + 1] - h->offsets[g]);
-    // ... counted in waves: 256 CUs x 4 SIMDs x ~8 resident waves (MDX_SQ_WAVES overrides)
+    // ... counted in waves: 256 CUs x 4 SIMDs x ~8 resident waves
     const int block_waves = (h->quads ? SQ_QUAD_THREADS : h->columns ? h->col_threads : SQ_THREADS) / 64;
-    static const int64_t want_waves = getenv("MDX_SQ_WAVES") ? atoll(getenv("MDX_SQ_WAVES")) : 4096;
+    constexpr int64_t want_waves = 4096;
     int n_split = 1;
     while (int64_t(qblocks) * block_waves * h->n_groups * n_split * std::min<int64_t>(n_frames, 4096) <
                want_waves &&

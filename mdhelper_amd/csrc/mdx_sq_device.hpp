@@ -893,7 +893,7 @@ inline bool sq_quad_plan(const std::vector<short> &trip, int64_t n_q, const SqLa
         std::vector<SqQuadItem> blk;
         SqLattice bl{};
         double used_blk = 0.0;
-        if (allow_regular && !getenv("MDX_SQ_NO_REGULAR") && sq_build_quad_blocks(trip, n_q, base, blk, bl, used_blk)) {
+        if (allow_regular && sq_build_quad_blocks(trip, n_q, base, blk, bl, used_blk)) {
             const bool general = sq_build_quads(trip, n_q, base, items);
             const double used_gen = general ? double(n_q) / (double(items.size()) * SQ_QCOLS * SQ_ZPT) : 0.0;
             if (used_blk >= 0.45 && used_blk >= 0.92 * used_gen) {

@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (source_digest only; nothing touches the GPU in this process)
 
-ROUND = os.environ.get("MDX_ROUND", "r03")
+ROUND = os.environ.get("MDX_ROUND", "r04")
 OUT = os.path.join(ROOT, "gpurun_out", "counters")
 os.makedirs(OUT, exist_ok=True)
 ENV = dict(os.environ, TMPDIR="/tmp")
@@ -158,9 +158,26 @@ def rdf_requests(tag, workload, frames, atoms=None):
                        f"partial (counted as 32-byte) write requests at the L2 - fabric interface")
 
 
-def sq_entry(tag):
-    """fp64 instruction mix of the S(q) kernel per 64 phase terms, and the clock it ran at."""
-    args = ["--workload", "sq", "--steps", "2", "--warmup", "0", "--no-cpu-baseline"]
+def traffic_passes(tag, args, match, per):
+    """HBM bytes of the kernels whose name contains one of `match`, from separate FETCH_SIZE / WRITE_SIZE passes
+    (FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950), divided by `per`."""
+    total, by_kernel = 0.0, {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        line, res, calls, dur = run_pmc(tag, [ctr], args)
+        for k in res:
+            if any(m in k for m in match):
+                v = res[k][ctr] * 1024.0 * (2.0 if ctr == "FETCH_SIZE" else 1.0) / per
+                total += v
+                by_kernel[k.split("(")[0][-48:] + ":" + ctr] = v
+    return total, by_kernel, (f"profiles/{ROUND}_{tag}_FETCH_SIZE_pmc.csv + {ROUND}_{tag}_WRITE_SIZE_pmc.csv (separate "
+                              f"passes, FETCH doubled per MI355X_MICROARCH.md)")
+
+
+def sq_entry(tag, n_points=8, frames=1000):
+    """fp64 instruction mix of the S(q) kernel per 64 phase terms, the clock it ran at, its HBM traffic."""
+    steps = 2
+    args = ["--workload", "sq", "--steps", str(steps), "--warmup", "0", "--no-cpu-baseline", "--no-ingest",
+            "--n-points", str(n_points), "--frames", str(frames)]
     line, res, calls, dur = run_pmc(tag, ["SQ_INSTS_VALU", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64",
                                           "SQ_INSTS_VALU_ADD_F64"], args)
     k = pick(res, "sq_rho_quads_kernel")
@@ -169,7 +186,7 @@ def sq_entry(tag):
     out = dict(valu_per_64_terms=res[k]["SQ_INSTS_VALU"] / terms64,
                fp64_per_64_terms=(res[k]["SQ_INSTS_VALU_FMA_F64"] + res[k]["SQ_INSTS_VALU_MUL_F64"]
                                   + res[k]["SQ_INSTS_VALU_ADD_F64"]) / terms64,
-               kernel_share_of_step=dur[k] / max(sum(dur.values()), 1.0))
+               kernel_share_of_step=dur[k] / max(sum(dur.values()), 1.0), n_points=n_points, frames=frames)
     line, res, calls, dur = run_pmc(tag, ["GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS"], args)
     k = pick(res, "sq_rho_quads_kernel")
     out.update(clock_hz=res[k]["GRBM_GUI_ACTIVE"] / 8.0 / dur[k] * 1e9,
@@ -184,6 +201,41 @@ def sq_entry(tag):
     out.update(lds_idx_active_per_64_terms=res[k]["SQ_LDS_IDX_ACTIVE"] / terms64,
                lds_bank_conflict_per_64_terms=res[k]["SQ_LDS_BANK_CONFLICT"] / terms64,
                lds_wait_share_of_wave_cycles=res[k]["SQ_WAIT_INST_LDS"] / max(res[k]["SQ_WAVE_CYCLES"], 1.0))
+    total, by_kernel, src = traffic_passes(tag, args, ("sq_",), steps * frames)
+    out.update(hbm_bytes_per_frame=total, hbm_bytes_per_frame_by_kernel=by_kernel, traffic_source=src)
+    return out
+
+
+ISF_KERNELS = ("isf_incoherent", "sq_rho", "isf_coherent", "isf_reduce", "isf_rho_merge")
+
+
+def isf_entry(tag):
+    """The ISF step (32 768 particles, 512 wavevectors, 64 lags, 256 frames): fp64 instructions actually issued by its
+    kernels against the model bench.py prices (2.5 per 64 displacement terms + 4.5 per 64 rho terms), the clock,
+    the HBM traffic."""
+    frames = 256
+    args = ["--workload", "isf", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-ingest",
+            "--frames", str(frames)]
+    line, res, calls, dur = run_pmc(tag, ["SQ_INSTS_VALU", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64",
+                                          "SQ_INSTS_VALU_ADD_F64"], args)
+    ks = [k for k in res if any(m in k for m in ISF_KERNELS)]
+    fp64 = sum(res[k]["SQ_INSTS_VALU_FMA_F64"] + res[k]["SQ_INSTS_VALU_MUL_F64"] + res[k]["SQ_INSTS_VALU_ADD_F64"]
+               for k in ks)
+    valu = sum(res[k]["SQ_INSTS_VALU"] for k in ks)
+    model = line["roofline"]["model_fp64_instructions_per_step"]
+    out = dict(fp64_instructions_per_step=fp64, valu_instructions_per_step=valu, model_fp64_instructions_per_step=model,
+               fp64_ratio_to_model=fp64 / model, frames=frames,
+               per_kernel_fp64={k.split("(")[0][-48:]: res[k]["SQ_INSTS_VALU_FMA_F64"] + res[k]["SQ_INSTS_VALU_MUL_F64"]
+                                + res[k]["SQ_INSTS_VALU_ADD_F64"] for k in ks})
+    line, res, calls, dur = run_pmc(tag, ["GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS"], args)
+    ks = [k for k in res if any(m in k for m in ISF_KERNELS)]
+    big = max(ks, key=lambda k: dur[k])
+    out.update(clock_hz=res[big]["GRBM_GUI_ACTIVE"] / 8.0 / dur[big] * 1e9, clock_kernel=big.split("(")[0][-48:],
+               kernel_ns={k.split("(")[0][-48:]: dur[k] for k in ks},
+               source=f"profiles/{ROUND}_{tag}_SQ_INSTS_VALU_SQ_INSTS_VALU_FMA_F64_SQ_INST_pmc.csv, scripts/make_counters.py",
+               source_digest=bench.source_digest(*bench.ISF_SOURCES))
+    total, by_kernel, src = traffic_passes(tag, args, ISF_KERNELS, frames)
+    out.update(hbm_bytes_per_frame=total, hbm_bytes_per_frame_by_kernel=by_kernel, traffic_source=src)
     return out
 
 
@@ -198,8 +250,9 @@ MSD_TCC_PASSES = (
 )
 
 
-def msd_tcc(tag):
-    args = ["--workload", "msd", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+def msd_tcc(tag, blocks=1):
+    args = ["--workload", "msd", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-onsager",
+            "--blocks", str(blocks)]
     table = collections.defaultdict(dict)
     for ctrs in MSD_TCC_PASSES:
         try:
@@ -219,26 +272,18 @@ def msd_tcc(tag):
     return table
 
 
-def msd_entry(tag):
-    args = ["--workload", "msd", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
-    total = 0.0
-    per_kernel = {}
-    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-        line, res, calls, dur = run_pmc(tag, [ctr], args)
-        for k in res:
-            if "msd" in k or "msdfft" in k:
-                # warm-up + timed step: two identical passes
-                v = res[k][ctr] * 1024.0 * (2.0 if ctr == "FETCH_SIZE" else 1.0) / 2.0
-                total += v
-                per_kernel[k[:60] + ":" + ctr] = v
-    return dict(hbm_bytes_per_step=total, per_kernel_bytes_per_step=per_kernel,
-                traffic_source=f"profiles/{ROUND}_{tag}_FETCH_SIZE_pmc.csv + {ROUND}_{tag}_WRITE_SIZE_pmc.csv (separate passes, "
-                               f"FETCH doubled per MI355X_MICROARCH.md)",
+def msd_entry(tag, blocks=1):
+    args = ["--workload", "msd", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-onsager",
+            "--blocks", str(blocks)]
+    # warm-up + timed step + the extra result() pass of bench_msd: three identical passes of the push kernels
+    total, per_kernel, src = traffic_passes(tag, args, ("msd",), 3.0)
+    return dict(hbm_bytes_per_step=total, per_kernel_bytes_per_step=per_kernel, traffic_source=src, n_blocks=blocks,
                 source_digest=bench.source_digest(*bench.MSD_SOURCES))
 
 
 def main():
-    which = sys.argv[1:] or ["rdf_c2", "rdf_wide", "rdf_c5", "rdf_c1", "rdf_req", "sq_c3", "msd_c4", "msd_tcc", "stats"]
+    which = sys.argv[1:] or ["rdf_c2", "rdf_wide", "rdf_c5", "rdf_c1", "rdf_req", "sq_c3", "sq_default", "isf", "msd_c4",
+                             "msd_c4_b8", "msd_tcc", "stats"]
     path = os.path.join(OUT, "counters.json")
     data = {}
     if os.path.exists(os.path.join(ROOT, "profiles", "counters.json")):
@@ -259,22 +304,33 @@ def main():
         data["rdf_c2"]["hbm_requests"] = rdf_requests("rdf_c2", "rdf", 2000)
     if "sq_c3" in which:
         data["sq_c3"] = sq_entry("sq_c3")
+    if "sq_default" in which:                     # the reference's default grid: n_points = 32, 32 768 wavevectors
+        data["sq_default"] = sq_entry("sq_default", n_points=32, frames=100)
+    if "isf" in which:
+        data["isf"] = isf_entry("isf")
     if "msd_c4" in which:
         data["msd_c4"] = msd_entry("msd_c4")
+    if "msd_c4_b8" in which:
+        data["msd_c4_b8"] = msd_entry("msd_c4_b8", blocks=8)
     with open(path, "w") as fh:
         json.dump(data, fh, indent=1, sort_keys=True)
     if "msd_tcc" in which:
         msd_tcc("msd_c4")
+        msd_tcc("msd_c4_b8", blocks=8)
     if "stats" in which:
         # the default command itself (what the driver runs): its kernel averages must agree with the line's own
         run_stats("bench_default", ["--no-extras", "--cpu-seconds", "2"])
         run_stats("rdf_c2", ["--frames", "2000", "--steps", "4", "--no-cpu-baseline", "--no-extras"])
         run_stats("rdf_wide", ["--workload", "rdf_wide", "--frames", "500", "--steps", "2", "--no-cpu-baseline"])
         run_stats("rdf_c5", ["--atoms", "131072", "--frames", "500", "--steps", "2", "--no-cpu-baseline", "--no-extras"])
-        run_stats("msd_c4", ["--workload", "msd", "--steps", "3", "--no-cpu-baseline"])
-        run_stats("sq_c3", ["--workload", "sq", "--steps", "5", "--no-cpu-baseline"])
+        run_stats("rdf_c1", ["--workload", "rdf_wide", "--atoms", "1000", "--frames", "20000", "--steps", "2",
+                             "--no-cpu-baseline", "--no-extras"])
+        run_stats("msd_c4", ["--workload", "msd", "--steps", "3", "--no-cpu-baseline", "--no-onsager"])
+        run_stats("msd_c4_b8", ["--workload", "msd", "--blocks", "8", "--steps", "3", "--no-cpu-baseline", "--no-onsager"])
+        run_stats("sq_c3", ["--workload", "sq", "--steps", "5", "--no-cpu-baseline", "--no-ingest"])
         run_stats("sq_default_grid", ["--workload", "sq", "--n-points", "32", "--frames", "200", "--steps", "3",
-                                      "--no-cpu-baseline"])
+                                      "--no-cpu-baseline", "--no-ingest"])
+        run_stats("isf", ["--workload", "isf", "--steps", "2", "--no-cpu-baseline", "--no-ingest"])
     print(json.dumps(data, indent=1, sort_keys=True))
 
 

@@ -143,18 +143,11 @@ def test_rdf_cell_tile_pairs_straddling_half_a_box(dims, exclusion):
     assert np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("overlap", [True, False])
-def test_rdf_cell_many_slabs_sort_beside_pair_kernel(overlap, monkeypatch):
-    """Frames beyond one slab of sorted copies, both forms of mdx_rdf.hip::accumulate_cell: one set on one stream
-    (the default since the pair kernel is persistent) and, with MDX_RDF_OVERLAP=1, the sort of slab k + 1 on its own
-    stream beside the pair kernel of slab k, on the other of two sets.  MDX_RDF_SLAB_BYTES shrinks the slab so that
-    23 frames take eight slabs; two groups, changing boxes, two accumulate calls on one engine."""
+def test_rdf_cell_many_slabs(monkeypatch):
+    """Frames beyond one slab of sorted copies (mdx_rdf.hip::accumulate_cell: sort and pair kernel of slab after slab
+    on the handle's stream).  MDX_RDF_SLAB_BYTES shrinks the slab so that 23 frames take eight slabs; two groups,
+    changing boxes, two accumulate calls on one engine."""
     monkeypatch.setenv("MDX_RDF_SLAB_BYTES", str(3 * 33 * (3072 + 1024)))     # three frames per slab
-    monkeypatch.delenv("MDX_RDF_NO_OVERLAP", raising=False)
-    if overlap:
-        monkeypatch.setenv("MDX_RDF_OVERLAP", "1")
-    else:
-        monkeypatch.delenv("MDX_RDF_OVERLAP", raising=False)
     rng = np.random.default_rng(41)
     F, n1, n2 = 23, 3000, 1000
     Ls = (36 + 4 * rng.random((F, 3))).astype(np.float32)
