@@ -73,6 +73,13 @@ def run_stats(tag, bench_args):
     return json.loads(line)
 
 
+def short(name):
+    """The kernel's own identifier out of a demangled name (templates and argument lists dropped)."""
+    import re
+    m = re.search(r"(\w*kernel\w*)", name)
+    return m.group(1) if m else name[:60]
+
+
 def pick(res, needle):
     for k in res:
         if needle in k:
@@ -168,7 +175,7 @@ def traffic_passes(tag, args, match, per):
             if any(m in k for m in match):
                 v = res[k][ctr] * 1024.0 * (2.0 if ctr == "FETCH_SIZE" else 1.0) / per
                 total += v
-                by_kernel[k.split("(")[0][-48:] + ":" + ctr] = v
+                by_kernel[short(k) + ":" + ctr] = by_kernel.get(short(k) + ":" + ctr, 0.0) + v
     return total, by_kernel, (f"profiles/{ROUND}_{tag}_FETCH_SIZE_pmc.csv + {ROUND}_{tag}_WRITE_SIZE_pmc.csv (separate "
                               f"passes, FETCH doubled per MI355X_MICROARCH.md)")
 
@@ -209,6 +216,13 @@ def sq_entry(tag, n_points=8, frames=1000):
 ISF_KERNELS = ("isf_incoherent", "sq_rho", "isf_coherent", "isf_reduce", "isf_rho_merge")
 
 
+def _sum_by(keys, value):
+    out = {}
+    for k in keys:
+        out[short(k)] = out.get(short(k), 0.0) + value(k)
+    return out
+
+
 def isf_entry(tag):
     """The ISF step (32 768 particles, 512 wavevectors, 64 lags, 256 frames): fp64 instructions actually issued by its
     kernels against the model bench.py prices (2.5 per 64 displacement terms + 4.5 per 64 rho terms), the clock,
@@ -225,13 +239,13 @@ def isf_entry(tag):
     model = line["roofline"]["model_fp64_instructions_per_step"]
     out = dict(fp64_instructions_per_step=fp64, valu_instructions_per_step=valu, model_fp64_instructions_per_step=model,
                fp64_ratio_to_model=fp64 / model, frames=frames,
-               per_kernel_fp64={k.split("(")[0][-48:]: res[k]["SQ_INSTS_VALU_FMA_F64"] + res[k]["SQ_INSTS_VALU_MUL_F64"]
-                                + res[k]["SQ_INSTS_VALU_ADD_F64"] for k in ks})
+               per_kernel_fp64=_sum_by(ks, lambda k: res[k]["SQ_INSTS_VALU_FMA_F64"] + res[k]["SQ_INSTS_VALU_MUL_F64"]
+                                       + res[k]["SQ_INSTS_VALU_ADD_F64"]))
     line, res, calls, dur = run_pmc(tag, ["GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS"], args)
     ks = [k for k in res if any(m in k for m in ISF_KERNELS)]
     big = max(ks, key=lambda k: dur[k])
-    out.update(clock_hz=res[big]["GRBM_GUI_ACTIVE"] / 8.0 / dur[big] * 1e9, clock_kernel=big.split("(")[0][-48:],
-               kernel_ns={k.split("(")[0][-48:]: dur[k] for k in ks},
+    out.update(clock_hz=res[big]["GRBM_GUI_ACTIVE"] / 8.0 / dur[big] * 1e9, clock_kernel=short(big),
+               kernel_ns=_sum_by(ks, lambda k: dur[k]),
                source=f"profiles/{ROUND}_{tag}_SQ_INSTS_VALU_SQ_INSTS_VALU_FMA_F64_SQ_INST_pmc.csv, scripts/make_counters.py",
                source_digest=bench.source_digest(*bench.ISF_SOURCES))
     total, by_kernel, src = traffic_passes(tag, args, ISF_KERNELS, frames)
@@ -262,7 +276,7 @@ def msd_tcc(tag, blocks=1):
             continue
         for k in res:
             if "msd" in k:
-                name = k.split("(")[0][-48:]
+                name = short(k)
                 table[name]["dispatches"] = len(calls[k])
                 table[name]["duration_ms"] = dur[k] / 1e6
                 for c in ctrs:
