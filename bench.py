@@ -1001,6 +1001,11 @@ def bench_onsager(args, world, engine_ms):
     finally:
         os.unlink(tmp.name)
     del h, um
+    # the host legs against what the link gave for the same 12 GB in this process
+    for name, key in (("class_host_f32", "h2d_pageable_ring_GB_per_sec"), ("class_host_f32_pinned", "h2d_page_locked_GB_per_sec")):
+        if name in legs:
+            legs[name]["link_bound_ms"] = gb32 / legs[key] * 1e3
+            legs[name]["link_bound_over_class"] = legs[name]["link_bound_ms"] / legs[name]["ms_per_analysis"]
     # every leg analysed the same numbers (float64 = the widened float32)
     ref = keep["class_hbm_f64"].results
     for name, o in keep.items():

@@ -61,6 +61,10 @@ int mdx_memset(int dev, void *dst, int value, size_t bytes);
  * where it lies, pageable memory through the library's pinned ring with its copy threads (mdx_memcpy_h2d is
  * the runtime's own single-threaded staging).  Returns when the data is in HBM. */
 int mdx_upload(int dev, void *d_dst, const void *src, size_t bytes);
+/* ... for n_rows rows of row_bytes that lie src_stride bytes apart on the host and end up contiguous in HBM: a
+ * range of particles out of every frame of float32[T][N][3] (row_bytes = 12 n_range, src_stride = 12 N) — what
+ * Onsager streams per group while the group before is being transformed (transport.py:976-992). */
+int mdx_upload_rows(int dev, void *d_dst, const void *src, size_t row_bytes, size_t src_stride, size_t n_rows);
 /* Destroyed handles leave their device blocks in a per-device cache (at most 4 GiB, blocks up to 512 MiB) so
  * that an analysis object per call does not pay hipMalloc / hipFree each time; the cache is given back
  * automatically when an allocation of the library fails (handles' buffers, mdx_malloc) and here on request

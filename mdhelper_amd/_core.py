@@ -51,6 +51,18 @@ class DeviceArray:
             raise
         return out
 
+    def upload_columns(self, host, first: int, count: int):
+        """Fill this array ``[T, count, ...]`` with columns ``[first, first + count)`` of the host array
+        ``[T, N, ...]`` (``mdx_upload_rows``: pinned ring and copy threads, or one 2-D DMA out of page-locked memory)."""
+        host = np.asarray(host)
+        if host.dtype != self.dtype or not host.flags.c_contiguous or host.shape[0] != self.shape[0] \
+                or host.shape[2:] != self.shape[2:] or self.shape[1] != count \
+                or not 0 <= first <= first + count <= host.shape[1]:
+            raise ValueError("upload_columns: shapes / dtype do not match")
+        item = int(np.prod(host.shape[2:], dtype=np.int64)) * host.dtype.itemsize
+        src = c_void_p(host.ctypes.data + first * item)
+        check(lib().mdx_upload_rows(self.dev, self.ptr, src, count * item, host.shape[1] * item, host.shape[0]))
+
     def to_host(self, first: int = 0, count: int | None = None):
         """Copy rows [first, first+count) of the leading axis back to the host."""
         n0 = self.shape[0]
@@ -65,6 +77,19 @@ class DeviceArray:
         """Raw pointer to row ``first`` of the leading axis."""
         row = self.nbytes // max(self.shape[0], 1)
         return c_void_p(self.ptr.value + first * row)
+
+    @staticmethod
+    def view(base, shape):
+        """The leading bytes of ``base`` as an array of another shape (same dtype) that does not own its memory."""
+        v = object.__new__(_DeviceView)
+        v.shape = tuple(int(x) for x in shape)
+        v.dtype, v.dev = base.dtype, base.dev
+        v.nbytes = int(np.prod(v.shape)) * base.dtype.itemsize
+        if v.nbytes > base.nbytes:
+            raise ValueError("view larger than its base")
+        v.ptr = c_void_p(base.ptr.value)
+        v.base = base
+        return v
 
     def rows(self, first: int, count: int):
         """Rows [first, first+count) of the leading axis as a DeviceArray that does not own its memory
@@ -600,6 +625,10 @@ class MsdEngine(_Engine):
 
     def reset(self):
         check(lib().mdx_msd_reset(self.handle))
+
+    def synchronize(self):
+        """Wait for everything queued on the engine's stream."""
+        check(lib().mdx_msd_stats(self.handle, None, None, None))
 
     def allreduce(self, comm: RcclComm):
         check(lib().mdx_msd_allreduce(self.handle, comm.handle))

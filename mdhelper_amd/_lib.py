@@ -43,6 +43,7 @@ _SIGNATURES = {
     "mdx_memcpy_d2h": (c_int, [c_int, _vp, _vp, c_size_t]),
     "mdx_memset": (c_int, [c_int, _vp, c_int, c_size_t]),
     "mdx_upload": (c_int, [c_int, _vp, _vp, c_size_t]),
+    "mdx_upload_rows": (c_int, [c_int, _vp, _vp, c_size_t, c_size_t, c_size_t]),
     "mdx_trim_cache": (c_int, [c_int, POINTER(c_size_t)]),
     "mdx_device_synchronize": (c_int, [c_int]),
     "mdx_host_register": (c_int, [c_int, _vp, c_size_t]),

@@ -144,6 +144,10 @@ struct HostStager {
     // d_dst[0, bytes) <- src: directly when src is pinned / registered memory, else in chunks
     // through the ring with the workers copying; the data is ordered before later work on `consumer`
     int upload(int device, hipStream_t consumer, void *d_dst, const void *src, size_t bytes);
+    // the same for n_rows rows of row_bytes that lie src_stride apart on the host and end up contiguous in d_dst
+    // (a range of particles out of frames [T][N][3]: what one group of an MSD analysis needs of every frame)
+    int upload_rows(int device, hipStream_t consumer, void *d_dst, const void *src, size_t row_bytes,
+                    size_t src_stride, size_t n_rows);
     int drain();                                     // host waits for every pinned buffer
     void destroy();
 };

@@ -537,6 +537,48 @@ int HostStager::upload(int device, hipStream_t consumer, void *d_dst, const void
     return finish(consumer);
 }
 
+int HostStager::upload_rows(int device, hipStream_t consumer, void *d_dst, const void *src, size_t row_bytes,
+                            size_t src_stride, size_t n_rows)
+{
+    if (row_bytes == 0 || n_rows == 0)
+        return MDX_OK;
+    if (src_stride == row_bytes)
+        return upload(device, consumer, d_dst, src, row_bytes * n_rows);
+    std::lock_guard<std::mutex> guard(lock);
+    const uint8_t *from = static_cast<const uint8_t *>(src);
+    // page-locked / registered memory (both ends of the strided range): one 2-D DMA where it lies
+    hipPointerAttribute_t attr, attr_end;
+    if (hipPointerGetAttributes(&attr, src) == hipSuccess && attr.type == hipMemoryTypeHost &&
+        hipPointerGetAttributes(&attr_end, from + (n_rows - 1) * src_stride + row_bytes - 1) == hipSuccess &&
+        attr_end.type == hipMemoryTypeHost) {
+        MDX_HIP(hipMemcpy2DAsync(d_dst, row_bytes, src, src_stride, row_bytes, n_rows, hipMemcpyHostToDevice, consumer));
+        return MDX_OK;
+    }
+    (void)hipGetLastError();
+    // pageable: whole rows gathered into the pinned ring by the copy threads, 16 MB at a time
+    const size_t chunk = size_t(16) << 20;
+    const size_t rows_per = std::max<size_t>(1, chunk / row_bytes);
+    MDX_TRY(ensure(device, std::max(chunk, row_bytes)));
+    MDX_TRY(after(consumer));
+    uint8_t *to = static_cast<uint8_t *>(d_dst);
+    const int parts = workers.size();
+    for (size_t r0 = 0; r0 < n_rows; r0 += rows_per) {
+        const size_t nr = std::min(rows_per, n_rows - r0);
+        int b;
+        void *host;
+        MDX_TRY(acquire(&b, &host));
+        const size_t per = (nr + parts - 1) / parts;
+        const std::function<void(int)> copy = [&](int t) {
+            const size_t lo = size_t(t) * per, hi = std::min(nr, lo + per);
+            for (size_t r = lo; r < hi; ++r)
+                memcpy(static_cast<uint8_t *>(host) + r * row_bytes, from + (r0 + r) * src_stride, row_bytes);
+        };
+        workers.parallel_for(parts, copy);
+        MDX_TRY(send(b, to + r0 * row_bytes, nr * row_bytes));
+    }
+    return finish(consumer);
+}
+
 void HostStager::destroy()
 {
     if (dev >= 0)
@@ -751,6 +793,21 @@ int mdx_free(int dev, void *dptr)
         }
     }
     MDX_HIP(hipFree(dptr));
+    return MDX_OK;
+}
+
+int mdx_upload_rows(int dev, void *d_dst, const void *src, size_t row_bytes, size_t src_stride, size_t n_rows)
+{
+    MDX_REQUIRE(d_dst && src, "NULL argument");
+    MDX_REQUIRE(src_stride >= row_bytes, "rows overlap: src_stride < row_bytes");
+    MDX_TRY(set_device(dev));
+    hipStream_t stream = nullptr;
+    MDX_TRY(stream_acquire(&stream));
+    const int rc = device_stager(dev).upload_rows(dev, stream, d_dst, src, row_bytes, src_stride, n_rows);
+    const hipError_t e = hipStreamSynchronize(stream);   // also on an error: no copy outlives the call
+    stream_release(stream);
+    MDX_TRY(rc);
+    MDX_HIP(e);
     return MDX_OK;
 }
 

@@ -522,6 +522,44 @@ def test_onsager_resident_streamed_and_hbm_universe_routes_agree(tmp_path, mode)
     d64.free()
 
 
+@pytest.mark.parametrize("mode", ["plain", "unwrap", "unwrap, bonds", "zero, blocks"])
+def test_onsager_host_groups_streamed_in_column_chunks(mode):
+    """Plain atom groups over consecutive particles of an in-memory trajectory travel in column chunks
+    (mdx_upload_rows into two alternating device blocks, the chunk before transformed meanwhile:
+    Onsager._stream_host_groups); the result must be that of whole frames kept in HBM and of the per-frame
+    host protocol — ragged last chunks, unwrapping with its per-chunk state, molecules made whole in the first
+    frame, a zeroed dimension, several blocks."""
+    import warnings
+    from mdhelper_amd.analysis import Onsager
+    rng = np.random.default_rng(77)
+    T, sizes, L = 260, (53, 38), np.array([9.0, 10.5, 8.25])
+    N = sum(sizes) + 5
+    walk = rng.uniform(0, L, (1, N, 3)) + np.cumsum(rng.normal(0.01, 0.3, (T, N, 3)), axis=0)
+    unwrap = "unwrap" in mode
+    stored = (np.mod(walk, L) if unwrap else walk).astype(np.float32)
+    dims = np.array([*L, 90, 90, 90], dtype=np.float32)
+    bonds = np.stack((np.arange(0, N - 1, 2), np.arange(1, N, 2)), axis=1) if "bonds" in mode else None
+    u = mdhelper_amd.ArrayUniverse(stored, dims, dt=0.5, bonds=bonds)
+    kw = dict(temperature=300, n_blocks=4 if "blocks" in mode else 1, unwrap=unwrap, verbose=False,
+              dimensions=[L[0], 0.0, L[2]] if "zero" in mode else None)
+
+    def run(route):
+        groups = [u.atoms[2:2 + sizes[0]], u.atoms[2 + sizes[0]:2 + sum(sizes)]]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            o = Onsager(groups, **kw)
+            o._stream_columns = route == "columns"
+            return (per_frame(o) if route == "per_frame" else o).run()
+
+    cols, whole, host = run("columns"), run("whole"), run("per_frame")
+    assert cols._from_file and whole._from_file and not host._from_file
+    for name in ("msd_self", "msd_cross"):
+        y = host.results[name]
+        assert np.allclose(cols.results[name], y, rtol=1e-8, atol=1e-9 * np.abs(y).max()), name
+        assert np.allclose(whole.results[name], y, rtol=1e-8, atol=1e-9 * np.abs(y).max()), name
+    assert np.abs(host.results.msd_self).max() > 0.5
+
+
 def test_onsager_unwrap_of_a_chain_longer_than_two_cells_starts_like_the_reference():
     """Reference topology.py:366-376: the first ``unwrap`` call after ``make_whole`` (transport.py:936-941)
     moves an image flag by sign(x - x_whole) — by one — however many cells a made-whole atom lies from
