@@ -288,3 +288,33 @@ def test_fragments_and_make_whole_images():
     # no bonds: nothing to make whole
     u0 = mdhelper_amd.ArrayUniverse(wrapped[None], [*L, 90, 90, 90])
     assert not make_whole_images(u0, L).any() and len(u0.atoms.fragments) == 14
+
+
+def test_equal_wavenumber_means_follow_the_reference_loop():
+    """structure.py:1536-1541 / 2116-2127: columns whose wavenumber is numpy.isclose to a unique one are averaged.
+    The bisection + segmented-sum form must give the reference loop's result on grids (every column belongs to one
+    unique wavenumber) and fall back to the loop itself where uniques lie within isclose's tolerance of each other."""
+    from mdhelper_amd.analysis.structure import _mean_over_equal_wavenumbers as fast
+    rng = np.random.default_rng(4)
+
+    def loop(x, w, u):
+        return np.stack([x[..., np.isclose(q, w)].mean(axis=-1) for q in u], axis=-1)
+
+    for n, L in ((6, 31.0), (9, 68.94)):
+        grid = 2 * np.pi * np.arange(n) / L
+        w = np.linalg.norm(np.stack(np.meshgrid(grid, grid, grid), -1).reshape(-1, 3), axis=1)
+        u = np.unique(w.round(11))
+        for shape in ((3, len(w)), (4, 2, len(w))):
+            x = rng.normal(size=shape)
+            assert np.allclose(fast(x, w, u), loop(x, w, u), rtol=1e-13, atol=1e-15)
+    # non-cubic cell, arbitrary wavevectors, unsorted uniques
+    w = np.linalg.norm(rng.normal(size=(300, 3)), axis=1)
+    w = np.concatenate((w, w[:40]))
+    u = np.unique(w.round(11))[::-1].copy()
+    x = rng.normal(size=(2, len(w)))
+    assert np.allclose(fast(x, w, u), loop(x, w, u), rtol=1e-13, atol=1e-15)
+    # uniques closer than isclose's tolerance: both columns count for both (the reference's behaviour)
+    w = np.array([1.0, 1.0 + 2e-6, 2.0, 2.0])
+    u = np.unique(w.round(11))
+    x = np.arange(8.0).reshape(2, 4)
+    assert np.array_equal(fast(x, w, u), loop(x, w, u))
