@@ -1,0 +1,23 @@
+#!/bin/bash
+# Round-4 bench lines for profiles/ (run on the GPU box through gpurun).
+out=gpurun_out/r4final; mkdir -p $out
+run() { name=$1; shift; t0=$(date +%s.%N); python bench.py "$@" > $out/$name.json 2> $out/$name.err; echo "$name: $(echo "$(date +%s.%N) - $t0" | bc) s wall"; }
+run bench_final
+run bench_c5size --atoms 131072 --frames 500 --steps 3 --no-extras --cpu-seconds 3
+run bench_c1like --workload rdf_wide --atoms 1000 --frames 20000 --steps 3 --no-extras --cpu-seconds 3
+run bench_sq_c3 --workload sq --steps 10 --warmup 2
+run bench_sq_default_grid --workload sq --n-points 32 --frames 200 --steps 3 --no-ingest
+run bench_isf --workload isf --steps 3 --warmup 1
+run bench_msd_20steps --workload msd --steps 20 --warmup 3
+run bench_msd8 --workload msd --blocks 8 --steps 20 --warmup 3
+run bench_2ranks_shared --gpus 2 --share-devices --shard-fixed --frames 2000 --steps 2 --no-cpu-baseline
+python - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/r4final/*.json")):
+    try:
+        d = json.load(open(f))
+        r = d.get("roofline", {})
+        print(f.split("/")[-1], d.get("metric"), "%.4g" % d.get("value", 0), "ms/step %.2f" % d.get("ms_per_step", 0), "frac", r.get("frac"), "traffic", r.get("traffic"))
+    except Exception as e:
+        print(f, "ERR", e)
+PY
