@@ -367,13 +367,19 @@ static int msd_push_device(mdx_msd *h, int group, const double *d_pos, int64_t n
     if (count == 0)
         return MDX_OK;
     const int B = h->n_blocks;
-    // chunk the particles so that series + spectrum stay within ~40% of free HBM
-    size_t free_b = 0, total_b = 0;
-    MDX_HIP(hipMemGetInfo(&free_b, &total_b));
-    free_b += h->d_series.bytes + h->d_spec.bytes + cached_device_bytes(h->dev);
+    // chunk the particles so that series + spectrum stay within ~40% of free HBM.  The driver is asked for the
+    // free memory only when the buffers the handle already holds do not take the whole push as one chunk:
+    // hipMemGetInfo costs the host 1 - 2 ms, and right after a synchronisation point (every analysis starts with
+    // one) the device idles for as long.
     const int64_t per_atom = h->own_fft ? 3 * B * h->n_fft * 8   // Y: one complex per two reals
                                         : 3 * B * (h->n_fft * 8 + h->nc * 16);
-    int64_t chunk = std::max<int64_t>(1, int64_t(double(free_b) * 0.4) / per_atom);
+    int64_t chunk = count;
+    if (size_t(count + 6) * per_atom > h->d_series.bytes + h->d_spec.bytes) {
+        size_t free_b = 0, total_b = 0;
+        MDX_HIP(hipMemGetInfo(&free_b, &total_b));
+        free_b += h->d_series.bytes + h->d_spec.bytes + cached_device_bytes(h->dev);
+        chunk = std::max<int64_t>(1, int64_t(double(free_b) * 0.4) / per_atom);
+    }
     chunk = std::min<int64_t>(chunk, count);
     // a handful of equal chunks keeps the rocFFT plan cache small
     const int64_t n_chunks = ceil_div(count, chunk);
