@@ -820,6 +820,10 @@ def bench_msd(args, world):
         if world.comm is not None and not world.device_collectives:
             msd, tr = world.reduce_host(msd), world.reduce_host(tr)
         box["msd"], box["traj"] = msd, tr
+        # (reset() clears the engine's event timer: the kernels' time is summed step by step, so that the roofline
+        # figure covers the same steps as ms_per_step — the first steps after an idle period run at a lower clock)
+        box["kernel_ms"] = box.get("kernel_ms", 0.0) + eng.stats()["kernel_ms"]
+        box["kernel_steps"] = box.get("kernel_steps", 0) + 1
 
     def finish():
         pass
@@ -827,8 +831,10 @@ def bench_msd(args, world):
     for _ in range(args.warmup):     # includes the inverse-transform plan (rocFFT builds it once)
         step()
 
+    box["kernel_ms"], box["kernel_steps"] = 0.0, 0
     dt, own = timed_region(world, dev, args.steps, step, finish)
     st = eng.stats()
+    st["kernel_ms"] = box["kernel_ms"] / max(box["kernel_steps"], 1)      # average over the timed steps
     # what result() costs on its own (inverse transforms + recurrence + D2H), the pushes already finished
     eng.reset()
     for g, (first, count) in enumerate(mine):

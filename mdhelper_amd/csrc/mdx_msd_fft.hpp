@@ -1280,10 +1280,10 @@ constexpr int ROWS_PARTS_MAX = 32;
 constexpr int BLOCK_SLOTS = 512;   // two 512-thread blocks per CU (their LDS) x 256 CUs
 
 // A factor f in [lo, hi] for a grid of base * f equal blocks: the smallest one that gives at least
-// four rounds of the chip's block slots and wastes under 3 % of the last round (a grid of 3.7 rounds
+// min_rounds (four) rounds of the chip's block slots and wastes under 3 % of the last round (a grid of 3.7 rounds
 // takes as long as one of 4; with fewer than ~4 rounds the ramp-up and the tail weigh too much), else
 // the one that wastes least.
-inline int slots_split(int64_t base, int lo, int hi)
+inline int slots_split(int64_t base, int lo, int hi, int min_rounds = 4)
 {
     int best = lo;
     double best_eff = -1.0;
@@ -1291,10 +1291,10 @@ inline int slots_split(int64_t base, int lo, int hi)
         const int64_t blocks = base * f;
         const int64_t rounds = (blocks + BLOCK_SLOTS - 1) / BLOCK_SLOTS;
         const double eff = double(blocks) / double(rounds * BLOCK_SLOTS);
-        if (rounds >= 4 && eff >= 0.97)
+        if (rounds >= min_rounds && eff >= 0.97)
             return f;
-        if (eff * (rounds >= 4 ? 1.0 : 0.9) > best_eff) {
-            best_eff = eff * (rounds >= 4 ? 1.0 : 0.9);
+        if (eff * (rounds >= min_rounds ? 1.0 : 0.9) > best_eff) {
+            best_eff = eff * (rounds >= min_rounds ? 1.0 : 0.9);
             best = f;
         }
     }
@@ -1390,7 +1390,9 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
     } else if (sh.r1 == 400 && part) {
         // per-frame sums fused into pass A: super groups of SG pair groups, >= ~1024 blocks
         const int n_sg = fused_super_groups(p_pad);
-        const int fsplit = slots_split(int64_t(n_sg) * n_blocks, 8, std::min(64, sh.r2));
+        // (twelve rounds of the chip's block slots: C4 with one block 27.1 -> 26.2 ms of kernels per step against the
+        // four rounds of round 2 — blocks in more different phases share a CU, and the tail is a twelfth)
+        const int fsplit = slots_split(int64_t(n_sg) * n_blocks, 8, std::min(64, sh.r2), 12);
         if (sh.r2 == 64)
             hipLaunchKernelGGL((msd_fft_cols400_fused_kernel<64>), dim3((unsigned)n_sg, (unsigned)fsplit, (unsigned)n_blocks),
                                dim3(THREADS), 0, stream, pos, n_total, first, n_elem, t_block, zero_dims, p_pad,
