@@ -1276,7 +1276,7 @@ def run_extras(args, world):
     extra = {}
     # (ten and twelve steps: a step is 3.5 / 27 ms, and the first few after another workload run at a lower clock)
     plan = (("sq", dict(workload="sq", frames=1000, steps=10, warmup=2)),
-            ("msd", dict(workload="msd", frames=None, steps=12, warmup=2)),
+            ("msd", dict(workload="msd", frames=None, steps=12, warmup=5)),
             ("rdf_wide", dict(workload="rdf_wide", frames=1000, steps=3, warmup=1)))
     for name, over in plan:
         a = copy.copy(args)
