@@ -148,6 +148,15 @@ def _is_array_trajectory(traj) -> bool:
     return hasattr(traj, "frame_block") and hasattr(traj, "box_block")
 
 
+def _device_frames(traj, frames):
+    """The listed frames as a float32 device array without a copy (a ``universe.DeviceTrajectory`` over float32
+    frames, consecutive frames), else None: the caller then goes through host memory."""
+    block = getattr(traj, "device_block", None)
+    if block is None or traj.device_array.dtype != np.float32:
+        return None
+    return block(frames)
+
+
 class RadialDistributionFunction(DynamicAnalysisBase):
     r"""
     Radial distribution function :math:`g_{ij}(r)` and related properties
@@ -351,6 +360,17 @@ class RadialDistributionFunction(DynamicAnalysisBase):
             if native is not None:
                 self._engine.accumulate_traj(native, sel, boxes, None if all1 else i1,
                                              None if self._same else i2, same=self._same)
+                continue
+            resident = _device_frames(traj, sel) if (all1 and self._same and off1 is None) else None
+            if resident is not None:
+                # float32 frames already in HBM (ArrayUniverse.from_device), every particle, one group: the
+                # kernels read them where they lie
+                d_boxes = _core.DeviceArray.from_host(
+                    np.ascontiguousarray(np.broadcast_to(np.asarray(boxes, dtype=np.float32), (len(sel), 6))),
+                    self._device)
+                self._engine.accumulate_device(resident.ptr, traj.n_atoms, None, traj.n_atoms, d_boxes.ptr, len(sel))
+                self._engine.synchronize()
+                d_boxes.free()
                 continue
             pos = traj.frame_block(sel)
             p1 = pos if all1 else pos[:, i1]
@@ -605,13 +625,19 @@ class StructureFactor(NumbaAnalysisBase):
             sel = mine[b0:b0 + block]
             if self._engine is None:       # an ISF rank without wavevectors of its own
                 break
+            resident = _device_frames(traj, sel) if (identity and not self._engine_has_grouping()) else None
             if native is not None:
                 self._engine.accumulate_traj(native, sel, None if identity else index)
+            elif resident is not None:
+                self._engine.accumulate_device(resident.ptr, traj.n_atoms, len(sel))      # frames already in HBM
             else:
                 pos = traj.frame_block(sel)
                 self._engine.accumulate(pos if identity else pos[:, index])
         self._conclude()
         return self
+
+    def _engine_has_grouping(self) -> bool:
+        return any(g != "atoms" for g in self._groupings)
 
     def _conclude(self) -> None:
         self._batch.flush()

@@ -609,3 +609,51 @@ def test_structure_factor_and_isf_centres_of_mass_on_device(kind, tmp_path):
         si.run()
         assert np.allclose(fi.results.cisf, si.results.cisf, rtol=1e-10, atol=1e-12), groupings
         assert np.allclose(fi.results.iisf, si.results.iisf, rtol=1e-10, atol=1e-12), groupings
+
+
+def test_structure_classes_on_frames_resident_in_hbm():
+    """``ArrayUniverse.from_device``: float32 frames already in HBM are analysed where they lie (RDF of all
+    particles, S(q) / ISF over groups that tile the particles in order); selections, float64 frames and scattered
+    frame lists go through host memory.  Every route must give the in-memory universe's result."""
+    from mdhelper_amd import _core
+    from mdhelper_amd.analysis import IntermediateScatteringFunction
+    rng = np.random.default_rng(23)
+    F, N, L = 40, 1500, 19.0
+    pos = np.mod(rng.uniform(0, L, (1, N, 3)) + np.cumsum(rng.normal(0, 0.2, (F, N, 3)), axis=0), L).astype(np.float32)
+    dims = np.array([L, L, L, 90, 90, 90], dtype=np.float32)
+    um = mdhelper_amd.ArrayUniverse(pos, dims)
+    d32, d64 = _core.DeviceArray.from_host(pos), _core.DeviceArray.from_host(pos.astype(np.float64))
+    u32 = mdhelper_amd.ArrayUniverse.from_device(d32, dims)
+    u64 = mdhelper_amd.ArrayUniverse.from_device(d64, dims)
+
+    def rdf(u, **run):
+        return RadialDistributionFunction(u.atoms, n_bins=60, range=(0.0, 8.0), exclusion=(1, 1),
+                                          verbose=False).run(**run).results.counts
+
+    want = rdf(um)
+    assert np.array_equal(rdf(u32), want) and np.array_equal(rdf(u64), want)
+    assert np.array_equal(rdf(u32, start=5, stop=31), rdf(um, start=5, stop=31))
+    assert np.array_equal(rdf(u32, frames=np.arange(0, F, 3)), rdf(um, frames=np.arange(0, F, 3)))
+    cross = lambda u: RadialDistributionFunction(u.atoms[:700], u.atoms[700:], n_bins=60, range=(0.0, 8.0),  # noqa: E731
+                                                 verbose=False).run().results.counts
+    assert np.array_equal(cross(u32), cross(um))
+
+    def sq(u, **run):
+        return StructureFactor((u.atoms[:600], u.atoms[600:]), mode="partial", n_points=5, verbose=False).run(**run)
+
+    a, b, c = sq(um), sq(u32), sq(u64)
+    assert np.allclose(b.results.ssf, a.results.ssf, rtol=1e-12, atol=1e-12 * np.abs(a.results.ssf).max())
+    assert np.allclose(c.results.ssf, a.results.ssf, rtol=1e-12, atol=1e-12 * np.abs(a.results.ssf).max())
+    a, b = sq(um, start=3, stop=33, step=2), sq(u32, start=3, stop=33, step=2)
+    assert np.allclose(b.results.ssf, a.results.ssf, rtol=1e-12, atol=1e-12 * np.abs(a.results.ssf).max())
+
+    def isf(u):
+        return IntermediateScatteringFunction((u.atoms[:600], u.atoms[600:]), mode="partial", n_points=4, n_lags=6,
+                                              incoherent=True, verbose=False).run()
+
+    a, b = isf(um), isf(u32)
+    for name in ("cisf", "iisf"):
+        x, y = b.results[name], a.results[name]
+        assert np.allclose(x, y, rtol=1e-12, atol=1e-12 * np.abs(y).max()), name
+    d32.free()
+    d64.free()
