@@ -877,6 +877,11 @@ def bench_msd(args, world):
                      "kernel": "msd pipeline of one step: forward transforms with the per-frame sums fused in + "
                                "power (msd_fft_cols/rows_power kernels for n_fft = 2^13..2^16, 204800, "
                                "2^18..2^20, else gather + rocFFT R2C + power)",
+                     # what the memory system actually carries: the counters' bytes of a step over the kernels' time
+                     # (the half-transformed block is written and read once: 5.2 x the algorithmic bytes)
+                     "hbm_throughput_GBps": (ctr["hbm_bytes_per_step"] / max(kernel_s, 1e-9) / 1e9) if ctr else None,
+                     "hbm_throughput_frac_of_peak": (ctr["hbm_bytes_per_step"] / max(kernel_s, 1e-9) / 1e9 / HBM_PEAK_GBS)
+                     if ctr else None,
                      "kernel_ms_per_step": st["kernel_ms"],
                      "kernel_ms_each_step": [round(x, 3) for x in box["kernel_ms_each"]],
                      # (on the shared hosts a step now and then takes twice as long — the list shows them; the
