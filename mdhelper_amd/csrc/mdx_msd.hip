@@ -672,10 +672,10 @@ template <typename In> struct HostFrames final : FrameSource {
     }
     int stage(mdx_msd *h, int64_t a0, int64_t c, int64_t f0, int64_t nf, void *d_out) override
     {
+        // (through the pinned ring, or one 2-D DMA out of page-locked memory: not the runtime's pageable path)
         const size_t row = 3 * sizeof(In);
-        MDX_HIP(hipMemcpy2DAsync(d_out, row * c, pos + (f0 * n_sel + a0) * 3, row * n_sel, row * c,
-                                 (size_t)nf, hipMemcpyHostToDevice, h->stream));
-        return MDX_OK;
+        return device_stager(h->dev).upload_rows(h->dev, h->stream, d_out, pos + (f0 * n_sel + a0) * 3, row * c,
+                                                 row * n_sel, (size_t)nf);
     }
 };
 
@@ -1080,9 +1080,8 @@ int mdx_msd_push(mdx_msd_t h, int group, const double *pos, int64_t n_total, int
     for (int64_t a0 = 0; a0 < count; a0 += chunk) {
         const int64_t c = std::min(chunk, count - a0);
         MDX_TRY(h->d_stage.ensure(size_t(T) * c * 24));
-        MDX_HIP(hipMemcpy2DAsync(h->d_stage.ptr, size_t(c) * 24, pos + (first + a0) * 3,
-                                 size_t(n_total) * 24, size_t(c) * 24, (size_t)T,
-                                 hipMemcpyHostToDevice, h->stream));
+        MDX_TRY(device_stager(h->dev).upload_rows(h->dev, h->stream, h->d_stage.ptr, pos + (first + a0) * 3,
+                                                  size_t(c) * 24, size_t(n_total) * 24, (size_t)T));
         MDX_TRY(msd_push_device(h, group, h->d_stage.as<double>(), c, 0, c, zero_dims));
         MDX_HIP(hipStreamSynchronize(h->stream));
     }
@@ -1374,7 +1373,7 @@ static int msd_result(mdx_msd_t h, double *msd_self_sum, double *acf_sum, double
     const int64_t Tb = h->t_block;
     if (sum_traj) {
         MDX_HIP(hipStreamSynchronize(h->stream));
-        MDX_HIP(hipMemcpy(sum_traj, h->d_traj.ptr, size_t(8) * h->traj_len(), hipMemcpyDeviceToHost));
+        MDX_TRY(mdx_memcpy_d2h(h->dev, sum_traj, h->d_traj.ptr, size_t(8) * h->traj_len()));
     }
     if (!msd_self_sum && !acf_sum) {
         h->timer.collect();
@@ -1474,12 +1473,12 @@ int mdx_correlate(int dev, const double *a, const double *b, int64_t n_series, i
         for (int64_t s0 = 0; s0 < n_series; s0 += chunk) {
             const int64_t c = std::min(chunk, n_series - s0);
             const unsigned gp = (unsigned)ceil_div(c * n_fft, 256);
-            MDX_HIP(hipMemcpy(d_in.ptr, a + s0 * n_t, size_t(c) * n_t * 8, hipMemcpyHostToDevice));
+            MDX_TRY(mdx_memcpy_h2d(dev, d_in.ptr, a + s0 * n_t, size_t(c) * n_t * 8));
             hipLaunchKernelGGL(corr_pad_kernel, dim3(gp), dim3(256), 0, 0, d_in.as<double>(), c, n_t,
                                n_fft, d_pad.as<double>());
             MDX_TRY(fft.exec(0, c, d_pad.ptr, d_fa.ptr, nullptr));
             if (b) {
-                MDX_HIP(hipMemcpy(d_in.ptr, b + s0 * n_t, size_t(c) * n_t * 8, hipMemcpyHostToDevice));
+                MDX_TRY(mdx_memcpy_h2d(dev, d_in.ptr, b + s0 * n_t, size_t(c) * n_t * 8));
                 hipLaunchKernelGGL(corr_pad_kernel, dim3(gp), dim3(256), 0, 0, d_in.as<double>(), c,
                                    n_t, n_fft, d_pad.as<double>());
                 MDX_TRY(fft.exec(0, c, d_pad.ptr, d_fb.ptr, nullptr));
@@ -1488,8 +1487,7 @@ int mdx_correlate(int dev, const double *a, const double *b, int64_t n_series, i
                                0, 0, d_fa.as<double2>(), b ? d_fb.as<double2>() : nullptr, c * nc,
                                d_fa.as<double2>());
             MDX_TRY(fft.exec(1, c, d_fa.ptr, d_pad.ptr, nullptr));
-            MDX_HIP(hipDeviceSynchronize());
-            MDX_HIP(hipMemcpy(host.data(), d_pad.ptr, size_t(c) * n_fft * 8, hipMemcpyDeviceToHost));
+            MDX_TRY(mdx_memcpy_d2h(dev, host.data(), d_pad.ptr, size_t(c) * n_fft * 8));     // (waits for the device)
             const double inv_n = 1.0 / double(n_fft);
             for (int64_t s = 0; s < c; ++s) {
                 const double *r = host.data() + s * n_fft;
