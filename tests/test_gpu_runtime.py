@@ -38,15 +38,24 @@ def test_upload_and_strided_rows_round_trip(pinned):
 
 
 def test_a_range_registered_too_short_goes_through_the_ring():
-    """memory whose START is page-locked but whose end is not must not be handed to the DMA engine."""
-    h = np.arange(6 << 20, dtype=np.float32)           # 24 MB
+    """memory whose START is page-locked but whose end is not must not be handed to the DMA engine.
+    (A page-aligned buffer, whole pages registered; the registration ends before the buffer does.)"""
+    import mmap
+    n = 24 << 20
+    mm = mmap.mmap(-1, n)
+    h = np.frombuffer(mm, dtype=np.float32)
+    h[:] = np.arange(h.size, dtype=np.float32)
     check(lib().mdx_host_register(0, h.ctypes.data, 1 << 20))      # only the first MiB
     try:
         d = _core.DeviceArray.upload(h)
-        assert np.array_equal(d.to_host(), h)
+        got = d.to_host()
         d.free()
     finally:
+        _core.synchronize(0)
         check(lib().mdx_host_unregister(0, h.ctypes.data))
+    assert np.array_equal(got, h)
+    del h
+    mm.close()
 
 
 def test_block_cache_reuses_and_trims():
