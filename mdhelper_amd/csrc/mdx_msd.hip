@@ -385,7 +385,8 @@ static int msd_push_device(mdx_msd *h, int group, const double *d_pos, int64_t n
     const int64_t n_chunks = ceil_div(count, chunk);
     chunk = ceil_div(count, n_chunks);
     if (h->own_fft) {
-        const int64_t p_pad_max = ceil_div(ceil_div(chunk * 3 + 15, 2), msdfft::PG) * msdfft::PG;   // (+ 15: head)
+        const int64_t pmul = int64_t(msdfft::PG) * msdfft::pair_group_multiple(h->shape);
+        const int64_t p_pad_max = ceil_div(ceil_div(chunk * 3 + 15, 2), pmul) * pmul;   // (+ 15: head)
         MDX_TRY(h->d_spec.ensure(size_t(B) * h->n_fft * p_pad_max * 16));
         if (h->fused_sums)
             MDX_TRY(h->d_part.ensure(msdfft::fused_part_bytes(h->shape, (int)p_pad_max, B)));
@@ -414,7 +415,8 @@ static int msd_push_device(mdx_msd *h, int group, const double *d_pos, int64_t n
                                  ? int(((first + a0) * 3) % 16)
                                  : 0;
             const int64_t ne = c * 3 + head;
-            const int p_pad = (int)(ceil_div(ceil_div(ne, 2), msdfft::PG) * msdfft::PG);
+            const int64_t pmul = int64_t(msdfft::PG) * msdfft::pair_group_multiple(h->shape);
+            const int p_pad = (int)(ceil_div(ceil_div(ne, 2), pmul) * pmul);
             msdfft::launch(h->shape, h->stream, d_pos, n_total, first + a0, ne, h->t_block, B, zero_dims, p_pad,
                            tw_r1, tw_r2, twN, h->d_spec.as<double2>(), h->d_pfull.as<double>(), 0,
                            h->fused_sums ? h->d_part.as<double2>() : nullptr, h->traj(group), h->dsq(group), head);
@@ -945,8 +947,8 @@ int mdx_msd_create(mdx_msd_t *out, int dev, int64_t n_frames_block, int n_blocks
     // Any length >= 2 N_t - 1 gives the same linear correlation up to rounding.  The reference pads to
     // 2 * next_fast_len(N_t) (correlation.py:176-178).  Here:
     //   * blocks of more than 2 048 frames take the shortest length of the engine's own two-pass transform
-    //     (mdx_msd_fft.hpp) that covers 2 N_t: 2^13, 2^14, 25 600 = 400 x 64, 2^15, 2^16, 204 800 = 400 x 512,
-    //     2^18, 2^19, 2^20 (2^17 is served by 204 800 / 2^18).  It never materialises the padding and moves
+    //     (mdx_msd_fft.hpp) that covers 2 N_t: 2^13, 2^14, 25 600 = 400 x 64, 2^15, 51 200 = 400 x 128, 2^16,
+    //     102 400 = 400 x 256, 204 800 = 400 x 512, 2^18, 2^19, 2^20 (2^17 is served by 204 800 / 2^18).  It never materialises the padding and moves
     //     ~4.3 MB per series at 2^18 whatever N_t is, where the rocFFT pipeline moves ~17.7 MB;
     //   * everything else goes through rocFFT at the reference's length, or at the next power of two when that is
     //     at most 1.5 x longer (fewer rocFFT passes: measured 15 % faster end to end at N_t = 1e5).
@@ -958,11 +960,15 @@ int mdx_msd_create(mdx_msd_t *out, int dev, int64_t n_frames_block, int n_blocks
             p <<= 1;
         int64_t own_len = 0;
         if (!getenv("MDX_MSD_ROCFFT") && n_frames_block > 2048) {
-            own_len = p <= (int64_t(1) << 16) ? p : std::max<int64_t>(p, int64_t(1) << 18);
-            if (own_len == (int64_t(1) << 18) && 2 * n_frames_block <= 204800)
-                own_len = 204800;
-            if (own_len == (int64_t(1) << 15) && 2 * n_frames_block <= 25600)
-                own_len = 25600;
+            // the shortest own length that covers 2 N_t
+            static const int64_t lengths[] = {int64_t(1) << 13, int64_t(1) << 14, 25600, int64_t(1) << 15, 51200,
+                                              int64_t(1) << 16, 102400, 204800, int64_t(1) << 18, int64_t(1) << 19,
+                                              int64_t(1) << 20};
+            for (int64_t len : lengths)
+                if (len >= 2 * n_frames_block) {
+                    own_len = len;
+                    break;
+                }
         }
         if (own_len && msdfft::shape_for(own_len).r1)
             h->n_fft = own_len;

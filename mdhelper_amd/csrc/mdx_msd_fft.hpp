@@ -1219,6 +1219,110 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_rows64_power_kernel(
     }
 }
 
+// Pass B for 128- and 256-point rows (n_fft = 51 200 = 400 x 128 and 102 400 = 400 x 256: blocks of 12 801 .. 25 600
+// and 25 601 .. 51 200 frames, which the power-of-two shapes padded by up to 2 x and 204 800 points by up to 3 x).
+// The structure of msd_fft_rows512_power_kernel with a short first stage: a block streams 64 KB pieces of Y — now
+// NPG = 512 / R2 whole pair groups — and thread (pair p = tid & 7, j = tid >> 3) loads piece elements tid + 512 r:
+// pair group r / F, points j + 64 (r % F) with F = R2 / 64.  Those ARE the inputs of NPG radix-F butterflies of the
+// first Stockham stage (F = 2 or 4, no twiddles), done on the registers; stage 2 (radix 8, NS = F) runs in LDS, a
+// wave owning TPW = NPG transforms of its pair index side by side (R2 / 8 butterflies each: 64 lanes in all); stage 3
+// (radix 8, NS = R2 / 8) ends in registers: lane (c, l) of wave w holds X[l + (R2 / 8) r] of transform (w TPW + c) and adds
+// |X|^2 to eight running sums.
+template <int R1, int R2>
+__global__ __launch_bounds__(THREADS, 4) void msd_fft_rows_mid_power_kernel(
+    const double2 *__restrict__ Y, int p_pad, const double2 *__restrict__ tw_r2,
+    double *__restrict__ Pfull, int accumulate)
+{
+    static_assert(R2 == 128 || R2 == 256, "row lengths of this kernel");
+    constexpr int F = R2 / 64;              // first radix
+    constexpr int NPG = 512 / R2;            // pair groups per 64 KB piece
+    constexpr int NT = NPG * PG;             // transforms per piece
+    constexpr int TPW = NT / PG;             // transforms per wave (= NPG)
+    constexpr int T8 = R2 / 8;               // butterflies of a radix-8 stage
+    constexpr int ZS = R2 + 1;
+    __shared__ double2 zb[NT][ZS];
+    __shared__ double2 s_tw[R2 / 2];
+    const int k1 = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < R2 / 2; i += THREADS)
+        s_tw[i] = tw_r2[i];
+    const int n_all = p_pad / PG / NPG;      // pieces per (b, k1) row of Y (p_pad is a multiple of NPG pair groups)
+    const int n_parts = gridDim.z, part = blockIdx.z;
+    const int n_pieces = (n_all - part + n_parts - 1) / n_parts;      // pieces part, part + n_parts, ...
+    double *pout = Pfull + ((int64_t(part) * gridDim.y + b) * R1 + k1) * R2 + tid;
+    if (n_pieces <= 0) {
+        if (!accumulate && tid < R2)
+            *pout = 0.0;
+        return;
+    }
+    const int64_t g_stride = int64_t(n_parts) * (512 * PG);
+    const double2 *src = Y + ((int64_t(b) * R1 + k1) * n_all + part) * (512 * PG) + tid;
+    const int p = tid & 7, j = tid >> 3;
+    double2 v[8];
+    double acc[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        acc[r] = 0.0;
+        v[r] = src[THREADS * r];
+    }
+    __syncthreads();   // twiddle table
+    const int c = lane / T8, l = lane % T8;                 // stage 3: transform c of this wave, butterfly l
+    for (int pc = 0; pc < n_pieces; ++pc) {
+        // stage 1 on the loaded values: pair group g, butterfly j of pair p -> points F j + k
+#pragma unroll
+        for (int g = 0; g < NPG; ++g) {
+            double2 *z = &zb[g * PG + p][F * j];
+            if (F == 2) {
+                z[0] = cadd(v[2 * g], v[2 * g + 1]);
+                z[1] = csub(v[2 * g], v[2 * g + 1]);
+            } else {
+                double2 a[4] = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+                dft4(a);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    z[k] = a[k];
+            }
+        }
+        __syncthreads();
+        {   // the next piece is in flight during stages 2 and 3 (the last iteration reloads its own: no branch)
+            const int64_t off = int64_t(min(pc + 1, n_pieces - 1)) * g_stride;
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                v[r] = src[off + THREADS * r];
+        }
+        // wave w owns pair index w of every pair group of the piece: transforms g * PG + w.  They are not adjacent
+        // rows of zb, so the batch stage takes its stride between them: PG rows
+        stockham_stage_batch<R2, TPW, 8, F, false>(&zb[wave][0], PG * ZS, s_tw, lane, R2);
+        {   // stage 3 (NS = R2 / 8): butterfly l reads points l + T8 r, output r is X[l + T8 r]
+            const double2 *z = &zb[c * PG + wave][0];
+            double2 u[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                u[r] = z[l + T8 * r];
+                if (r)
+                    u[r] = cmul(u[r], tw_at<R2>(s_tw, r * l));
+            }
+            dft8(u);
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                acc[r] = fma(u[r].x, u[r].x, fma(u[r].y, u[r].y, acc[r]));
+        }
+        __syncthreads();
+    }
+    // the NT transforms' sums, added in a fixed order: red[transform][k2], k2 = l + T8 r
+    double *red = reinterpret_cast<double *>(&zb[0][0]);      // NT x R2 doubles = 32 KB
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        red[(c * PG + wave) * R2 + l + T8 * r] = acc[r];
+    __syncthreads();
+    if (tid < R2) {
+        double total = 0.0;
+        for (int t = 0; t < NT; ++t)
+            total += red[t * R2 + tid];
+        *pout = accumulate ? *pout + total : total;
+    }
+}
+
 // P[b][k] += sum over the parts of (Pfull[part][b][k] + Pfull[part][b][N - k]) / 2 for the half
 // spectrum k <= N/2, with Pfull stored as [k1][k2], k = k1 + R1 k2.
 __global__ __launch_bounds__(256) void msd_power_fold_kernel(const double *__restrict__ Pfull,
@@ -1259,6 +1363,10 @@ inline Shape shape_for(int64_t n_fft)
         s.r1 = 64, s.r2 = 1024;
     else if (n_fft == 25600)
         s.r1 = 400, s.r2 = 64;
+    else if (n_fft == 51200)
+        s.r1 = 400, s.r2 = 128;
+    else if (n_fft == 102400)
+        s.r1 = 400, s.r2 = 256;
     else if (n_fft == 204800)
         s.r1 = 400, s.r2 = 512;
     else if (n_fft == (int64_t(1) << 18))
@@ -1308,6 +1416,10 @@ inline int rows_parts(const Shape &sh, int n_blocks)
         return 1;
     return slots_split(base, 1, ROWS_PARTS_MAX);
 }
+
+// Pass B of the 128- and 256-point rows takes 64 KB pieces of 4 / 2 whole pair groups: the padded pair count of a
+// launch is a multiple of this many pair groups (the padding pairs are zeros and add nothing to the spectrum).
+inline int pair_group_multiple(const Shape &sh) { return (sh.r1 == 400 && (sh.r2 == 128 || sh.r2 == 256)) ? 512 / sh.r2 : 1; }
 
 // Shapes whose pass A carries the per-frame sums (x^2 and the coordinate sums of every frame) itself:
 // the caller then skips its own sums kernel and hands `part`, `traj`, `dsq` to launch().
@@ -1393,19 +1505,31 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
         // (twelve rounds of the chip's block slots: C4 with one block 27.1 -> 26.2 ms of kernels per step against the
         // four rounds of round 2 — blocks in more different phases share a CU, and the tail is a twelfth)
         const int fsplit = slots_split(int64_t(n_sg) * n_blocks, 8, std::min(64, sh.r2), 12);
-        if (sh.r2 == 64)
-            hipLaunchKernelGGL((msd_fft_cols400_fused_kernel<64>), dim3((unsigned)n_sg, (unsigned)fsplit, (unsigned)n_blocks),
-                               dim3(THREADS), 0, stream, pos, n_total, first, n_elem, t_block, zero_dims, p_pad,
-                               tw_r1, twN, Y, part, head);
-        else
-            hipLaunchKernelGGL((msd_fft_cols400_fused_kernel<512>), dim3((unsigned)n_sg, (unsigned)fsplit, (unsigned)n_blocks),
-                               dim3(THREADS), 0, stream, pos, n_total, first, n_elem, t_block, zero_dims, p_pad,
-                               tw_r1, twN, Y, part, head);
+#define MDX_MSDFFT_COLS400(R2_)                                                                                       \
+    hipLaunchKernelGGL((msd_fft_cols400_fused_kernel<R2_>), dim3((unsigned)n_sg, (unsigned)fsplit, (unsigned)n_blocks), \
+                       dim3(THREADS), 0, stream, pos, n_total, first, n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y, \
+                       part, head)
+        if (sh.r2 == 64) {
+            MDX_MSDFFT_COLS400(64);
+        } else if (sh.r2 == 128) {
+            MDX_MSDFFT_COLS400(128);
+        } else if (sh.r2 == 256) {
+            MDX_MSDFFT_COLS400(256);
+        } else {
+            MDX_MSDFFT_COLS400(512);
+        }
+#undef MDX_MSDFFT_COLS400
         hipLaunchKernelGGL(msd_partials_reduce_kernel,
                            dim3((unsigned)((int64_t(sh.r2) * SUMS_ROWS + 255) / 256), (unsigned)n_blocks), dim3(256), 0,
                            stream, part, n_sg, sh.r2, 1, SUMS_ROWS, t_block, traj, dsq);
         if (sh.r2 == 64)
             hipLaunchKernelGGL((msd_fft_rows64_power_kernel<400>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,
+                               Pfull, accumulate);
+        else if (sh.r2 == 128)
+            hipLaunchKernelGGL((msd_fft_rows_mid_power_kernel<400, 128>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,
+                               Pfull, accumulate);
+        else if (sh.r2 == 256)
+            hipLaunchKernelGGL((msd_fft_rows_mid_power_kernel<400, 256>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,
                                Pfull, accumulate);
         else
             hipLaunchKernelGGL((msd_fft_rows512_power_kernel<400>), gb, dim3(THREADS), 0, stream, Y, p_pad,

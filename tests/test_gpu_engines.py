@@ -545,12 +545,15 @@ def test_rdf_mixed_orthorhombic_and_triclinic_frames_in_one_batch():
                                   (100000, 1, 29, 0), (102400, 1, 8, 3), (102401, 1, 8, 0), (32769, 3, 17, 0),
                                   # 25 600 = 400 x 64 points: blocks of 8 193 .. 12 800 frames
                                   (12800, 2, 19, 0), (12801, 2, 19, 0), (9000, 11, 37, 6), (12500, 8, 16, 1),
+                                  # 51 200 = 400 x 128 and 102 400 = 400 x 256 points: 16 385 .. 25 600 and 32 769 .. 51 200
+                                  (25600, 1, 21, 0), (25601, 1, 9, 3), (20000, 3, 43, 0), (16385, 2, 32, 4),
+                                  (51200, 1, 11, 0), (51201, 1, 7, 0), (45000, 2, 29, 5), (32769, 1, 64, 0),
                                   # rows of whole 128-byte lines (16 | 3 n_atoms): the second push starts 9
                                   # coordinates into a line and pass A enters its chunk early (head)
                                   (70001, 1, 16, 0), (40000, 2, 32, 5), (50000, 1, 48, 2)])
 def test_msd_own_two_pass_transform_equals_rocfft(case, monkeypatch):
-    """n_fft = 2^13, 2^14, 25 600, 2^15, 2^16, 204 800, 2^18, 2^19, 2^20: the engine's own packed two-pass
-    transforms against the rocFFT pipeline."""
+    """n_fft = 2^13, 2^14, 25 600, 2^15, 51 200, 2^16, 102 400, 204 800, 2^18, 2^19, 2^20: the engine's own packed
+    two-pass transforms against the rocFFT pipeline."""
     t_block, n_blocks, n_atoms, zero_dims = case
     rng = np.random.default_rng(7)
     T = t_block * n_blocks
@@ -563,8 +566,8 @@ def test_msd_own_two_pass_transform_equals_rocfft(case, monkeypatch):
             monkeypatch.delenv("MDX_MSD_ROCFFT", raising=False)
         eng = _core.MsdEngine(t_block, n_blocks, 2)
         want = (8192 if t_block <= 4096 else 16384 if t_block <= 8192 else 25600 if t_block <= 12800
-                else 32768 if t_block <= 16384
-                else 65536 if t_block <= 32768 else 204800 if t_block <= 102400
+                else 32768 if t_block <= 16384 else 51200 if t_block <= 25600
+                else 65536 if t_block <= 32768 else 102400 if t_block <= 51200 else 204800 if t_block <= 102400
                 else 262144 if t_block <= 131072
                 else 524288 if t_block <= 262144 else 1048576)
         assert mode != "own" or eng.n_fft == want     # rocFFT runs its own choice of length
