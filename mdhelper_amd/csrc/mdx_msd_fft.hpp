@@ -1142,20 +1142,41 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_rows512_power_kernel(
     *pout = accumulate ? *pout + total : total;
 }
 
-// Pass B for 64-point rows (n_fft = 25 600 = 400 x 64: blocks of 8 193 .. 12 800 frames — C4 with eight blocks, whose
-// half-transformed block is then as large as with one block; padded to 2^15 it was 28 % larger).
-// A (k1, pair group) run of Y is 64 n2 x 8 pairs = 8 KB, eight consecutive pair groups are 64 KB contiguous.  Wave g of
+// Pass B for 16-, 32- and 64-point rows (n_fft = 6 400 = 400 x 16, 12 800 = 400 x 32, 25 600 = 400 x 64: blocks of
+// 2 049 .. 3 200, 4 097 .. 6 400 and 8 193 .. 12 800 frames — C4 with eight blocks is the last, whose half-transformed
+// block is then as large as with one block; padded to 2^15 it was 28 % larger).
+// A (k1, pair group) run of Y is R2 n2 x 8 pairs = R2 x 128 B, consecutive pair groups are contiguous.  Wave g of
 // a block streams pair groups g, g + 8, ... of the block's share on its own: lane (pair p = lane & 7, j = lane >> 3)
-// loads n2 = j + 8 r, r < 8 — a wave instruction reads 1 KB contiguous, and the eight values ARE butterfly j of the
-// first radix-8 stage.  Stage 1 on those registers, outputs times W_64^(j ka) (seven per-thread constants) into the
-// wave's own 8 x 64 slots, stage 2 back into registers: lane (p, ka) holds X[ka + 8 kb] of pair p and adds |X|^2 to
-// eight running sums.  Nothing in the loop is shared between waves: no block barrier until the sums meet at the end.
-template <int R1>
-__global__ __launch_bounds__(THREADS, 4) void msd_fft_rows64_power_kernel(
+// loads n2 = j + 8 r, r < F = R2 / 8 — a wave instruction reads 1 KB contiguous, and the F values ARE butterfly j of the
+// first radix-F stage.  Stage 1 on those registers, outputs times W_R2^(j ka) (F - 1 per-thread constants) into the
+// wave's own 8 x R2 slots, stage 2 (radix 8; lanes j < F) back into registers: lane (p, ka) holds X[ka + F kb] of pair
+// p and adds |X|^2 to eight running sums.  Nothing in the loop is shared between waves: no block barrier until the
+// sums meet at the end.
+template <int F> __device__ __forceinline__ void dft_first(double2 *a)
+{
+    if constexpr (F == 8) {
+        dft8(a);
+    } else if constexpr (F == 4) {
+        const double2 t0 = cadd(a[0], a[2]), t1 = csub(a[0], a[2]);
+        const double2 t2 = cadd(a[1], a[3]), t3 = mul_mi(csub(a[1], a[3]));
+        a[0] = cadd(t0, t2);
+        a[1] = cadd(t1, t3);
+        a[2] = csub(t0, t2);
+        a[3] = csub(t1, t3);
+    } else {
+        const double2 t0 = cadd(a[0], a[1]), t1 = csub(a[0], a[1]);
+        a[0] = t0;
+        a[1] = t1;
+    }
+}
+
+template <int R1, int R2>
+__global__ __launch_bounds__(THREADS, 4) void msd_fft_rows_short_power_kernel(
     const double2 *__restrict__ Y, int p_pad, const double2 *__restrict__ tw_r2,
     double *__restrict__ Pfull, int accumulate)
 {
-    constexpr int R2 = 64, ZS = R2 + 1;
+    static_assert(R2 == 16 || R2 == 32 || R2 == 64, "row lengths of this kernel");
+    constexpr int F = R2 / 8, ZS = R2 + 1;
     __shared__ double2 zb[PG][PG][ZS];            // [wave][pair][point]
     const int k1 = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1164,10 +1185,10 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_rows64_power_kernel(
     double *pout = Pfull + ((int64_t(part) * gridDim.y + b) * R1 + k1) * R2 + tid;
     const int n_mine = (n_groups - wave + PG - 1) / PG;               // ... of which this wave takes wave, wave + 8, ...
     const int p = lane & 7, j = lane >> 3;
-    // W_64^(j r), r = 1 .. 7, from the half table exp(-2 pi i m / 64), m < 32
-    double2 w[8];
+    // W_R2^(j r), r = 1 .. F - 1, from the half table exp(-2 pi i m / R2), m < R2 / 2
+    double2 w[F];
 #pragma unroll
-    for (int r = 1; r < 8; ++r)
+    for (int r = 1; r < F; ++r)
         w[r] = tw_at<R2>(tw_r2, j * r);
     double acc[8];
 #pragma unroll
@@ -1176,40 +1197,44 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_rows64_power_kernel(
     if (n_mine > 0) {
         const int64_t g_stride = int64_t(n_parts) * PG * (R2 * PG);     // this wave's next pair group
         const double2 *src = Y + ((int64_t(b) * R1 + k1) * n_all + part + int64_t(wave) * n_parts) * (R2 * PG) + lane;
-        double2 v[8];
+        double2 v[F];
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
+        for (int r = 0; r < F; ++r)
             v[r] = src[64 * r];
         double2 *z = &zb[wave][p][0];
         for (int it = 0; it < n_mine; ++it) {
-            dft8(v);
+            dft_first<F>(v);
 #pragma unroll
-            for (int r = 0; r < 8; ++r)
+            for (int r = 0; r < F; ++r)
                 z[8 * r + j] = r ? cmul(v[r], w[r]) : v[r];
             {   // the next pair group is in flight during stage 2 (the last iteration reloads its own: no branch)
                 const int64_t off = int64_t(min(it + 1, n_mine - 1)) * g_stride;
 #pragma unroll
-                for (int r = 0; r < 8; ++r)
+                for (int r = 0; r < F; ++r)
                     v[r] = src[off + 64 * r];
             }
             wave_lds_fence();
-            double2 u[8];
+            if (F == 8 || j < F) {
+                double2 u[8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r)
-                u[r] = z[8 * j + r];        // lane (p, ka = j): the eight first-stage outputs ka of butterflies r
-            dft8(u);
+                for (int r = 0; r < 8; ++r)
+                    u[r] = z[8 * j + r];        // lane (p, ka = j): the eight first-stage outputs ka of butterflies r
+                dft8(u);
 #pragma unroll
-            for (int r = 0; r < 8; ++r)
-                acc[r] = fma(u[r].x, u[r].x, fma(u[r].y, u[r].y, acc[r]));
+                for (int r = 0; r < 8; ++r)
+                    acc[r] = fma(u[r].x, u[r].x, fma(u[r].y, u[r].y, acc[r]));
+            }
             wave_lds_fence();
         }
     }
-    // the sums of the 8 waves x 8 pairs, added in a fixed order: red[wave * 8 + pair][k2], k2 = ka + 8 kb
+    // the sums of the 8 waves x 8 pairs, added in a fixed order: red[wave * 8 + pair][k2], k2 = ka + F kb
     __syncthreads();
-    double *red = reinterpret_cast<double *>(&zb[0][0][0]);      // 64 x 64 doubles
+    double *red = reinterpret_cast<double *>(&zb[0][0][0]);      // 64 x R2 doubles
+    if (F == 8 || j < F) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r)
-        red[(wave * PG + p) * R2 + j + 8 * r] = acc[r];
+        for (int r = 0; r < 8; ++r)
+            red[(wave * PG + p) * R2 + j + F * r] = acc[r];
+    }
     __syncthreads();
     if (tid < R2) {
         double total = 0.0;
@@ -1361,6 +1386,10 @@ inline Shape shape_for(int64_t n_fft)
         s.r1 = 64, s.r2 = 512;
     else if (n_fft == (int64_t(1) << 16))
         s.r1 = 64, s.r2 = 1024;
+    else if (n_fft == 6400)
+        s.r1 = 400, s.r2 = 16;
+    else if (n_fft == 12800)
+        s.r1 = 400, s.r2 = 32;
     else if (n_fft == 25600)
         s.r1 = 400, s.r2 = 64;
     else if (n_fft == 51200)
@@ -1509,7 +1538,11 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
     hipLaunchKernelGGL((msd_fft_cols400_fused_kernel<R2_>), dim3((unsigned)n_sg, (unsigned)fsplit, (unsigned)n_blocks), \
                        dim3(THREADS), 0, stream, pos, n_total, first, n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y, \
                        part, head)
-        if (sh.r2 == 64) {
+        if (sh.r2 == 16) {
+            MDX_MSDFFT_COLS400(16);
+        } else if (sh.r2 == 32) {
+            MDX_MSDFFT_COLS400(32);
+        } else if (sh.r2 == 64) {
             MDX_MSDFFT_COLS400(64);
         } else if (sh.r2 == 128) {
             MDX_MSDFFT_COLS400(128);
@@ -1522,8 +1555,14 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
         hipLaunchKernelGGL(msd_partials_reduce_kernel,
                            dim3((unsigned)((int64_t(sh.r2) * SUMS_ROWS + 255) / 256), (unsigned)n_blocks), dim3(256), 0,
                            stream, part, n_sg, sh.r2, 1, SUMS_ROWS, t_block, traj, dsq);
-        if (sh.r2 == 64)
-            hipLaunchKernelGGL((msd_fft_rows64_power_kernel<400>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,
+        if (sh.r2 == 16)
+            hipLaunchKernelGGL((msd_fft_rows_short_power_kernel<400, 16>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,
+                               Pfull, accumulate);
+        else if (sh.r2 == 32)
+            hipLaunchKernelGGL((msd_fft_rows_short_power_kernel<400, 32>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,
+                               Pfull, accumulate);
+        else if (sh.r2 == 64)
+            hipLaunchKernelGGL((msd_fft_rows_short_power_kernel<400, 64>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,
                                Pfull, accumulate);
         else if (sh.r2 == 128)
             hipLaunchKernelGGL((msd_fft_rows_mid_power_kernel<400, 128>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,
