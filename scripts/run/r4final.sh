@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-4 bench lines for profiles/ (run on the GPU box through gpurun).
 out=gpurun_out/r4final; mkdir -p $out
-run() { name=$1; shift; t0=$(date +%s.%N); python bench.py "$@" > $out/$name.json 2> $out/$name.err; echo "$name: $(echo "$(date +%s.%N) - $t0" | bc) s wall"; }
+run() { name=$1; shift; t0=$SECONDS; python bench.py "$@" > $out/$name.json 2> $out/$name.err; echo "$name: $((SECONDS - t0)) s wall"; }
 run bench_final
 run bench_c5size --atoms 131072 --frames 500 --steps 3 --no-extras --cpu-seconds 3
 run bench_c1like --workload rdf_wide --atoms 1000 --frames 20000 --steps 3 --no-extras --cpu-seconds 3
