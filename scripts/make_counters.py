@@ -331,6 +331,14 @@ def main():
     if "msd_tcc" in which:
         msd_tcc("msd_c4")
         msd_tcc("msd_c4_b8", blocks=8)
+    if "stats_msd" in which:
+        # the MSD lines alone (after a change to the transforms), plus one block count for each new row kernel
+        run_stats("msd_c4", ["--workload", "msd", "--steps", "3", "--no-cpu-baseline", "--no-onsager"])
+        run_stats("msd_c4_b8", ["--workload", "msd", "--blocks", "8", "--steps", "3", "--no-cpu-baseline", "--no-onsager"])
+        run_stats("msd_c4_b2", ["--workload", "msd", "--blocks", "2", "--steps", "3", "--no-cpu-baseline", "--no-onsager"])
+        run_stats("msd_c4_b4", ["--workload", "msd", "--blocks", "4", "--steps", "3", "--no-cpu-baseline", "--no-onsager"])
+        run_stats("msd_c4_b16", ["--workload", "msd", "--blocks", "16", "--steps", "3", "--no-cpu-baseline", "--no-onsager"])
+        run_stats("msd_c4_b32", ["--workload", "msd", "--blocks", "32", "--steps", "3", "--no-cpu-baseline", "--no-onsager"])
     if "stats" in which:
         # the default command itself (what the driver runs): its kernel averages must agree with the line's own
         run_stats("bench_default", ["--no-extras", "--cpu-seconds", "2"])
