@@ -875,7 +875,7 @@ def bench_msd(args, world):
                      "traffic": ctr.get("hbm_bytes_per_step") if ctr else None,
                      "traffic_source": ctr.get("traffic_source") if ctr else None,
                      "kernel": "msd pipeline of one step: forward transforms with the per-frame sums fused in + "
-                               "power (msd_fft_cols/rows_power kernels for n_fft = 2^13..2^16, 204800, "
+                               "power (msd_fft_cols/rows_power kernels for n_fft = 400 x 16..512, 2^13..2^16, "
                                "2^18..2^20, else gather + rocFFT R2C + power)",
                      # what the memory system actually carries: the counters' bytes of a step over the kernels' time
                      # (the half-transformed block is written and read once: 5.2 x the algorithmic bytes)
