@@ -67,6 +67,19 @@ def run_stats(tag, bench_args):
     for path in glob.glob(f"{d}/**/*kernel_stats.csv", recursive=True):
         with open(path) as src, open(os.path.join(OUT, f"{tag}_kernel_stats.csv"), "w") as dst:
             dst.write(src.read())
+    # the profiler's averages take in the cold first launch and the one step during which it flushes its buffers
+    # (a step of twice the time in every profiled run): medians of the same trace beside them
+    import statistics
+    per = collections.defaultdict(list)
+    for path in glob.glob(f"{d}/**/*kernel_trace.csv", recursive=True):
+        with open(path) as fh:
+            for row in csv.DictReader(fh):
+                per[row["Kernel_Name"]].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+    with open(os.path.join(OUT, f"{tag}_kernel_medians.csv"), "w") as fh:
+        fh.write("kernel,calls,median_ns,min_ns,mean_ns,max_ns\n")
+        for k in sorted(per, key=lambda k: -sum(per[k])):
+            v = per[k]
+            fh.write(f"\"{k[:110]}\",{len(v)},{statistics.median(v):.0f},{min(v):.0f},{sum(v) / len(v):.0f},{max(v):.0f}\n")
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
     with open(os.path.join(OUT, f"{tag}_bench_under_rocprof.json"), "w") as fh:
         fh.write(line + "\n")
@@ -333,12 +346,12 @@ def main():
         msd_tcc("msd_c4_b8", blocks=8)
     if "stats_msd" in which:
         # the MSD lines alone (after a change to the transforms), plus one block count for each new row kernel
-        run_stats("msd_c4", ["--workload", "msd", "--steps", "3", "--no-cpu-baseline", "--no-onsager"])
-        run_stats("msd_c4_b8", ["--workload", "msd", "--blocks", "8", "--steps", "3", "--no-cpu-baseline", "--no-onsager"])
-        run_stats("msd_c4_b2", ["--workload", "msd", "--blocks", "2", "--steps", "3", "--no-cpu-baseline", "--no-onsager"])
-        run_stats("msd_c4_b4", ["--workload", "msd", "--blocks", "4", "--steps", "3", "--no-cpu-baseline", "--no-onsager"])
-        run_stats("msd_c4_b16", ["--workload", "msd", "--blocks", "16", "--steps", "3", "--no-cpu-baseline", "--no-onsager"])
-        run_stats("msd_c4_b32", ["--workload", "msd", "--blocks", "32", "--steps", "3", "--no-cpu-baseline", "--no-onsager"])
+        run_stats("msd_c4", ["--workload", "msd", "--steps", "6", "--warmup", "3", "--no-cpu-baseline", "--no-onsager"])
+        run_stats("msd_c4_b8", ["--workload", "msd", "--blocks", "8", "--steps", "6", "--warmup", "3", "--no-cpu-baseline", "--no-onsager"])
+        run_stats("msd_c4_b2", ["--workload", "msd", "--blocks", "2", "--steps", "6", "--warmup", "3", "--no-cpu-baseline", "--no-onsager"])
+        run_stats("msd_c4_b4", ["--workload", "msd", "--blocks", "4", "--steps", "6", "--warmup", "3", "--no-cpu-baseline", "--no-onsager"])
+        run_stats("msd_c4_b16", ["--workload", "msd", "--blocks", "16", "--steps", "6", "--warmup", "3", "--no-cpu-baseline", "--no-onsager"])
+        run_stats("msd_c4_b32", ["--workload", "msd", "--blocks", "32", "--steps", "6", "--warmup", "3", "--no-cpu-baseline", "--no-onsager"])
     if "stats" in which:
         # the default command itself (what the driver runs): its kernel averages must agree with the line's own
         run_stats("bench_default", ["--no-extras", "--cpu-seconds", "2"])
@@ -347,8 +360,8 @@ def main():
         run_stats("rdf_c5", ["--atoms", "131072", "--frames", "500", "--steps", "2", "--no-cpu-baseline", "--no-extras"])
         run_stats("rdf_c1", ["--workload", "rdf_wide", "--atoms", "1000", "--frames", "20000", "--steps", "2",
                              "--no-cpu-baseline", "--no-extras"])
-        run_stats("msd_c4", ["--workload", "msd", "--steps", "3", "--no-cpu-baseline", "--no-onsager"])
-        run_stats("msd_c4_b8", ["--workload", "msd", "--blocks", "8", "--steps", "3", "--no-cpu-baseline", "--no-onsager"])
+        run_stats("msd_c4", ["--workload", "msd", "--steps", "6", "--warmup", "3", "--no-cpu-baseline", "--no-onsager"])
+        run_stats("msd_c4_b8", ["--workload", "msd", "--blocks", "8", "--steps", "6", "--warmup", "3", "--no-cpu-baseline", "--no-onsager"])
         run_stats("sq_c3", ["--workload", "sq", "--steps", "5", "--no-cpu-baseline", "--no-ingest"])
         run_stats("sq_default_grid", ["--workload", "sq", "--n-points", "32", "--frames", "200", "--steps", "3",
                                       "--no-cpu-baseline", "--no-ingest"])

@@ -61,6 +61,65 @@ __global__ __launch_bounds__(512) void k_load(const double2 *__restrict__ X, int
     if (acc == 1.2345e300) sink[0] = acc;
 }
 
+// HALF variants (what 256-thread blocks of four pairs would do): a block owns pairs 4 h .. 4 h + 3 of the pair groups of its
+// super group, a wave instruction touches 16 lines with 64 bytes each.  SAME_XCD: the two halves are blocks i and i + 8
+// (one XCD, round-robin dispatch), else neighbours i, i + 1 (two XCDs).
+template <bool SAME_XCD>
+__global__ __launch_bounds__(256) void k_store_half(double2 *__restrict__ Y, int n_pg, int cols_per_block)
+{
+    const int bx = blockIdx.x;
+    const int half = SAME_XCD ? (bx >> 3) & 1 : bx & 1;
+    const int sg = SAME_XCD ? ((bx >> 4) << 3) + (bx & 7) : bx >> 1;
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.y * cols_per_block;
+    if (sg * 8 >= n_pg) return;
+    for (int n2 = c0; n2 < c0 + cols_per_block && n2 < 512; ++n2)
+        for (int q = 0; q < 8; ++q) {
+            const int pg = sg * 8 + q;
+            if (pg >= n_pg) break;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                const int k1 = (tid >> 2) + 64 * i;
+                const int p = 4 * half + (tid & 3);
+                if (k1 < 400) {
+                    const int64_t line = (int64_t(k1) * n_pg + pg) * 512 + n2;
+                    Y[line * 8 + p] = make_double2(double(k1), double(n2));
+                }
+            }
+        }
+}
+
+template <bool SAME_XCD>
+__global__ __launch_bounds__(256) void k_load_half(const double2 *__restrict__ X, int64_t row_pairs, int n_pg,
+                                                   int cols_per_block, double *__restrict__ sink)
+{
+    const int bx = blockIdx.x;
+    const int half = SAME_XCD ? (bx >> 3) & 1 : bx & 1;
+    const int sg = SAME_XCD ? ((bx >> 4) << 3) + (bx & 7) : bx >> 1;
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.y * cols_per_block;
+    if (sg * 8 >= n_pg) return;
+    double acc = 0.0;
+    for (int n2 = c0; n2 < c0 + cols_per_block && n2 < 512; ++n2)
+        for (int q = 0; q < 8; ++q) {
+            const int pg = sg * 8 + q;
+            if (pg >= n_pg) break;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = (tid >> 2) + 64 * i;
+                const int p = 4 * half + (tid & 3);
+                if (row < 200) {
+                    const int64_t t = int64_t(row) * 512 + n2;
+                    if (t < 100000) {
+                        const double2 v = X[t * row_pairs + int64_t(pg) * 8 + p];
+                        acc += v.x + v.y;
+                    }
+                }
+            }
+        }
+    if (acc == 1.2345e300) sink[0] = acc;
+}
+
 int main()
 {
     const int n_pg = 938;
@@ -100,6 +159,12 @@ int main()
     const size_t rbytes = size_t(100000) * n_pg * 128;
     timeit("loads, whole rows per instruction (today)", [&] { k_load<false><<<grid, 512>>>(X, row_pairs, n_pg, cpb, sink); }, rbytes);
     timeit("loads, 16-byte pieces per wave", [&] { k_load<true><<<grid, 512>>>(X, row_pairs, n_pg, cpb, sink); }, rbytes);
+    const int n_sg16 = (n_sg + 7) / 8 * 8;     // whole groups of 16 blocks for the SAME_XCD numbering
+    dim3 gridh(2 * n_sg16, split);
+    timeit("stores, 64-byte pieces, halves on two XCDs", [&] { k_store_half<false><<<gridh, 256>>>(Y, n_pg, cpb); }, ybytes);
+    timeit("stores, 64-byte pieces, halves on one XCD", [&] { k_store_half<true><<<gridh, 256>>>(Y, n_pg, cpb); }, ybytes);
+    timeit("loads, 64-byte pieces, halves on two XCDs", [&] { k_load_half<false><<<gridh, 256>>>(X, row_pairs, n_pg, cpb, sink); }, rbytes);
+    timeit("loads, 64-byte pieces, halves on one XCD", [&] { k_load_half<true><<<gridh, 256>>>(X, row_pairs, n_pg, cpb, sink); }, rbytes);
     hipFree(Y);
     hipFree(X);
     return 0;
