@@ -344,7 +344,7 @@ struct mdx_msd {
     std::vector<int> images0;                       // initial image flags [n_sel][3] of the next unwrapped pushes
     double mol_mass = 0.0;                          // total mass of the grouping's molecules
     DeviceBuffer d_mol_offsets, d_mol_masses, d_mol_total, d_mol_com;
-    bool own_fft = false;                           // n_fft = 2^15, 2^16, 2^18..2^20: mdx_msd_fft.hpp
+    bool own_fft = false;                           // n_fft is one of the shapes of mdx_msd_fft.hpp
     bool fused_sums = false;                        // pass A of this shape also forms the per-frame sums
     DeviceBuffer d_part;                            // its partial-sum records
     msdfft::Shape shape;
@@ -983,8 +983,7 @@ int mdx_msd_create(mdx_msd_t *out, int dev, int64_t n_frames_block, int n_blocks
         h->timer.stream = h->stream;
         if ((rc = h->d_acc.ensure(size_t(8) * h->acc_len())) != MDX_OK) break;
         if ((rc = h->d_traj.ensure(size_t(8) * h->traj_len())) != MDX_OK) break;
-        // forward transforms of length 2^18 run through the engine's own two-pass kernels
-        // (MDX_MSD_ROCFFT=1 keeps rocFFT for them too)
+        // the shapes of mdx_msd_fft.hpp run through the engine's own two-pass kernels (MDX_MSD_ROCFFT=1: rocFFT)
         h->shape = msdfft::shape_for(h->n_fft);
         h->own_fft = h->shape.r1 != 0 && !getenv("MDX_MSD_ROCFFT");
         h->fused_sums = h->own_fft && msdfft::fuses_sums(h->shape);

@@ -1,4 +1,5 @@
-// mdx_msd_fft.hpp — the MSD engine's own forward transforms for n_fft = 2^13 .. 2^16, 2^18, 2^19, 2^20.
+// mdx_msd_fft.hpp — the MSD engine's own forward transforms for n_fft = 400 x R2 (R2 = 16 .. 512: 6 400 .. 204 800),
+// 2^13 .. 2^16, 2^18, 2^19, 2^20.
 //
 // The power spectrum sum_series |F_k|^2 of ~30 000 zero-padded real series of 10^5 points is
 // HBM traffic, not arithmetic.  Through rocFFT the pipeline moves ~17.7 MB per series at 2^18
@@ -20,8 +21,11 @@
 //
 // One wave owns one transform (radix-8 Stockham stages, a radix-16 last stage for 1024 points,
 // in place in a wave-private LDS buffer; a wave's LDS operations execute in order, so there is
-// no barrier inside a transform).  Shapes: 2^13 = 16 x 512, 2^14 = 16 x 1024, 2^15 = 64 x 512,
-// 2^16 = 64 x 1024 (32 or 8 short column transforms per wave at a time), 2^18 = 512 x 512, 2^19 = 1024 x 512, 2^20 = 1024 x 1024.
+// no barrier inside a transform).  Shapes: 400 x R2 — pass A msd_fft_cols400_fused_kernel<R2> (in-place DIF stages
+// 10, 10, 4 of the 400-point columns, the per-frame sums fused in), pass B msd_fft_rows_short_power_kernel (R2 = 16,
+// 32, 64), msd_fft_rows_mid_power_kernel (128, 256), msd_fft_rows512_power_kernel (512) —, 2^13 = 16 x 512,
+// 2^14 = 16 x 1024, 2^15 = 64 x 512, 2^16 = 64 x 1024 (32 or 8 short column transforms per wave at a time),
+// 2^18 = 512 x 512, 2^19 = 1024 x 512, 2^20 = 1024 x 1024.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -238,55 +242,6 @@ __device__ __forceinline__ void dft4(double2 *a)
     a[3] = csub(t1, t3);
 }
 
-// One in-place Stockham stage for lengths that are not powers of two (M = 400 = 4 x 4 x 5 x 5):
-// M / RADIX butterflies dealt to the lanes in rounds, full twiddle table tw[m] = exp(-2 pi i m / M).
-template <int M, int RADIX, int NS, bool FIRST>
-__device__ __forceinline__ void stockham_stage_mixed(double2 *z, const double2 *tw, int lane, int n_live)
-{
-    constexpr int T = M / RADIX;             // butterflies
-    constexpr int PER = (T + 63) / 64;       // rounds
-    double2 v[PER][RADIX];
-#pragma unroll
-    for (int p = 0; p < PER; ++p) {
-        const int j = lane + 64 * p;
-        if (j < T) {
-            // k = j mod NS without a division where NS is a power of two or covers every j
-            const int k = NS >= T ? j : (NS & (NS - 1)) == 0 ? (j & (NS - 1)) : j % NS;
-            constexpr int STEP = M / (RADIX * NS);
-            constexpr bool WRAPS = (RADIX - 1) * (NS - 1) * STEP >= M;    // exponent can pass M
-#pragma unroll
-            for (int r = 0; r < RADIX; ++r) {
-                const int idx = j + r * T;
-                // first stage: rows >= M / 2 are structurally zero (the zero padding), which is
-                // r >= RADIX / 2 for every butterfly — known at compile time, so the arithmetic
-                // on them folds away
-                v[p][r] = (!FIRST || r < RADIX / 2) ? z[idx] : make_double2(0.0, 0.0);
-                if (NS > 1 && r)   // W_(RADIX NS)^(r k)
-                    v[p][r] = cmul(v[p][r], tw[WRAPS ? (r * k * STEP) % M : r * k * STEP]);
-            }
-            if (RADIX == 5)
-                dft5(v[p]);
-            else if (RADIX == 4)
-                dft4(v[p]);
-            else
-                dft16(v[p]);
-        }
-    }
-    wave_lds_fence();
-#pragma unroll
-    for (int p = 0; p < PER; ++p) {
-        const int j = lane + 64 * p;
-        if (j < T) {
-            const int k = NS >= T ? j : (NS & (NS - 1)) == 0 ? (j & (NS - 1)) : j % NS;
-            const int j0 = (j - k) * RADIX + k;
-#pragma unroll
-            for (int r = 0; r < RADIX; ++r)
-                z[j0 + r * NS] = v[p][r];
-        }
-    }
-    wave_lds_fence();
-}
-
 // One in-place decimation-in-frequency stage of an M-point transform held by one wave: sub-transforms
 // of length MS, radix RADIX.  Butterfly (block, t) reads z[base + t + r MS/RADIX], forms the
 // RADIX-point transform, multiplies output k by W_MS^(t k) and writes it back to THE SAME slot
@@ -426,88 +381,12 @@ __global__ __launch_bounds__(THREADS, R1 == 512 ? 4 : 2) void msd_fft_cols_kerne
 #undef MDX_COLS_LOAD
 }
 
-// Pass A for R1 = 400 = 4 x 4 x 5 x 5 (n_fft = 204 800 = 400 x 512: blocks of 32 769 .. 102 400 frames,
-// C4's 100 000 among them — 22 % less of the half-transformed block than 2^18).  As
-// msd_fft_cols_kernel, with guarded row / line loops (200 live rows, 400 lines are not multiples
-// of the 32 / 64 a thread steps by) and the full twiddle table of the 400-point transform.
-template <int R2>
-__global__ __launch_bounds__(THREADS, 4) void msd_fft_cols400_kernel(
-    const double *__restrict__ pos, int64_t n_total, int64_t first, int64_t n_elem, int64_t t_block,
-    int zero_dims, int p_pad, const double2 *__restrict__ tw_r1, const double2 *__restrict__ twN,
-    double2 *__restrict__ Y)
-{
-    constexpr int R1 = 400, ZS = R1 + 1, LIVE = R1 / 2;
-    constexpr int LOADS = (LIVE + 31) / 32;     // 7 row rounds
-    constexpr int OUTS = (R1 + 63) / 64;        // 7 line rounds
-    __shared__ double2 zb[PG][ZS];
-    __shared__ double2 s_h[R1];       // exp(-2 pi i m / 400), m < 400
-    __shared__ double2 s_n[R2];       // exp(-2 pi i m / N),  m < R2
-    const int pg = blockIdx.x, b = blockIdx.z;
-    const int n2_count = R2 / int(gridDim.y);
-    const int n2_begin = blockIdx.y * n2_count;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < R1; i += THREADS)
-        s_h[i] = tw_r1[i];
-    for (int i = tid; i < R2; i += THREADS)
-        s_n[i] = twN[i];
-
-    const int s = tid & 15, row0 = tid >> 4;
-    const int64_t e = int64_t(pg) * 16 + s;
-    const bool live = e < n_elem && !((zero_dims >> int(e % 3)) & 1);
-    const double *src = pos + (int64_t(b) * t_block * n_total + first) * 3 + e;
-    const int64_t row_stride = n_total * 3;
-    double *dst = reinterpret_cast<double *>(&zb[s >> 1][0]) + (s & 1);
-    const int p = tid & 7, kbase = tid >> 3;
-    double2 *out = Y + ((int64_t(b) * R1 * (p_pad / PG) + pg) * R2) * PG + p;
-    const int64_t k1_stride = int64_t(p_pad / PG) * R2 * PG;
-
-    double x[LOADS];
-#define MDX_COLS400_LOAD(N2)                                                        \
-    _Pragma("unroll") for (int i = 0; i < LOADS; ++i)                               \
-    {                                                                               \
-        const int n1 = row0 + 32 * i;                                               \
-        const int64_t t = int64_t(n1) * R2 + (N2);                                  \
-        x[i] = (live && n1 < LIVE && t < t_block) ? src[t * row_stride] : 0.0;      \
-    }
-    MDX_COLS400_LOAD(n2_begin)
-    __syncthreads();
-    for (int n2 = n2_begin; n2 < n2_begin + n2_count; ++n2) {
-#pragma unroll
-        for (int i = 0; i < LOADS; ++i)
-            if (row0 + 32 * i < LIVE)
-                dst[2 * (row0 + 32 * i)] = x[i];
-        __syncthreads();
-        {
-            const int nxt = min(n2 + 1, R2 - 1);   // the last column reloads itself
-            MDX_COLS400_LOAD(nxt)
-        }
-        stockham_stage_mixed<R1, 4, 1, true>(zb[wave], s_h, lane, LIVE);
-        stockham_stage_mixed<R1, 4, 4, false>(zb[wave], s_h, lane, R1);
-        stockham_stage_mixed<R1, 5, 16, false>(zb[wave], s_h, lane, R1);
-        stockham_stage_mixed<R1, 5, 80, false>(zb[wave], s_h, lane, R1);
-        __syncthreads();
-        double2 *o = out + int64_t(n2) * PG;
-#pragma unroll 1
-        for (int i = 0; i < OUTS; ++i) {
-            const int k1 = kbase + 64 * i;
-            if (k1 < R1) {
-                // W_N^(n2 k1) = W_R1^(m / R2) * W_N^(m mod R2), m = n2 k1 < N
-                const unsigned m = unsigned(k1) * unsigned(n2);
-                const double2 w = cmul(s_h[m / R2], s_n[m & (R2 - 1)]);
-                o[int64_t(k1) * k1_stride] = cmul(zb[p][k1], w);
-            }
-        }
-        __syncthreads();
-    }
-#undef MDX_COLS400_LOAD
-}
-
 // Pass A for R1 = 400 with the per-frame sums fused in (the separate sums kernel read the positions
 // a second time: 12 GB per 5 000-particle group at C4).
 //
 // A block owns a SUPER GROUP of SG = 8 pair groups (64 pairs = 128 consecutive coordinates = 1 KB of
 // every frame row) and a range of columns; per column it runs the eight pair groups one after the
-// other through the same stage -> transform -> store iteration as msd_fft_cols400_kernel, so what a
+// other through one stage -> transform -> store iteration, so what a
 // block reads of one frame is one run of 1 KB.  While a pair group's rows sit in LDS, threads 0..199
 // (one per live row = frame) add up x^2 and the coordinate sums of their row; after the eighth pair
 // group the four sums of a frame leave as ONE 32-byte record part[super group][b][n2][row][4]
@@ -1573,11 +1452,6 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
         else
             hipLaunchKernelGGL((msd_fft_rows512_power_kernel<400>), gb, dim3(THREADS), 0, stream, Y, p_pad,
                                tw_r2, Pfull, accumulate);
-    } else if (sh.r1 == 400) {
-        hipLaunchKernelGGL((msd_fft_cols400_kernel<512>), ga, dim3(THREADS), 0, stream, pos, n_total, first,
-                           n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y);
-        hipLaunchKernelGGL((msd_fft_rows512_power_kernel<400>), gb, dim3(THREADS), 0, stream, Y, p_pad,
-                           tw_r2, Pfull, accumulate);
     } else if (sh.r1 == 512 && sh.r2 == 512) {
         MDX_MSDFFT_LAUNCH(512, 512);
     } else if (sh.r1 == 1024 && sh.r2 == 512) {
