@@ -1,4 +1,4 @@
-// mdx_msd_fft.hpp — the MSD engine's own forward transforms for n_fft = 400 x R2 (R2 = 16 .. 512: 6 400 .. 204 800),
+// mdx_msd_fft.hpp — the MSD engine's own forward transforms for n_fft = 400 x R2 (R2 = 8 .. 512: 3 200 .. 204 800),
 // 2^13 .. 2^16, 2^18, 2^19, 2^20.
 //
 // The power spectrum sum_series |F_k|^2 of ~30 000 zero-padded real series of 10^5 points is
@@ -22,8 +22,8 @@
 // One wave owns one transform (radix-8 Stockham stages, a radix-16 last stage for 1024 points,
 // in place in a wave-private LDS buffer; a wave's LDS operations execute in order, so there is
 // no barrier inside a transform).  Shapes: 400 x R2 — pass A msd_fft_cols400_fused_kernel<R2> (in-place DIF stages
-// 10, 10, 4 of the 400-point columns, the per-frame sums fused in), pass B msd_fft_rows_short_power_kernel (R2 = 16,
-// 32, 64), msd_fft_rows_mid_power_kernel (128, 256), msd_fft_rows512_power_kernel (512) —, 2^13 = 16 x 512,
+// 10, 10, 4 of the 400-point columns, the per-frame sums fused in), pass B msd_fft_rows_short_power_kernel (R2 = 8,
+// 16, 32, 64), msd_fft_rows_mid_power_kernel (128, 256), msd_fft_rows512_power_kernel (512) —, 2^13 = 16 x 512,
 // 2^14 = 16 x 1024, 2^15 = 64 x 512, 2^16 = 64 x 1024 (32 or 8 short column transforms per wave at a time),
 // 2^18 = 512 x 512, 2^19 = 1024 x 512, 2^20 = 1024 x 1024.
 #pragma once
@@ -1021,8 +1021,8 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_rows512_power_kernel(
     *pout = accumulate ? *pout + total : total;
 }
 
-// Pass B for 16-, 32- and 64-point rows (n_fft = 6 400 = 400 x 16, 12 800 = 400 x 32, 25 600 = 400 x 64: blocks of
-// 2 049 .. 3 200, 4 097 .. 6 400 and 8 193 .. 12 800 frames — C4 with eight blocks is the last, whose half-transformed
+// Pass B for 8-, 16-, 32- and 64-point rows (n_fft = 3 200 = 400 x 8, 6 400 = 400 x 16, 12 800 = 400 x 32, 25 600 = 400 x 64:
+// blocks of 801 .. 1 600, 1 601 .. 3 200, 4 097 .. 6 400 and 8 193 .. 12 800 frames — C4 with eight blocks is the last, whose half-transformed
 // block is then as large as with one block; padded to 2^15 it was 28 % larger).
 // A (k1, pair group) run of Y is R2 n2 x 8 pairs = R2 x 128 B, consecutive pair groups are contiguous.  Wave g of
 // a block streams pair groups g, g + 8, ... of the block's share on its own: lane (pair p = lane & 7, j = lane >> 3)
@@ -1033,7 +1033,9 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_rows512_power_kernel(
 // sums meet at the end.
 template <int F> __device__ __forceinline__ void dft_first(double2 *a)
 {
-    if constexpr (F == 8) {
+    if constexpr (F == 1) {
+        (void)a;
+    } else if constexpr (F == 8) {
         dft8(a);
     } else if constexpr (F == 4) {
         const double2 t0 = cadd(a[0], a[2]), t1 = csub(a[0], a[2]);
@@ -1054,7 +1056,7 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_rows_short_power_kernel(
     const double2 *__restrict__ Y, int p_pad, const double2 *__restrict__ tw_r2,
     double *__restrict__ Pfull, int accumulate)
 {
-    static_assert(R2 == 16 || R2 == 32 || R2 == 64, "row lengths of this kernel");
+    static_assert(R2 == 8 || R2 == 16 || R2 == 32 || R2 == 64, "row lengths of this kernel");
     constexpr int F = R2 / 8, ZS = R2 + 1;
     __shared__ double2 zb[PG][PG][ZS];            // [wave][pair][point]
     const int k1 = blockIdx.x, b = blockIdx.y;
@@ -1066,6 +1068,7 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_rows_short_power_kernel(
     const int p = lane & 7, j = lane >> 3;
     // W_R2^(j r), r = 1 .. F - 1, from the half table exp(-2 pi i m / R2), m < R2 / 2
     double2 w[F];
+    w[0] = make_double2(1.0, 0.0);
 #pragma unroll
     for (int r = 1; r < F; ++r)
         w[r] = tw_at<R2>(tw_r2, j * r);
@@ -1265,6 +1268,8 @@ inline Shape shape_for(int64_t n_fft)
         s.r1 = 64, s.r2 = 512;
     else if (n_fft == (int64_t(1) << 16))
         s.r1 = 64, s.r2 = 1024;
+    else if (n_fft == 3200)
+        s.r1 = 400, s.r2 = 8;
     else if (n_fft == 6400)
         s.r1 = 400, s.r2 = 16;
     else if (n_fft == 12800)
@@ -1412,12 +1417,14 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
         const int n_sg = fused_super_groups(p_pad);
         // (twelve rounds of the chip's block slots: C4 with one block 27.1 -> 26.2 ms of kernels per step against the
         // four rounds of round 2 — blocks in more different phases share a CU, and the tail is a twelfth)
-        const int fsplit = slots_split(int64_t(n_sg) * n_blocks, 8, std::min(64, sh.r2), 12);
+        const int fsplit = slots_split(int64_t(n_sg) * n_blocks, std::min(8, sh.r2), std::min(64, sh.r2), 12);
 #define MDX_MSDFFT_COLS400(R2_)                                                                                       \
     hipLaunchKernelGGL((msd_fft_cols400_fused_kernel<R2_>), dim3((unsigned)n_sg, (unsigned)fsplit, (unsigned)n_blocks), \
                        dim3(THREADS), 0, stream, pos, n_total, first, n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y, \
                        part, head)
-        if (sh.r2 == 16) {
+        if (sh.r2 == 8) {
+            MDX_MSDFFT_COLS400(8);
+        } else if (sh.r2 == 16) {
             MDX_MSDFFT_COLS400(16);
         } else if (sh.r2 == 32) {
             MDX_MSDFFT_COLS400(32);
@@ -1434,7 +1441,10 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
         hipLaunchKernelGGL(msd_partials_reduce_kernel,
                            dim3((unsigned)((int64_t(sh.r2) * SUMS_ROWS + 255) / 256), (unsigned)n_blocks), dim3(256), 0,
                            stream, part, n_sg, sh.r2, 1, SUMS_ROWS, t_block, traj, dsq);
-        if (sh.r2 == 16)
+        if (sh.r2 == 8)
+            hipLaunchKernelGGL((msd_fft_rows_short_power_kernel<400, 8>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,
+                               Pfull, accumulate);
+        else if (sh.r2 == 16)
             hipLaunchKernelGGL((msd_fft_rows_short_power_kernel<400, 16>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,
                                Pfull, accumulate);
         else if (sh.r2 == 32)

@@ -2,7 +2,7 @@
 import sys, os, json, numpy as np
 sys.path.insert(0, os.getcwd())
 import bench
-for b in (1, 2, 3, 4, 6, 8, 12, 16, 20, 32, 40):
+for b in [int(x) for x in sys.argv[1:]] or (1, 2, 3, 4, 6, 8, 12, 16, 20, 32, 40):
     args = bench.parse(["--workload", "msd", "--blocks", str(b), "--steps", "12", "--warmup", "4", "--no-onsager", "--no-cpu-baseline"])
     world = bench.World(args)
     d = bench.bench_msd(args, world)
