@@ -247,7 +247,7 @@ typedef struct mdx_msd *mdx_msd_t;
 /* One engine per (n_frames_block, n_blocks).  The transform length n_fft >= 2 n_frames_block - 1
  * (any such length gives the same linear correlation; the reference pads to
  * 2*next_fast_len(n_frames_block), correlation.py:176-178): a power of two served by the
- * engine's own two-pass kernels for blocks of 801 .. 524 288 frames, else the reference
+ * engine's own two-pass kernels for blocks of 201 .. 524 288 frames, else the reference
  * length or the next power of two through rocFFT (mdx_msd_n_fft reports it). */
 int mdx_msd_create(mdx_msd_t *out, int dev, int64_t n_frames_block, int n_blocks,
                    int n_groups);

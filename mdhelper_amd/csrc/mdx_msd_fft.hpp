@@ -1,4 +1,4 @@
-// mdx_msd_fft.hpp — the MSD engine's own forward transforms for n_fft = 400 x R2 (R2 = 8 .. 512: 3 200 .. 204 800),
+// mdx_msd_fft.hpp — the MSD engine's own forward transforms for n_fft = 400 x R2 (R2 = 2 .. 512: 800 .. 204 800),
 // 2^13 .. 2^16, 2^18, 2^19, 2^20.
 //
 // The power spectrum sum_series |F_k|^2 of ~30 000 zero-padded real series of 10^5 points is
@@ -22,7 +22,7 @@
 // One wave owns one transform (radix-8 Stockham stages, a radix-16 last stage for 1024 points,
 // in place in a wave-private LDS buffer; a wave's LDS operations execute in order, so there is
 // no barrier inside a transform).  Shapes: 400 x R2 — pass A msd_fft_cols400_fused_kernel<R2> (in-place DIF stages
-// 10, 10, 4 of the 400-point columns, the per-frame sums fused in), pass B msd_fft_rows_short_power_kernel (R2 = 8,
+// 10, 10, 4 of the 400-point columns, the per-frame sums fused in), pass B msd_fft_rows_tiny_power_kernel (R2 = 2, 4), msd_fft_rows_short_power_kernel (8,
 // 16, 32, 64), msd_fft_rows_mid_power_kernel (128, 256), msd_fft_rows512_power_kernel (512) —, 2^13 = 16 x 512,
 // 2^14 = 16 x 1024, 2^15 = 64 x 512, 2^16 = 64 x 1024 (32 or 8 short column transforms per wave at a time),
 // 2^18 = 512 x 512, 2^19 = 1024 x 512, 2^20 = 1024 x 1024.
@@ -1126,6 +1126,56 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_rows_short_power_kernel(
     }
 }
 
+// Pass B for 2- and 4-point rows (n_fft = 800 = 400 x 2, 1 600 = 400 x 4: blocks of 201 .. 400 and 401 .. 800 frames).
+// A (k1, pair group) run of Y is R2 lines of 128 B; thread (pair p = tid & 7, slot = tid >> 3) takes the pair groups
+// slot, slot + 64, ... of the block's share, loads its pair's R2 values (a wave instruction reads eight whole lines),
+// transforms them in registers and adds |X|^2 to R2 running sums.  The sums of the block meet in a fixed order:
+// xor-shuffles inside a wave, then the eight waves one after the other.
+template <int R1, int R2>
+__global__ __launch_bounds__(THREADS, 4) void msd_fft_rows_tiny_power_kernel(
+    const double2 *__restrict__ Y, int p_pad, double *__restrict__ Pfull, int accumulate)
+{
+    static_assert(R2 == 2 || R2 == 4, "row lengths of this kernel");
+    __shared__ double red[PG][R2];
+    const int k1 = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_all = p_pad / PG, n_parts = gridDim.z, part = blockIdx.z;
+    const int n_groups = (n_all - part + n_parts - 1) / n_parts;      // groups part, part + n_parts, ... of the block
+    const int p = tid & 7, slot = tid >> 3;
+    const double2 *src = Y + ((int64_t(b) * R1 + k1) * n_all + part) * (R2 * PG) + p;
+    double acc[R2];
+#pragma unroll
+    for (int r = 0; r < R2; ++r)
+        acc[r] = 0.0;
+    for (int g = slot; g < n_groups; g += THREADS / PG) {
+        const double2 *q = src + int64_t(g) * n_parts * (R2 * PG);
+        double2 v[R2];
+#pragma unroll
+        for (int r = 0; r < R2; ++r)
+            v[r] = q[r * PG];
+        dft_first<R2>(v);
+#pragma unroll
+        for (int r = 0; r < R2; ++r)
+            acc[r] = fma(v[r].x, v[r].x, fma(v[r].y, v[r].y, acc[r]));
+    }
+#pragma unroll
+    for (int r = 0; r < R2; ++r) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1)
+            acc[r] += __shfl_xor(acc[r], m);
+        if (lane == 0)
+            red[wave][r] = acc[r];
+    }
+    __syncthreads();
+    if (tid < R2) {
+        double total = 0.0;
+        for (int w = 0; w < PG; ++w)
+            total += red[w][tid];
+        double *pout = Pfull + ((int64_t(part) * gridDim.y + b) * R1 + k1) * R2 + tid;
+        *pout = accumulate ? *pout + total : total;
+    }
+}
+
 // Pass B for 128- and 256-point rows (n_fft = 51 200 = 400 x 128 and 102 400 = 400 x 256: blocks of 12 801 .. 25 600
 // and 25 601 .. 51 200 frames, which the power-of-two shapes padded by up to 2 x and 204 800 points by up to 3 x).
 // The structure of msd_fft_rows512_power_kernel with a short first stage: a block streams 64 KB pieces of Y — now
@@ -1268,6 +1318,10 @@ inline Shape shape_for(int64_t n_fft)
         s.r1 = 64, s.r2 = 512;
     else if (n_fft == (int64_t(1) << 16))
         s.r1 = 64, s.r2 = 1024;
+    else if (n_fft == 800)
+        s.r1 = 400, s.r2 = 2;
+    else if (n_fft == 1600)
+        s.r1 = 400, s.r2 = 4;
     else if (n_fft == 3200)
         s.r1 = 400, s.r2 = 8;
     else if (n_fft == 6400)
@@ -1422,7 +1476,11 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
     hipLaunchKernelGGL((msd_fft_cols400_fused_kernel<R2_>), dim3((unsigned)n_sg, (unsigned)fsplit, (unsigned)n_blocks), \
                        dim3(THREADS), 0, stream, pos, n_total, first, n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y, \
                        part, head)
-        if (sh.r2 == 8) {
+        if (sh.r2 == 2) {
+            MDX_MSDFFT_COLS400(2);
+        } else if (sh.r2 == 4) {
+            MDX_MSDFFT_COLS400(4);
+        } else if (sh.r2 == 8) {
             MDX_MSDFFT_COLS400(8);
         } else if (sh.r2 == 16) {
             MDX_MSDFFT_COLS400(16);
@@ -1441,7 +1499,13 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
         hipLaunchKernelGGL(msd_partials_reduce_kernel,
                            dim3((unsigned)((int64_t(sh.r2) * SUMS_ROWS + 255) / 256), (unsigned)n_blocks), dim3(256), 0,
                            stream, part, n_sg, sh.r2, 1, SUMS_ROWS, t_block, traj, dsq);
-        if (sh.r2 == 8)
+        if (sh.r2 == 2)
+            hipLaunchKernelGGL((msd_fft_rows_tiny_power_kernel<400, 2>), gb, dim3(THREADS), 0, stream, Y, p_pad, Pfull,
+                               accumulate);
+        else if (sh.r2 == 4)
+            hipLaunchKernelGGL((msd_fft_rows_tiny_power_kernel<400, 4>), gb, dim3(THREADS), 0, stream, Y, p_pad, Pfull,
+                               accumulate);
+        else if (sh.r2 == 8)
             hipLaunchKernelGGL((msd_fft_rows_short_power_kernel<400, 8>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,
                                Pfull, accumulate);
         else if (sh.r2 == 16)

@@ -15,7 +15,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 t_end = time.time() + budget
 cases = bad = 0
-edges = [2, 3, 17, 800, 801, 1000, 1600, 1601, 2047, 2048, 2049, 2050, 3200, 3201, 4095, 4096, 4097, 6400, 6401, 8191, 8192, 8193, 12800, 12801, 16383, 16384, 16385,
+edges = [2, 3, 17, 200, 201, 400, 401, 800, 801, 1000, 1600, 1601, 2047, 2048, 2049, 2050, 3200, 3201, 4095, 4096, 4097, 6400, 6401, 8191, 8192, 8193, 12800, 12801, 16383, 16384, 16385,
          25600, 25601, 32767, 32768, 32769, 40000, 51200, 51201, 65536, 65537]
 while time.time() < t_end:
     cases += 1

@@ -545,7 +545,9 @@ def test_rdf_mixed_orthorhombic_and_triclinic_frames_in_one_batch():
                                   (100000, 1, 29, 0), (102400, 1, 8, 3), (102401, 1, 8, 0), (32769, 3, 17, 0),
                                   # 25 600 = 400 x 64 points: blocks of 8 193 .. 12 800 frames
                                   (12800, 2, 19, 0), (12801, 2, 19, 0), (9000, 11, 37, 6), (12500, 8, 16, 1),
-                                  # 3 200 = 400 x 8: 801 .. 1 600 (shorter blocks: rocFFT)
+                                  # 800 = 400 x 2 and 1 600 = 400 x 4: 201 .. 400 and 401 .. 800 (shorter blocks: rocFFT)
+                                  (400, 5, 23, 0), (401, 5, 23, 0), (201, 12, 70, 4), (800, 3, 11, 0), (500, 40, 9, 1),
+                                  # 3 200 = 400 x 8: 801 .. 1 600
                                   (1600, 4, 21, 0), (1601, 4, 21, 0), (801, 7, 30, 3), (1000, 50, 9, 0),
                                   # 6 400 = 400 x 16 and 12 800 = 400 x 32 points: 2 049 .. 3 200 and 4 097 .. 6 400
                                   (3200, 3, 25, 0), (3201, 3, 25, 0), (2049, 9, 40, 2), (3000, 1, 8, 5),
@@ -570,7 +572,7 @@ def test_msd_own_two_pass_transform_equals_rocfft(case, monkeypatch):
         else:
             monkeypatch.delenv("MDX_MSD_ROCFFT", raising=False)
         eng = _core.MsdEngine(t_block, n_blocks, 2)
-        want = (3200 if t_block <= 1600 else 6400 if t_block <= 3200 else 8192 if t_block <= 4096 else 12800 if t_block <= 6400
+        want = (800 if t_block <= 400 else 1600 if t_block <= 800 else 3200 if t_block <= 1600 else 6400 if t_block <= 3200 else 8192 if t_block <= 4096 else 12800 if t_block <= 6400
                 else 16384 if t_block <= 8192 else 25600 if t_block <= 12800
                 else 32768 if t_block <= 16384 else 51200 if t_block <= 25600
                 else 65536 if t_block <= 32768 else 102400 if t_block <= 51200 else 204800 if t_block <= 102400
