@@ -8,8 +8,8 @@ run bench_c1like --workload rdf_wide --atoms 1000 --frames 20000 --steps 3 --no-
 run bench_sq_c3 --workload sq --steps 10 --warmup 2
 run bench_sq_default_grid --workload sq --n-points 32 --frames 200 --steps 3 --no-ingest
 run bench_isf --workload isf --steps 3 --warmup 1
-run bench_msd_20steps --workload msd --steps 20 --warmup 3
-run bench_msd8 --workload msd --blocks 8 --steps 20 --warmup 3
+run bench_msd_20steps --workload msd --steps 20 --warmup 6
+run bench_msd8 --workload msd --blocks 8 --steps 20 --warmup 6
 run bench_2ranks_shared --gpus 2 --share-devices --shard-fixed --frames 2000 --steps 2 --no-cpu-baseline
 python - <<'PY'
 import json, glob
