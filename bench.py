@@ -852,7 +852,7 @@ def bench_msd(args, world):
     kernel_s = st["kernel_ms"] * 1e-3
     achieved = alg_bytes / max(kernel_s, 1e-9) / 1e9
     msd = box["msd"][0, 0] / (N // 2 if args.shard_fixed else (N // 2) * world.world)
-    own_fft = (eng.n_fft in (800, 1600, 3200, 6400, 1 << 13, 12800, 1 << 14, 25600, 1 << 15, 51200, 1 << 16, 102400, 204800, 1 << 18, 1 << 19, 1 << 20)
+    own_fft = (eng.n_fft in (409600, 800, 1600, 3200, 6400, 1 << 13, 12800, 1 << 14, 25600, 1 << 15, 51200, 1 << 16, 102400, 204800, 1 << 18, 1 << 19, 1 << 20)
                and not os.environ.get("MDX_MSD_ROCFFT"))
     ctr = None
     if N == 10000 and T == 100000 and B == 8 and own_fft and world.world == 1:

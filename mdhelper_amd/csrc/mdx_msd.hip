@@ -948,7 +948,7 @@ int mdx_msd_create(mdx_msd_t *out, int dev, int64_t n_frames_block, int n_blocks
     // 2 * next_fast_len(N_t) (correlation.py:176-178).  Here:
     //   * blocks of more than 200 frames take the shortest length of the engine's own two-pass transform
     //     (mdx_msd_fft.hpp) that covers 2 N_t: 800 = 400 x 2, 1 600 = 400 x 4, 3 200 = 400 x 8, 6 400 = 400 x 16, 2^13, 12 800 = 400 x 32, 2^14, 25 600 = 400 x 64, 2^15, 51 200 = 400 x 128, 2^16,
-    //     102 400 = 400 x 256, 204 800 = 400 x 512, 2^18, 2^19, 2^20 (2^17 is served by 204 800 / 2^18).  It never materialises the padding and moves
+    //     102 400 = 400 x 256, 204 800 = 400 x 512, 2^18, 409 600 = 400 x 1024, 2^19, 2^20 (2^17 is served by 204 800 / 2^18).  It never materialises the padding and moves
     //     ~4.3 MB per series at 2^18 whatever N_t is, where the rocFFT pipeline moves ~17.7 MB;
     //   * everything else goes through rocFFT at the reference's length, or at the next power of two when that is
     //     at most 1.5 x longer (fewer rocFFT passes: measured 15 % faster end to end at N_t = 1e5).
@@ -962,7 +962,7 @@ int mdx_msd_create(mdx_msd_t *out, int dev, int64_t n_frames_block, int n_blocks
         if (!getenv("MDX_MSD_ROCFFT") && n_frames_block > 200) {
             // the shortest own length that covers 2 N_t
             static const int64_t lengths[] = {800, 1600, 3200, 6400, int64_t(1) << 13, 12800, int64_t(1) << 14, 25600, int64_t(1) << 15, 51200,
-                                              int64_t(1) << 16, 102400, 204800, int64_t(1) << 18, int64_t(1) << 19,
+                                              int64_t(1) << 16, 102400, 204800, int64_t(1) << 18, 409600, int64_t(1) << 19,
                                               int64_t(1) << 20};
             for (int64_t len : lengths)
                 if (len >= 2 * n_frames_block) {

@@ -1,4 +1,4 @@
-// mdx_msd_fft.hpp — the MSD engine's own forward transforms for n_fft = 400 x R2 (R2 = 2 .. 512: 800 .. 204 800),
+// mdx_msd_fft.hpp — the MSD engine's own forward transforms for n_fft = 400 x R2 (R2 = 2 .. 1024: 800 .. 409 600),
 // 2^13 .. 2^16, 2^18, 2^19, 2^20.
 //
 // The power spectrum sum_series |F_k|^2 of ~30 000 zero-padded real series of 10^5 points is
@@ -23,7 +23,8 @@
 // in place in a wave-private LDS buffer; a wave's LDS operations execute in order, so there is
 // no barrier inside a transform).  Shapes: 400 x R2 — pass A msd_fft_cols400_fused_kernel<R2> (in-place DIF stages
 // 10, 10, 4 of the 400-point columns, the per-frame sums fused in), pass B msd_fft_rows_tiny_power_kernel (R2 = 2, 4), msd_fft_rows_short_power_kernel (8,
-// 16, 32, 64), msd_fft_rows_mid_power_kernel (128, 256), msd_fft_rows512_power_kernel (512) —, 2^13 = 16 x 512,
+// 16, 32, 64), msd_fft_rows_mid_power_kernel (128, 256), msd_fft_rows512_power_kernel (512),
+// msd_fft_rows_power_kernel (1024) —, 2^13 = 16 x 512,
 // 2^14 = 16 x 1024, 2^15 = 64 x 512, 2^16 = 64 x 1024 (32 or 8 short column transforms per wave at a time),
 // 2^18 = 512 x 512, 2^19 = 1024 x 512, 2^20 = 1024 x 1024.
 #pragma once
@@ -1336,6 +1337,8 @@ inline Shape shape_for(int64_t n_fft)
         s.r1 = 400, s.r2 = 256;
     else if (n_fft == 204800)
         s.r1 = 400, s.r2 = 512;
+    else if (n_fft == 409600)
+        s.r1 = 400, s.r2 = 1024;
     else if (n_fft == (int64_t(1) << 18))
         s.r1 = 512, s.r2 = 512;
     else if (n_fft == (int64_t(1) << 19))
@@ -1492,8 +1495,10 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
             MDX_MSDFFT_COLS400(128);
         } else if (sh.r2 == 256) {
             MDX_MSDFFT_COLS400(256);
-        } else {
+        } else if (sh.r2 == 512) {
             MDX_MSDFFT_COLS400(512);
+        } else {
+            MDX_MSDFFT_COLS400(1024);     // 80.5 KB of LDS: still two blocks per CU
         }
 #undef MDX_MSDFFT_COLS400
         hipLaunchKernelGGL(msd_partials_reduce_kernel,
@@ -1523,8 +1528,11 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
         else if (sh.r2 == 256)
             hipLaunchKernelGGL((msd_fft_rows_mid_power_kernel<400, 256>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,
                                Pfull, accumulate);
-        else
+        else if (sh.r2 == 512)
             hipLaunchKernelGGL((msd_fft_rows512_power_kernel<400>), gb, dim3(THREADS), 0, stream, Y, p_pad,
+                               tw_r2, Pfull, accumulate);
+        else
+            hipLaunchKernelGGL((msd_fft_rows_power_kernel<400, 1024>), gb, dim3(THREADS), 0, stream, Y, p_pad,
                                tw_r2, Pfull, accumulate);
     } else if (sh.r1 == 512 && sh.r2 == 512) {
         MDX_MSDFFT_LAUNCH(512, 512);

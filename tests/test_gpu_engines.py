@@ -555,6 +555,8 @@ def test_rdf_mixed_orthorhombic_and_triclinic_frames_in_one_batch():
                                   # 51 200 = 400 x 128 and 102 400 = 400 x 256 points: 16 385 .. 25 600 and 32 769 .. 51 200
                                   (25600, 1, 21, 0), (25601, 1, 9, 3), (20000, 3, 43, 0), (16385, 2, 32, 4),
                                   (51200, 1, 11, 0), (51201, 1, 7, 0), (45000, 2, 29, 5), (32769, 1, 64, 0),
+                                  # 409 600 = 400 x 1024 points: 131 073 .. 204 800
+                                  (204800, 1, 7, 0), (204801, 1, 5, 0), (131073, 1, 9, 2), (160000, 2, 6, 0),
                                   # rows of whole 128-byte lines (16 | 3 n_atoms): the second push starts 9
                                   # coordinates into a line and pass A enters its chunk early (head)
                                   (70001, 1, 16, 0), (40000, 2, 32, 5), (50000, 1, 48, 2)])
@@ -576,7 +578,7 @@ def test_msd_own_two_pass_transform_equals_rocfft(case, monkeypatch):
                 else 16384 if t_block <= 8192 else 25600 if t_block <= 12800
                 else 32768 if t_block <= 16384 else 51200 if t_block <= 25600
                 else 65536 if t_block <= 32768 else 102400 if t_block <= 51200 else 204800 if t_block <= 102400
-                else 262144 if t_block <= 131072
+                else 262144 if t_block <= 131072 else 409600 if t_block <= 204800
                 else 524288 if t_block <= 262144 else 1048576)
         assert mode != "own" or eng.n_fft == want     # rocFFT runs its own choice of length
         eng.push(0, pos, 0, n_atoms, zero_dims)
