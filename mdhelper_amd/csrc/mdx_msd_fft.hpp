@@ -24,8 +24,8 @@
 // no barrier inside a transform).  Shapes: 400 x R2 — pass A msd_fft_cols400_fused_kernel<R2> (in-place DIF stages
 // 10, 10, 4 of the 400-point columns, the per-frame sums fused in), pass B msd_fft_rows_tiny_power_kernel (R2 = 2, 4), msd_fft_rows_short_power_kernel (8,
 // 16, 32, 64), msd_fft_rows_mid_power_kernel (128, 256), msd_fft_rows512_power_kernel (512),
-// msd_fft_rows_power_kernel (1024) —, 2^13 = 16 x 512,
-// 2^14 = 16 x 1024, 2^15 = 64 x 512, 2^16 = 64 x 1024 (32 or 8 short column transforms per wave at a time),
+// msd_fft_rows_power_kernel (1024) —, 2^13 = 64 x 128,
+// 2^14 = 64 x 256, 2^15 = 64 x 512, 2^16 = 64 x 1024 (8 short column transforms per wave at a time, the rows as above),
 // 2^18 = 512 x 512, 2^19 = 1024 x 512, 2^20 = 1024 x 1024.
 #pragma once
 
@@ -637,83 +637,10 @@ __global__ __launch_bounds__(256) void msd_partials_reduce_kernel(const double2 
     traj[3 * fo + 2] += z;
 }
 
-// Pass A for short first factors, R1 = 64 (n_fft = 2^15, 2^16) and R1 = 16 (2^13, 2^14): a wave
-// transforms NC = 512 / R1 neighbouring columns of its pair at once (one butterfly per lane and
-// stage for R1 = 64; one radix-16 butterfly per column for R1 = 16), so a block still moves 4 096
-// values per barrier, and the NC columns of a (k1, pair group) leave as one run of NC x 128 B.
-// Same grid and arguments as msd_fft_cols_kernel; gridDim.y <= R2 / NC.
-template <int R1, int R2>
-__global__ __launch_bounds__(THREADS, 2) void msd_fft_cols_small_kernel(
-    const double *__restrict__ pos, int64_t n_total, int64_t first, int64_t n_elem, int64_t t_block,
-    int zero_dims, int p_pad, const double2 *__restrict__ tw_r1, const double2 *__restrict__ twN,
-    double2 *__restrict__ Y)
-{
-    static_assert(R1 == 64 || R1 == 16, "supported first factors");
-    constexpr int NC = 512 / R1, ZS = R1 + 1, LIVE = R1 / 2;
-    constexpr int PER = 8;                         // columns per thread on either side
-    __shared__ double2 zb[PG][NC][ZS];
-    __shared__ double2 s_h[R1 / 2];   // exp(-2 pi i m / R1), m < R1 / 2
-    __shared__ double2 s_n[R2];       // exp(-2 pi i m / N),  m < R2
-    const int pg = blockIdx.x, b = blockIdx.z;
-    const int n2_count = R2 / int(gridDim.y);
-    const int n2_begin = blockIdx.y * n2_count;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < R1 / 2; i += THREADS)
-        s_h[i] = tw_r1[i];
-    for (int i = tid; i < R2; i += THREADS)
-        s_n[i] = twN[i];
-
-    // loads: coordinate s of the group, live row n1 (< R1 / 2), PER consecutive columns from c_in
-    const int s = tid & 15, n1 = (tid >> 4) % LIVE, c_in = (tid >> 4) / LIVE * PER;
-    const int64_t e = int64_t(pg) * 16 + s;
-    const bool live = e < n_elem && !((zero_dims >> int(e % 3)) & 1);
-    const double *src = pos + (int64_t(b) * t_block * n_total + first) * 3 + e;
-    const int64_t row_stride = n_total * 3;
-    double *dst = reinterpret_cast<double *>(&zb[s >> 1][c_in][0]) + (s & 1);
-    // stores: pair p, line k1, PER consecutive columns from c_out
-    const int p = tid & 7, k1 = (tid >> 3) % R1, c_out = (tid >> 3) / R1 * PER;
-    double2 *out = Y + ((int64_t(b) * R1 + k1) * (p_pad / PG) + pg) * R2 * PG + p;
-
-    double x[PER];   // row n1 of PER columns: consecutive frames
-#define MDX_COLS_SMALL_LOAD(N2)                                                     \
-    _Pragma("unroll") for (int i = 0; i < PER; ++i)                                 \
-    {                                                                               \
-        const int64_t t = int64_t(n1) * R2 + (N2) + c_in + i;                       \
-        x[i] = (live && t < t_block) ? src[t * row_stride] : 0.0;                   \
-    }
-    MDX_COLS_SMALL_LOAD(n2_begin)
-    __syncthreads();
-    for (int n2 = n2_begin; n2 < n2_begin + n2_count; n2 += NC) {
-#pragma unroll
-        for (int i = 0; i < PER; ++i)
-            dst[2 * (i * ZS + n1)] = x[i];
-        __syncthreads();
-        {
-            const int nxt = min(n2 + NC, R2 - NC);   // the last group reloads itself
-            MDX_COLS_SMALL_LOAD(nxt)
-        }
-        if (R1 == 64) {
-            stockham_stage_batch<R1, NC, 8, 1, true>(&zb[wave][0][0], ZS, s_h, lane, LIVE);
-            stockham_stage_batch<R1, NC, 8, 8, false>(&zb[wave][0][0], ZS, s_h, lane, R1);
-        } else {
-            stockham_stage_batch<R1, NC, 16, 1, true>(&zb[wave][0][0], ZS, s_h, lane, LIVE);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            // W_N^(n2 k1) = W_R1^(m / R2) * W_N^(m mod R2), m = n2 k1 < N
-            const int col = c_out + i;
-            const unsigned m = unsigned(k1) * unsigned(n2 + col);
-            const double2 w = cmul(tw_at<R1>(s_h, int(m / R2)), s_n[m & (R2 - 1)]);
-            out[int64_t(n2 + col) * PG] = cmul(zb[p][col][k1], w);
-        }
-        __syncthreads();
-    }
-#undef MDX_COLS_SMALL_LOAD
-}
-
-// Pass A for the short first factors with the per-frame sums fused in, as msd_fft_cols400_fused_kernel:
-// a block owns a super group of SG pair groups and a range of column groups; per group of NC columns
+// Pass A for the 64-point first factor (n_fft = 2^13 .. 2^16 = 64 x 128 .. 1024) with the per-frame sums fused in, as
+// msd_fft_cols400_fused_kernel: a wave transforms NC = 8 neighbouring columns of its pair at once (one butterfly per lane
+// and stage), so a block still moves 4 096 values per barrier, and the NC columns of a (k1, pair group) leave as one run
+// of NC x 128 B.  A block owns a super group of SG pair groups and a range of column groups; per group of NC columns
 // it runs the pair groups one after the other; while a pair group's rows sit in LDS every wave adds
 // up x^2 and the coordinate sums of the 256 frames of the iteration (R1 / 2 live rows x NC columns);
 // one 32-byte record per frame leaves after the last pair group.  Loads are branch-free (dead
@@ -726,7 +653,7 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols_small_fused_kernel(
     int zero_dims, int p_pad, const double2 *__restrict__ tw_r1, const double2 *__restrict__ twN,
     double2 *__restrict__ Y, double2 *__restrict__ part)
 {
-    static_assert(R1 == 64 || R1 == 16, "supported first factors");
+    static_assert(R1 == 64, "supported first factor");
     constexpr int NC = 512 / R1, ZS = R1 + 1, LIVE = R1 / 2;
     constexpr int PER = 8;                         // columns per thread on either side
     constexpr int FR = LIVE * NC;                  // frames of one iteration: 256
@@ -829,12 +756,8 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols_small_fused_kernel(
             }
         }
         __syncthreads();   // the sums read every pair's rows; the transforms below overwrite them
-        if (R1 == 64) {
-            stockham_stage_batch<R1, NC, 8, 1, true>(&zb[wave][0][0], ZS, s_h, lane, LIVE);
-            stockham_stage_batch<R1, NC, 8, 8, false>(&zb[wave][0][0], ZS, s_h, lane, R1);
-        } else {
-            stockham_stage_batch<R1, NC, 16, 1, true>(&zb[wave][0][0], ZS, s_h, lane, LIVE);
-        }
+        stockham_stage_batch<R1, NC, 8, 1, true>(&zb[wave][0][0], ZS, s_h, lane, LIVE);
+        stockham_stage_batch<R1, NC, 8, 8, false>(&zb[wave][0][0], ZS, s_h, lane, R1);
         const int q_n = wrap ? 0 : q + 1;
         const int n2_n = wrap ? min(n2 + NC, (g_begin + g_count - 1) * NC) : n2;
         cur += wrap ? (n2_n - n2) * row_stride - int64_t(n_q - 1) * 16 : 16;
@@ -1312,9 +1235,9 @@ inline Shape shape_for(int64_t n_fft)
 {
     Shape s;
     if (n_fft == (int64_t(1) << 13))
-        s.r1 = 16, s.r2 = 512;
+        s.r1 = 64, s.r2 = 128;
     else if (n_fft == (int64_t(1) << 14))
-        s.r1 = 16, s.r2 = 1024;
+        s.r1 = 64, s.r2 = 256;
     else if (n_fft == (int64_t(1) << 15))
         s.r1 = 64, s.r2 = 512;
     else if (n_fft == (int64_t(1) << 16))
@@ -1389,7 +1312,7 @@ inline int rows_parts(const Shape &sh, int n_blocks)
 
 // Pass B of the 128- and 256-point rows takes 64 KB pieces of 4 / 2 whole pair groups: the padded pair count of a
 // launch is a multiple of this many pair groups (the padding pairs are zeros and add nothing to the spectrum).
-inline int pair_group_multiple(const Shape &sh) { return (sh.r1 == 400 && (sh.r2 == 128 || sh.r2 == 256)) ? 512 / sh.r2 : 1; }
+inline int pair_group_multiple(const Shape &sh) { return (sh.r2 == 128 || sh.r2 == 256) ? 512 / sh.r2 : 1; }
 
 // Shapes whose pass A carries the per-frame sums (x^2 and the coordinate sums of every frame) itself:
 // the caller then skips its own sums kernel and hands `part`, `traj`, `dsq` to launch().
@@ -1413,6 +1336,9 @@ inline void launch_rows(dim3 gb, hipStream_t stream, const double2 *Y, int p_pad
     if constexpr (R2 == 512)
         hipLaunchKernelGGL((msd_fft_rows512_power_kernel<R1>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,
                            Pfull, accumulate);
+    else if constexpr (R2 == 128 || R2 == 256)
+        hipLaunchKernelGGL((msd_fft_rows_mid_power_kernel<R1, R2>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,
+                           Pfull, accumulate);
     else
         hipLaunchKernelGGL((msd_fft_rows_power_kernel<R1, R2>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,
                            Pfull, accumulate);
@@ -1428,7 +1354,7 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
 {
     // >= ~1024 blocks of pass A where the batch allows it
     int split = 4;
-    while (split < (sh.r1 <= 64 ? sh.r2 / (512 / sh.r1) : sh.r2 / 2) && int64_t(p_pad / PG) * split * n_blocks < 1024)
+    while (split < sh.r2 / 2 && int64_t(p_pad / PG) * split * n_blocks < 1024)
         split *= 2;
     const dim3 ga((unsigned)(p_pad / PG), (unsigned)split, (unsigned)n_blocks);
     const dim3 gb((unsigned)sh.r1, (unsigned)n_blocks, (unsigned)rows_parts(sh, n_blocks));
@@ -1448,27 +1374,16 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
     hipLaunchKernelGGL(msd_partials_reduce_kernel, dim3((unsigned)((int64_t(B) * (A / 2) + 255) / 256),          \
                        (unsigned)n_blocks), dim3(256), 0, stream, part, n_sg, B, 512 / A, A / 2, t_block, traj, dsq); \
     launch_rows<A, B>(gb, stream, Y, p_pad, tw_r2, Pfull, accumulate)
-        if (sh.r2 == 512) {
+        if (sh.r2 == 128) {
+            MDX_MSDFFT_SMALL_FUSED(64, 128);
+        } else if (sh.r2 == 256) {
+            MDX_MSDFFT_SMALL_FUSED(64, 256);
+        } else if (sh.r2 == 512) {
             MDX_MSDFFT_SMALL_FUSED(64, 512);
         } else {
             MDX_MSDFFT_SMALL_FUSED(64, 1024);
         }
 #undef MDX_MSDFFT_SMALL_FUSED
-    } else if (sh.r1 <= 64) {
-#define MDX_MSDFFT_SMALL(A, B)                                                                           \
-    hipLaunchKernelGGL((msd_fft_cols_small_kernel<A, B>), ga, dim3(THREADS), 0, stream, pos, n_total, first, \
-                       n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y);                                \
-    launch_rows<A, B>(gb, stream, Y, p_pad, tw_r2, Pfull, accumulate)
-        if (sh.r1 == 64 && sh.r2 == 512) {
-            MDX_MSDFFT_SMALL(64, 512);
-        } else if (sh.r1 == 64) {
-            MDX_MSDFFT_SMALL(64, 1024);
-        } else if (sh.r2 == 512) {
-            MDX_MSDFFT_SMALL(16, 512);
-        } else {
-            MDX_MSDFFT_SMALL(16, 1024);
-        }
-#undef MDX_MSDFFT_SMALL
     } else if (sh.r1 == 400 && part) {
         // per-frame sums fused into pass A: super groups of SG pair groups, >= ~1024 blocks
         const int n_sg = fused_super_groups(p_pad);
