@@ -852,8 +852,7 @@ def bench_msd(args, world):
     kernel_s = st["kernel_ms"] * 1e-3
     achieved = alg_bytes / max(kernel_s, 1e-9) / 1e9
     msd = box["msd"][0, 0] / (N // 2 if args.shard_fixed else (N // 2) * world.world)
-    own_fft = (eng.n_fft in (409600, 800, 1600, 3200, 6400, 1 << 13, 12800, 1 << 14, 25600, 1 << 15, 51200, 1 << 16, 102400, 204800, 1 << 18, 1 << 19, 1 << 20)
-               and not os.environ.get("MDX_MSD_ROCFFT"))
+    own_fft, fft_r1, fft_r2 = eng.transform
     ctr = None
     if N == 10000 and T == 100000 and B == 8 and own_fft and world.world == 1:
         ctr = profiled("msd_c4_b8", *MSD_SOURCES)
@@ -867,7 +866,7 @@ def bench_msd(args, world):
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"C4 self-MSD {N} atoms" + (" (fixed set, sharded)" if args.shard_fixed else "/GPU")
                                + f" x {T} frames, 2 groups, n_blocks={B}, n_fft={eng.n_fft}"
-                               + (" (own two-pass transform)" if own_fft else " (rocFFT)")},
+                               + (f" (own two-pass transform {fft_r1} x {fft_r2})" if own_fft else " (rocFFT)")},
         "per_rank_atom_frames_per_sec": world.gather(args.steps * float(n_mine) * T / own),
         **world.describe(),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

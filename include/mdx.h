@@ -246,14 +246,18 @@ typedef struct mdx_msd *mdx_msd_t;
 
 /* One engine per (n_frames_block, n_blocks).  The transform length n_fft >= 2 n_frames_block - 1
  * (any such length gives the same linear correlation; the reference pads to
- * 2*next_fast_len(n_frames_block), correlation.py:176-178): a power of two served by the
- * engine's own two-pass kernels for blocks of 201 .. 524 288 frames, else the reference
- * length or the next power of two through rocFFT (mdx_msd_n_fft reports it). */
+ * 2*next_fast_len(n_frames_block), correlation.py:176-178): the shortest length of the engine's own
+ * two-pass kernels (400 x 2^k or a power of two) for blocks of 201 .. 524 288 frames, else the reference
+ * length or the next power of two through rocFFT (mdx_msd_n_fft / mdx_msd_transform report it). */
 int mdx_msd_create(mdx_msd_t *out, int dev, int64_t n_frames_block, int n_blocks,
                    int n_groups);
 int mdx_msd_destroy(mdx_msd_t h);
 int mdx_msd_reset(mdx_msd_t h);
 int mdx_msd_n_fft(mdx_msd_t h, int64_t *n_fft);
+/* Which forward transform the engine runs: *own = 1 and n_fft = r1 x r2 for the engine's own two-pass kernels
+ * (csrc/mdx_msd_fft.hpp), *own = 0 (r1 = r2 = 0) for the rocFFT pipeline.  No reference counterpart: the
+ * reference has one path (scipy.fft, correlation.py:176-197); benchmarks and tests name the path they measured. */
+int mdx_msd_transform(mdx_msd_t h, int *own, int *r1, int *r2);
 /* Feed particles of one group: pos float64[n_blocks*n_frames_block][n_total][3]
  * (transport.py:932 layout), of which particles [first, first+count) belong to
  * `group`.  Accumulates sum_particles of the per-particle self MSD numerators

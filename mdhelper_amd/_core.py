@@ -494,6 +494,14 @@ class MsdEngine(_Engine):
         check(lib().mdx_msd_n_fft(self.handle, byref(n)))
         return n.value
 
+    @property
+    def transform(self):
+        """``(own, r1, r2)``: the engine's own two-pass transform ``n_fft = r1 * r2`` (``own`` True), or the rocFFT
+        pipeline (``(False, 0, 0)``)."""
+        own, r1, r2 = c_int(), c_int(), c_int()
+        check(lib().mdx_msd_transform(self.handle, byref(own), byref(r1), byref(r2)))
+        return bool(own.value), r1.value, r2.value
+
     def push(self, group, positions, first, count, zero_dims=0):
         """positions: float64[T, N_total, 3] on the host."""
         p = np.ascontiguousarray(positions, dtype=np.float64)

@@ -100,6 +100,7 @@ _SIGNATURES = {
     "mdx_msd_destroy": (c_int, [_vp]),
     "mdx_msd_reset": (c_int, [_vp]),
     "mdx_msd_n_fft": (c_int, [_vp, POINTER(c_int64)]),
+    "mdx_msd_transform": (c_int, [_vp, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "mdx_msd_push": (c_int, [_vp, c_int, _vp, c_int64, c_int64, c_int64, c_int]),
     "mdx_msd_push_device": (c_int, [_vp, c_int, _vp, c_int64, c_int64, c_int64, c_int]),
     "mdx_msd_result": (c_int, [_vp, _vp, _vp]),

@@ -1058,6 +1058,15 @@ int mdx_msd_n_fft(mdx_msd_t h, int64_t *n_fft)
     return MDX_OK;
 }
 
+int mdx_msd_transform(mdx_msd_t h, int *own, int *r1, int *r2)
+{
+    MDX_REQUIRE(h && own && r1 && r2, "NULL argument");
+    *own = h->own_fft ? 1 : 0;
+    *r1 = h->own_fft ? h->shape.r1 : 0;
+    *r2 = h->own_fft ? h->shape.r2 : 0;
+    return MDX_OK;
+}
+
 int mdx_msd_push_device(mdx_msd_t h, int group, const double *d_pos, int64_t n_total, int64_t first,
                         int64_t count, int zero_dims)
 {

@@ -581,6 +581,8 @@ def test_msd_own_two_pass_transform_equals_rocfft(case, monkeypatch):
                 else 262144 if t_block <= 131072 else 409600 if t_block <= 204800
                 else 524288 if t_block <= 262144 else 1048576)
         assert mode != "own" or eng.n_fft == want     # rocFFT runs its own choice of length
+        own, r1, r2 = eng.transform
+        assert own == (mode == "own") and (r1 * r2 == eng.n_fft if own else (r1, r2) == (0, 0))
         eng.push(0, pos, 0, n_atoms, zero_dims)
         eng.push(1, pos, 3, n_atoms - 5, zero_dims)
         out[mode] = eng.result()
