@@ -307,6 +307,25 @@ def test_onsager_matches_reference_driver(n_blocks):
     assert np.allclose(ons.results.transference_numbers.sum(axis=-1), 1)
 
 
+@pytest.mark.parametrize("T,n_blocks,n_fft", [(2400, 4, 1600), (2400, 1, 6400), (9000, 2, 12800), (9000, 1, 25600),
+                                               (8000, 1, 16384), (30000, 1, 65536), (30001, 3, 25600)])
+def test_onsager_on_the_engines_own_transforms(T, n_blocks, n_fft):
+    """The class on block lengths that take the engine's own two-pass transforms (400 x 2^k and 2^k points; the
+    small cases above run on 800 points or rocFFT): every cross and self MSD element-wise against the oracle's
+    restatement of Onsager._conclude (reference transport.py:1016-1059)."""
+    from mdhelper_amd import _core
+    u, pos = _random_walk_universe(T=T, sizes=(17, 12), seed=T + n_blocks)
+    groups = (u.atoms[:17], u.atoms[17:])
+    eng = _core.MsdEngine(T // n_blocks, n_blocks, 2)
+    assert eng.n_fft == n_fft and eng.transform[0]
+    eng.close()
+    ons = Onsager(groups, temperature=1.0, reduced=True, n_blocks=n_blocks).run()
+    cross, self_ = _onsager_ref(pos, (17, 12), n_blocks)
+    assert np.allclose(ons.results.times, 2.0 * np.arange(T // n_blocks))
+    assert np.allclose(ons.results.msd_self, self_, rtol=1e-6, atol=1e-8)
+    assert np.allclose(ons.results.msd_cross, cross, rtol=1e-6, atol=1e-7)
+
+
 def test_onsager_blocks_warning_center_and_unwrap():
     u, pos = _random_walk_universe(T=103)
     with pytest.warns(UserWarning):
