@@ -337,8 +337,9 @@ def main():
         data["isf"] = isf_entry("isf")
     if "msd_c4" in which:
         data["msd_c4"] = msd_entry("msd_c4")
-    if "msd_c4_b8" in which:
-        data["msd_c4_b8"] = msd_entry("msd_c4_b8", blocks=8)
+    for name in which:                             # msd_c4_b<N>: C4 in N blocks (8 is the quoted one)
+        if name.startswith("msd_c4_b") and name[8:].isdigit():
+            data[name] = msd_entry(name, blocks=int(name[8:]))
     with open(path, "w") as fh:
         json.dump(data, fh, indent=1, sort_keys=True)
     if "msd_tcc" in which:

@@ -10,6 +10,7 @@ run bench_sq_default_grid --workload sq --n-points 32 --frames 200 --steps 3 --n
 run bench_isf --workload isf --steps 3 --warmup 1
 run bench_msd_20steps --workload msd --steps 20 --warmup 6
 run bench_msd8 --workload msd --blocks 8 --steps 20 --warmup 6
+for b in 2 4 16 32; do run bench_msd$b --workload msd --blocks $b --steps 12 --warmup 6 --no-onsager; done
 run bench_2ranks_shared --gpus 2 --share-devices --shard-fixed --frames 2000 --steps 2 --no-cpu-baseline
 python - <<'PY'
 import json, glob
