@@ -165,6 +165,25 @@ int main()
     timeit("stores, 64-byte pieces, halves on one XCD", [&] { k_store_half<true><<<gridh, 256>>>(Y, n_pg, cpb); }, ybytes);
     timeit("loads, 64-byte pieces, halves on two XCDs", [&] { k_load_half<false><<<gridh, 256>>>(X, row_pairs, n_pg, cpb, sink); }, rbytes);
     timeit("loads, 64-byte pieces, halves on one XCD", [&] { k_load_half<true><<<gridh, 256>>>(X, row_pairs, n_pg, cpb, sink); }, rbytes);
+    {   // pass A's whole memory side with no arithmetic at all: the store and the load kernel side by side on two streams
+        hipStream_t s0, s1;
+        hipStreamCreate(&s0);
+        hipStreamCreate(&s1);
+        float best = 1e30f;
+        for (int rep = 0; rep < 4; ++rep) {
+            hipDeviceSynchronize();
+            hipEventRecord(e0, s0);
+            k_store<false, false><<<grid, 512, 0, s0>>>(Y, n_pg, cpb);
+            k_load<false><<<grid, 512, 0, s1>>>(X, row_pairs, n_pg, cpb, sink);
+            hipStreamSynchronize(s1);
+            hipEventRecord(e1, s0);
+            hipEventSynchronize(e1);
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            if (ms < best) best = ms;
+        }
+        printf("%-46s %.3f ms  %.2f TB/s\n", "stores and loads (whole lines) side by side", best, (ybytes + rbytes) / best * 1e-9);
+    }
     hipFree(Y);
     hipFree(X);
     return 0;
