@@ -12,7 +12,9 @@
 //       pass A (msd_fft_cols_kernel): reads the positions where they lie ([frame][particle][xyz],
 //         16 consecutive coordinates = 128 B per frame row, only the t < T_b rows — the zero
 //         padding is never materialised), R1-point transforms over n1 in LDS, twiddle
-//         W_N^(n2 k1), writes Y[k1][pair group][n2][pair] (8 pairs = 128 B contiguous);
+//         W_N^(n2 k1), writes Y[k1][pair group][n2][pair] (8 pairs = 128 B contiguous) — the 400-point family with
+//         rows of 32 .. 512 points Y[pair group][k1][n2][pair]: the lines an iteration stores then lie R2 x 128 B
+//         apart inside one pair group's block instead of a whole k1 row apart (`pg_major`);
 //       pass B (msd_fft_rows512_power_kernel; msd_fft_rows_power_kernel for 1024-point rows): streams
 //         Y once (R2 x 128 B contiguous per step), R2-point transforms over n2 — first stage on the
 //         registers the loads land in, middle stage in LDS, last stage back in registers —
@@ -405,8 +407,11 @@ template <int R2>
 __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols400_fused_kernel(
     const double *__restrict__ pos, int64_t n_total, int64_t first, int64_t n_elem, int64_t t_block,
     int zero_dims, int p_pad, const double2 *__restrict__ tw_r1, const double2 *__restrict__ twN,
-    double2 *__restrict__ Y, double2 *__restrict__ part, int head)
+    double2 *__restrict__ Y, double2 *__restrict__ part, int head, int pg_major)
 {
+    // pg_major: Y is laid out [block][pair group][k1][n2][8 pairs] instead of [block][k1][pair group][n2][8 pairs] — the
+    // 400 lines an iteration stores are then 64 KB (R2 = 512) apart inside one pair group's 26 MB instead of a whole
+    // k1 row (61 MB at C4) apart: the store side alone runs at 5.5 instead of 4.9 TB/s (scripts/ypiece_bench.hip).
     // head: the chunk is entered `head` (< 16) coordinates BEFORE the first particle's x, so that every
     // 128-byte piece a lane group loads is one cache line (a group that starts 64 bytes off a line touched two
     // lines per piece: 31 % more fetched and 1.6 ms per step at C4, round 3).  n_elem counts from there; the
@@ -444,8 +449,9 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols400_fused_kernel(
     const int64_t istr = int64_t(64) * R2 * row_stride;       // rows row0 + 64 i -> + i * istr
     // stores: pair p of line kbase + 64 i
     const int p = tid & 7, kbase = tid >> 3;
-    const int64_t k1_stride = int64_t(n_pg) * R2 * PG;
-    double2 *out = Y + (int64_t(b) * R1 + kbase) * k1_stride + p;
+    const int64_t k1_stride = pg_major ? int64_t(R2) * PG : int64_t(n_pg) * R2 * PG;
+    const int64_t pg_stride = pg_major ? int64_t(R1) * R2 * PG : int64_t(R2) * PG;
+    double2 *out = Y + int64_t(b) * n_pg * (int64_t(R1) * R2 * PG) + int64_t(kbase) * k1_stride + p;
 
     // rows of the current iteration: coordinate e = 16 (pg0 + q) + s, column n2
     const double *cur = base + (int64_t(row0) * R2 + n2_begin) * row_stride + int64_t(pg0) * 16 + s;
@@ -492,7 +498,7 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols400_fused_kernel(
     // loads followed by seven stores — and the compiler's wait for the loads at the top of the loop
     // becomes vmcnt(7 + ...) on both paths instead of draining the previous iteration's stores.
     {
-        double2 *o = out + (int64_t(pg0) * R2 + n2_begin) * PG;
+        double2 *o = out + int64_t(pg0) * pg_stride + int64_t(n2_begin) * PG;
 #pragma unroll
         for (int i = 0; i < OUTS; ++i) {
             const int k1 = kbase + 64 * i;
@@ -581,7 +587,7 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols400_fused_kernel(
         dif_stage<R1, 40, 10, false>(zb[wave], s_h, lane);
         dif_stage<R1, 4, 4, false>(zb[wave], s_h, lane);
         __syncthreads();
-        double2 *o = out + (int64_t(pg0 + q) * R2 + n2) * PG;
+        double2 *o = out + int64_t(pg0 + q) * pg_stride + int64_t(n2) * PG;
 #pragma unroll
         for (int i = 0; i < OUTS; ++i) {
             // the last round holds lines for kbase < 16 only: the other threads repeat round 5
@@ -651,7 +657,7 @@ template <int R1, int R2>
 __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols_small_fused_kernel(
     const double *__restrict__ pos, int64_t n_total, int64_t first, int64_t n_elem, int64_t t_block,
     int zero_dims, int p_pad, const double2 *__restrict__ tw_r1, const double2 *__restrict__ twN,
-    double2 *__restrict__ Y, double2 *__restrict__ part)
+    double2 *__restrict__ Y, double2 *__restrict__ part, int pg_major)
 {
     static_assert(R1 == 64, "supported first factor");
     constexpr int NC = 512 / R1, ZS = R1 + 1, LIVE = R1 / 2;
@@ -685,7 +691,10 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols_small_fused_kernel(
     double *dst = reinterpret_cast<double *>(&zb[s >> 1][c_in][0]) + (s & 1);
     // stores: pair p, line k1, PER consecutive columns from c_out
     const int p = tid & 7, k1 = (tid >> 3) % R1, c_out = (tid >> 3) / R1 * PER;
-    double2 *out = Y + ((int64_t(b) * R1 + k1) * n_pg) * R2 * PG + p;
+    // (pg_major: Y[block][pair group][k1][n2][pair], see msd_fft_cols400_fused_kernel)
+    const int64_t k1_stride = pg_major ? int64_t(R2) * PG : int64_t(n_pg) * R2 * PG;
+    const int64_t pg_stride = pg_major ? int64_t(R1) * R2 * PG : int64_t(R2) * PG;
+    double2 *out = Y + int64_t(b) * n_pg * (int64_t(R1) * R2 * PG) + int64_t(k1) * k1_stride + p;
 
     // frame (n1 R2 + n2 + c_in + i) of coordinate 16 (pg0 + q) + s; 32-bit liveness tests
     const int e_lim = int(min<int64_t>(n_elem - int64_t(pg0) * 16 - s, 1 << 20));                    // 16 Q < e_lim
@@ -702,7 +711,7 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols_small_fused_kernel(
     }
     MDX_SF_LOAD(g_begin * NC, 0, cur)
     {   // placeholder stores into the first iteration's own slots (see the 400-point kernel)
-        double2 *o = out + (int64_t(pg0) * R2 + g_begin * NC + c_out) * PG;
+        double2 *o = out + int64_t(pg0) * pg_stride + int64_t(g_begin * NC + c_out) * PG;
 #pragma unroll
         for (int i = 0; i < PER; ++i)
             o[int64_t(i) * PG] = make_double2(0.0, 0.0);
@@ -763,7 +772,7 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols_small_fused_kernel(
         cur += wrap ? (n2_n - n2) * row_stride - int64_t(n_q - 1) * 16 : 16;
         MDX_SF_LOAD(n2_n, q_n, cur)
         __syncthreads();
-        double2 *o = out + (int64_t(pg0 + q) * R2 + n2 + c_out) * PG;
+        double2 *o = out + int64_t(pg0 + q) * pg_stride + int64_t(n2 + c_out) * PG;
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             // W_N^(n2 k1) = W_R1^(m / R2) * W_N^(m mod R2), m = n2 k1 < N; the second from two tables
@@ -874,7 +883,7 @@ __global__ __launch_bounds__(THREADS, R2 == 512 ? 4 : 2) void msd_fft_rows_power
 template <int R1>
 __global__ __launch_bounds__(THREADS, 4) void msd_fft_rows512_power_kernel(
     const double2 *__restrict__ Y, int p_pad, const double2 *__restrict__ tw_r2,
-    double *__restrict__ Pfull, int accumulate)
+    double *__restrict__ Pfull, int accumulate, int pg_major = 0)
 {
     constexpr int R2 = 512, ZS = R2 + 1;
     __shared__ double2 zb[PG][ZS];
@@ -891,8 +900,11 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_rows512_power_kernel(
             *pout = 0.0;
         return;
     }
-    const int64_t g_stride = int64_t(n_parts) * (R2 * PG);
-    const double2 *src = Y + ((int64_t(b) * R1 + k1) * n_all + part) * (R2 * PG) + tid;
+    // (pg_major: Y[block][pair group][k1][n2][pair], see msd_fft_cols400_fused_kernel; a (k1, pair group) run is 64 KB either way)
+    const int64_t k1_stride = pg_major ? int64_t(R2) * PG : int64_t(n_all) * R2 * PG;
+    const int64_t pg_stride = pg_major ? int64_t(R1) * R2 * PG : int64_t(R2) * PG;
+    const int64_t g_stride = int64_t(n_parts) * pg_stride;
+    const double2 *src = Y + int64_t(b) * n_all * (int64_t(R1) * R2 * PG) + int64_t(k1) * k1_stride + int64_t(part) * pg_stride + tid;
     const int p = tid & 7, j = tid >> 3;
     double2 v[8];
     double acc[8];
@@ -978,7 +990,7 @@ template <int F> __device__ __forceinline__ void dft_first(double2 *a)
 template <int R1, int R2>
 __global__ __launch_bounds__(THREADS, 4) void msd_fft_rows_short_power_kernel(
     const double2 *__restrict__ Y, int p_pad, const double2 *__restrict__ tw_r2,
-    double *__restrict__ Pfull, int accumulate)
+    double *__restrict__ Pfull, int accumulate, int pg_major = 0)
 {
     static_assert(R2 == 8 || R2 == 16 || R2 == 32 || R2 == 64, "row lengths of this kernel");
     constexpr int F = R2 / 8, ZS = R2 + 1;
@@ -1001,8 +1013,12 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_rows_short_power_kernel(
     for (int r = 0; r < 8; ++r)
         acc[r] = 0.0;
     if (n_mine > 0) {
-        const int64_t g_stride = int64_t(n_parts) * PG * (R2 * PG);     // this wave's next pair group
-        const double2 *src = Y + ((int64_t(b) * R1 + k1) * n_all + part + int64_t(wave) * n_parts) * (R2 * PG) + lane;
+        // (pg_major: Y[block][pair group][k1][n2][pair], see msd_fft_cols400_fused_kernel)
+        const int64_t k1_stride = pg_major ? int64_t(R2) * PG : int64_t(n_all) * R2 * PG;
+        const int64_t pg_stride = pg_major ? int64_t(R1) * R2 * PG : int64_t(R2) * PG;
+        const int64_t g_stride = int64_t(n_parts) * PG * pg_stride;     // this wave's next pair group
+        const double2 *src = Y + int64_t(b) * n_all * (int64_t(R1) * R2 * PG) + int64_t(k1) * k1_stride +
+                             (part + int64_t(wave) * n_parts) * pg_stride + lane;
         double2 v[F];
 #pragma unroll
         for (int r = 0; r < F; ++r)
@@ -1112,7 +1128,7 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_rows_tiny_power_kernel(
 template <int R1, int R2>
 __global__ __launch_bounds__(THREADS, 4) void msd_fft_rows_mid_power_kernel(
     const double2 *__restrict__ Y, int p_pad, const double2 *__restrict__ tw_r2,
-    double *__restrict__ Pfull, int accumulate)
+    double *__restrict__ Pfull, int accumulate, int pg_major = 0)
 {
     static_assert(R2 == 128 || R2 == 256, "row lengths of this kernel");
     constexpr int F = R2 / 64;              // first radix
@@ -1136,15 +1152,20 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_rows_mid_power_kernel(
             *pout = 0.0;
         return;
     }
-    const int64_t g_stride = int64_t(n_parts) * (512 * PG);
-    const double2 *src = Y + ((int64_t(b) * R1 + k1) * n_all + part) * (512 * PG) + tid;
+    // (pg_major: Y[block][pair group][k1][n2][pair], see msd_fft_cols400_fused_kernel: the NPG pair groups of a piece are
+    // then pg_stride apart; element tid + 512 r of a piece is element tid + 512 (r % F) of its pair group r / F)
+    const int64_t k1_stride = pg_major ? int64_t(R2) * PG : int64_t(n_all) * NPG * R2 * PG;
+    const int64_t pg_stride = pg_major ? int64_t(R1) * R2 * PG : int64_t(R2) * PG;
+    const int64_t g_stride = int64_t(n_parts) * NPG * pg_stride;
+    const double2 *src = Y + int64_t(b) * n_all * NPG * (int64_t(R1) * R2 * PG) + int64_t(k1) * k1_stride +
+                         int64_t(part) * NPG * pg_stride + tid;
     const int p = tid & 7, j = tid >> 3;
     double2 v[8];
     double acc[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         acc[r] = 0.0;
-        v[r] = src[THREADS * r];
+        v[r] = src[(r / F) * pg_stride + (r % F) * THREADS];
     }
     __syncthreads();   // twiddle table
     const int c = lane / T8, l = lane % T8;                 // stage 3: transform c of this wave, butterfly l
@@ -1169,7 +1190,7 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_rows_mid_power_kernel(
             const int64_t off = int64_t(min(pc + 1, n_pieces - 1)) * g_stride;
 #pragma unroll
             for (int r = 0; r < 8; ++r)
-                v[r] = src[off + THREADS * r];
+                v[r] = src[off + (r / F) * pg_stride + (r % F) * THREADS];
         }
         // wave w owns pair index w of every pair group of the piece: transforms g * PG + w.  They are not adjacent
         // rows of zb, so the batch stage takes its stride between them: PG rows
@@ -1331,14 +1352,14 @@ inline size_t fused_part_bytes(const Shape &sh, int p_pad, int n_blocks)
 // pass B of shape R1 x R2: the register-staged kernel for 512-point rows, the general one for 1024
 template <int R1, int R2>
 inline void launch_rows(dim3 gb, hipStream_t stream, const double2 *Y, int p_pad, const double2 *tw_r2,
-                        double *Pfull, int accumulate)
+                        double *Pfull, int accumulate, int pg_major = 0)
 {
     if constexpr (R2 == 512)
         hipLaunchKernelGGL((msd_fft_rows512_power_kernel<R1>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,
-                           Pfull, accumulate);
+                           Pfull, accumulate, pg_major);
     else if constexpr (R2 == 128 || R2 == 256)
         hipLaunchKernelGGL((msd_fft_rows_mid_power_kernel<R1, R2>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,
-                           Pfull, accumulate);
+                           Pfull, accumulate, pg_major);
     else
         hipLaunchKernelGGL((msd_fft_rows_power_kernel<R1, R2>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,
                            Pfull, accumulate);
@@ -1370,10 +1391,13 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
         const dim3 gf((unsigned)n_sg, (unsigned)fsplit, (unsigned)n_blocks);
 #define MDX_MSDFFT_SMALL_FUSED(A, B)                                                                              \
     hipLaunchKernelGGL((msd_fft_cols_small_fused_kernel<A, B>), gf, dim3(THREADS), 0, stream, pos, n_total, first, \
-                       n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y, part);                                  \
+                       n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y, part, pgm);                             \
     hipLaunchKernelGGL(msd_partials_reduce_kernel, dim3((unsigned)((int64_t(B) * (A / 2) + 255) / 256),          \
                        (unsigned)n_blocks), dim3(256), 0, stream, part, n_sg, B, 512 / A, A / 2, t_block, traj, dsq); \
-    launch_rows<A, B>(gb, stream, Y, p_pad, tw_r2, Pfull, accumulate)
+    launch_rows<A, B>(gb, stream, Y, p_pad, tw_r2, Pfull, accumulate, pgm)
+        // (the pair-group-major layout of the 400-point family gains nothing here — this pass A already stores runs of
+        // NC x 128 B = 1 KB: C4 size in 25 / 13 / 7 blocks 25.6 / 27.1 / 28.8 ms k1-major, 26.1 / 27.4 / 28.6 pair-group-major)
+        const int pgm = 0;
         if (sh.r2 == 128) {
             MDX_MSDFFT_SMALL_FUSED(64, 128);
         } else if (sh.r2 == 256) {
@@ -1390,10 +1414,13 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
         // (twelve rounds of the chip's block slots: C4 with one block 27.1 -> 26.2 ms of kernels per step against the
         // four rounds of round 2 — blocks in more different phases share a CU, and the tail is a twelfth)
         const int fsplit = slots_split(int64_t(n_sg) * n_blocks, std::min(8, sh.r2), std::min(64, sh.r2), 12);
+        // Y[block][pair group][k1][n2][pair] where a (k1, pair group) run is at least 4 KB (measured: 1 and 2 KB runs cost pass B
+        // 0.3 ms more than the layout saves pass A) and pass B takes the layout
+        const int pg_major = sh.r2 >= 32 && sh.r2 <= 512 ? 1 : 0;
 #define MDX_MSDFFT_COLS400(R2_)                                                                                       \
     hipLaunchKernelGGL((msd_fft_cols400_fused_kernel<R2_>), dim3((unsigned)n_sg, (unsigned)fsplit, (unsigned)n_blocks), \
                        dim3(THREADS), 0, stream, pos, n_total, first, n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y, \
-                       part, head)
+                       part, head, pg_major)
         if (sh.r2 == 2) {
             MDX_MSDFFT_COLS400(2);
         } else if (sh.r2 == 4) {
@@ -1427,25 +1454,25 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
                                accumulate);
         else if (sh.r2 == 8)
             hipLaunchKernelGGL((msd_fft_rows_short_power_kernel<400, 8>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,
-                               Pfull, accumulate);
+                               Pfull, accumulate, pg_major);
         else if (sh.r2 == 16)
             hipLaunchKernelGGL((msd_fft_rows_short_power_kernel<400, 16>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,
-                               Pfull, accumulate);
+                               Pfull, accumulate, pg_major);
         else if (sh.r2 == 32)
             hipLaunchKernelGGL((msd_fft_rows_short_power_kernel<400, 32>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,
-                               Pfull, accumulate);
+                               Pfull, accumulate, pg_major);
         else if (sh.r2 == 64)
             hipLaunchKernelGGL((msd_fft_rows_short_power_kernel<400, 64>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,
-                               Pfull, accumulate);
+                               Pfull, accumulate, pg_major);
         else if (sh.r2 == 128)
             hipLaunchKernelGGL((msd_fft_rows_mid_power_kernel<400, 128>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,
-                               Pfull, accumulate);
+                               Pfull, accumulate, pg_major);
         else if (sh.r2 == 256)
             hipLaunchKernelGGL((msd_fft_rows_mid_power_kernel<400, 256>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,
-                               Pfull, accumulate);
+                               Pfull, accumulate, pg_major);
         else if (sh.r2 == 512)
             hipLaunchKernelGGL((msd_fft_rows512_power_kernel<400>), gb, dim3(THREADS), 0, stream, Y, p_pad,
-                               tw_r2, Pfull, accumulate);
+                               tw_r2, Pfull, accumulate, pg_major);
         else
             hipLaunchKernelGGL((msd_fft_rows_power_kernel<400, 1024>), gb, dim3(THREADS), 0, stream, Y, p_pad,
                                tw_r2, Pfull, accumulate);

@@ -34,6 +34,28 @@ __global__ __launch_bounds__(512) void k_store(double2 *__restrict__ Y, int n_pg
         }
 }
 
+// The whole-line store with Y laid out [pair group][k1][n2][8 pairs] instead of [k1][pair group][n2][8 pairs]: the 400 lines
+// of an iteration are then 64 KB apart inside one 26 MB region instead of 61 MB apart.
+__global__ __launch_bounds__(512) void k_store_pgmajor(double2 *__restrict__ Y, int n_pg, int cols_per_block)
+{
+    const int sg = blockIdx.x, tid = threadIdx.x;
+    const int c0 = blockIdx.y * cols_per_block;
+    for (int n2 = c0; n2 < c0 + cols_per_block && n2 < 512; ++n2)
+        for (int q = 0; q < 8; ++q) {
+            const int pg = sg * 8 + q;
+            if (pg >= n_pg) break;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                const int k1 = (tid >> 3) + 64 * i;
+                const int p = tid & 7;
+                if (k1 < 400) {
+                    const int64_t line = (int64_t(pg) * 400 + k1) * 512 + n2;
+                    Y[line * 8 + p] = make_double2(double(k1), double(n2));
+                }
+            }
+        }
+}
+
 template <bool PIECES>
 __global__ __launch_bounds__(512) void k_load(const double2 *__restrict__ X, int64_t row_pairs, int n_pg,
                                               int cols_per_block, double *__restrict__ sink)
@@ -165,6 +187,7 @@ int main()
     timeit("stores, 64-byte pieces, halves on one XCD", [&] { k_store_half<true><<<gridh, 256>>>(Y, n_pg, cpb); }, ybytes);
     timeit("loads, 64-byte pieces, halves on two XCDs", [&] { k_load_half<false><<<gridh, 256>>>(X, row_pairs, n_pg, cpb, sink); }, rbytes);
     timeit("loads, 64-byte pieces, halves on one XCD", [&] { k_load_half<true><<<gridh, 256>>>(X, row_pairs, n_pg, cpb, sink); }, rbytes);
+    timeit("stores, whole lines, Y[pair group][k1][n2][8]", [&] { k_store_pgmajor<<<grid, 512>>>(Y, n_pg, cpb); }, ybytes);
     {   // pass A's whole memory side with no arithmetic at all: the store and the load kernel side by side on two streams
         hipStream_t s0, s1;
         hipStreamCreate(&s0);
