@@ -322,7 +322,7 @@ template <int R1, int R2>
 __global__ __launch_bounds__(THREADS, R1 == 512 ? 4 : 2) void msd_fft_cols_kernel(
     const double *__restrict__ pos, int64_t n_total, int64_t first, int64_t n_elem, int64_t t_block,
     int zero_dims, int p_pad, const double2 *__restrict__ tw_r1, const double2 *__restrict__ twN,
-    double2 *__restrict__ Y)
+    double2 *__restrict__ Y, int pg_major)
 {
     constexpr int ZS = R1 + 1;                  // +1: bank spread of the transposed reads
     constexpr int LOADS = R1 / 2 / 32;          // rows per thread and column (8 or 16)
@@ -346,8 +346,10 @@ __global__ __launch_bounds__(THREADS, R1 == 512 ? 4 : 2) void msd_fft_cols_kerne
     const int64_t row_stride = n_total * 3;
     double *dst = reinterpret_cast<double *>(&zb[s >> 1][0]) + (s & 1);
     const int p = tid & 7, kbase = tid >> 3;
-    double2 *out = Y + ((int64_t(b) * R1 * (p_pad / PG) + pg) * R2) * PG + p;
-    const int64_t k1_stride = int64_t(p_pad / PG) * R2 * PG;
+    // (pg_major: Y[block][pair group][k1][n2][pair], see msd_fft_cols400_fused_kernel)
+    const int64_t k1_stride = pg_major ? int64_t(R2) * PG : int64_t(p_pad / PG) * R2 * PG;
+    const int64_t pg_stride = pg_major ? int64_t(R1) * R2 * PG : int64_t(R2) * PG;
+    double2 *out = Y + int64_t(b) * (p_pad / PG) * (int64_t(R1) * R2 * PG) + int64_t(pg) * pg_stride + p;
 
     // rows n1 = row0 + 32 i of the current column (indexed by unrolled constants only)
     double x[LOADS];
@@ -1381,8 +1383,8 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
     const dim3 gb((unsigned)sh.r1, (unsigned)n_blocks, (unsigned)rows_parts(sh, n_blocks));
 #define MDX_MSDFFT_LAUNCH(A, B)                                                                    \
     hipLaunchKernelGGL((msd_fft_cols_kernel<A, B>), ga, dim3(THREADS), 0, stream, pos, n_total, first, \
-                       n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y);                          \
-    launch_rows<A, B>(gb, stream, Y, p_pad, tw_r2, Pfull, accumulate)
+                       n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y, (B) == 512 ? 1 : 0);      \
+    launch_rows<A, B>(gb, stream, Y, p_pad, tw_r2, Pfull, accumulate, (B) == 512 ? 1 : 0)
     if (sh.r1 == 64 && part) {
         // per-frame sums fused into pass A (short first factors)
         const int n_sg = fused_super_groups(p_pad);
