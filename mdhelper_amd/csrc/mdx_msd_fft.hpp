@@ -798,7 +798,7 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols_small_fused_kernel(
 template <int R1, int R2>
 __global__ __launch_bounds__(THREADS, R2 == 512 ? 4 : 2) void msd_fft_rows_power_kernel(
     const double2 *__restrict__ Y, int p_pad, const double2 *__restrict__ tw_r2,
-    double *__restrict__ Pfull, int accumulate)
+    double *__restrict__ Pfull, int accumulate, int pg_major = 0)
 {
     constexpr int ZS = R2 + 1;
     constexpr int LOADS = R2 * PG / THREADS;    // 8 or 16 complex values per thread and group
@@ -812,8 +812,11 @@ __global__ __launch_bounds__(THREADS, R2 == 512 ? 4 : 2) void msd_fft_rows_power
     // Y[b][k1][pair group][n2][pair]: one group's R2 x 8 values are contiguous
     const int n_all = p_pad / PG, n_parts = gridDim.z, part = blockIdx.z;
     const int n_groups = (n_all - part + n_parts - 1) / n_parts;      // groups part, part + n_parts, ...
-    const int64_t g_stride = int64_t(n_parts) * (R2 * PG);
-    const double2 *src = Y + ((int64_t(b) * R1 + k1) * n_all + part) * (R2 * PG) + tid;
+    // (pg_major: Y[block][pair group][k1][n2][pair], see msd_fft_cols400_fused_kernel)
+    const int64_t k1_stride = pg_major ? int64_t(R2) * PG : int64_t(n_all) * R2 * PG;
+    const int64_t pg_stride = pg_major ? int64_t(R1) * R2 * PG : int64_t(R2) * PG;
+    const int64_t g_stride = int64_t(n_parts) * pg_stride;
+    const double2 *src = Y + int64_t(b) * n_all * (int64_t(R1) * R2 * PG) + int64_t(k1) * k1_stride + int64_t(part) * pg_stride + tid;
     if (n_groups <= 0) {   // more parts than pair groups: this part contributes nothing
         if (!accumulate)
 #pragma unroll
@@ -1364,7 +1367,7 @@ inline void launch_rows(dim3 gb, hipStream_t stream, const double2 *Y, int p_pad
                            Pfull, accumulate, pg_major);
     else
         hipLaunchKernelGGL((msd_fft_rows_power_kernel<R1, R2>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,
-                           Pfull, accumulate);
+                           Pfull, accumulate, pg_major);
 }
 
 // tw_r1 / tw_r2: half tables exp(-2 pi i m / R), m < R / 2; twN: exp(-2 pi i m / N), m < R2
@@ -1383,8 +1386,8 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
     const dim3 gb((unsigned)sh.r1, (unsigned)n_blocks, (unsigned)rows_parts(sh, n_blocks));
 #define MDX_MSDFFT_LAUNCH(A, B)                                                                    \
     hipLaunchKernelGGL((msd_fft_cols_kernel<A, B>), ga, dim3(THREADS), 0, stream, pos, n_total, first, \
-                       n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y, (B) == 512 ? 1 : 0);      \
-    launch_rows<A, B>(gb, stream, Y, p_pad, tw_r2, Pfull, accumulate, (B) == 512 ? 1 : 0)
+                       n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y, 1);                           \
+    launch_rows<A, B>(gb, stream, Y, p_pad, tw_r2, Pfull, accumulate, 1)
     if (sh.r1 == 64 && part) {
         // per-frame sums fused into pass A (short first factors)
         const int n_sg = fused_super_groups(p_pad);
@@ -1418,7 +1421,7 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
         const int fsplit = slots_split(int64_t(n_sg) * n_blocks, std::min(8, sh.r2), std::min(64, sh.r2), 12);
         // Y[block][pair group][k1][n2][pair] where a (k1, pair group) run is at least 4 KB (measured: 1 and 2 KB runs cost pass B
         // 0.3 ms more than the layout saves pass A) and pass B takes the layout
-        const int pg_major = sh.r2 >= 32 && sh.r2 <= 512 ? 1 : 0;
+        const int pg_major = sh.r2 >= 32 ? 1 : 0;
 #define MDX_MSDFFT_COLS400(R2_)                                                                                       \
     hipLaunchKernelGGL((msd_fft_cols400_fused_kernel<R2_>), dim3((unsigned)n_sg, (unsigned)fsplit, (unsigned)n_blocks), \
                        dim3(THREADS), 0, stream, pos, n_total, first, n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y, \
@@ -1477,7 +1480,7 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
                                tw_r2, Pfull, accumulate, pg_major);
         else
             hipLaunchKernelGGL((msd_fft_rows_power_kernel<400, 1024>), gb, dim3(THREADS), 0, stream, Y, p_pad,
-                               tw_r2, Pfull, accumulate);
+                               tw_r2, Pfull, accumulate, pg_major);
     } else if (sh.r1 == 512 && sh.r2 == 512) {
         MDX_MSDFFT_LAUNCH(512, 512);
     } else if (sh.r1 == 1024 && sh.r2 == 512) {
