@@ -12,8 +12,8 @@
 //       pass A (msd_fft_cols_kernel): reads the positions where they lie ([frame][particle][xyz],
 //         16 consecutive coordinates = 128 B per frame row, only the t < T_b rows — the zero
 //         padding is never materialised), R1-point transforms over n1 in LDS, twiddle
-//         W_N^(n2 k1), writes Y[k1][pair group][n2][pair] (8 pairs = 128 B contiguous) — the 400-point family with
-//         rows of 32 .. 512 points Y[pair group][k1][n2][pair]: the lines an iteration stores then lie R2 x 128 B
+//         W_N^(n2 k1), writes Y[k1][pair group][n2][pair] (8 pairs = 128 B contiguous) — the 400-, 512- and 1024-point
+//         first factors with rows of >= 32 points Y[pair group][k1][n2][pair]: the lines an iteration stores then lie R2 x 128 B
 //         apart inside one pair group's block instead of a whole k1 row apart (`pg_major`);
 //       pass B (msd_fft_rows512_power_kernel; msd_fft_rows_power_kernel for 1024-point rows): streams
 //         Y once (R2 x 128 B contiguous per step), R2-point transforms over n2 — first stage on the
