@@ -1330,6 +1330,8 @@ def dry_run(args):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    from mdhelper_amd import _lib
+    rt = _lib.runtime_summary()          # (dlopen + version queries: no device is touched)
     rdzv = Rendezvous(rank, world) if world > 1 else None
     token = bytes((7 * i + 1) & 255 for i in range(128))
     got = rdzv.bcast(token if rank == 0 else None) if rdzv else token
@@ -1347,19 +1349,23 @@ def dry_run(args):
         total = n if args.shard_fixed else n * world
     plans = [None] * world
     if rdzv:
-        blob = rdzv.gather((json.dumps({"rank": rank, "device": local, unit: mine}) + "\n").encode()).decode()
+        blob = rdzv.gather((json.dumps({"rank": rank, "device": local, unit: mine, "librccl": rt["librccl"],
+                                        "rccl_version": rt["rccl_version"], "one_runtime": rt["one_runtime"]})
+                            + "\n").encode()).decode()
         plans = [json.loads(x) for x in blob.splitlines()]
         summed = int(rdzv.allreduce(np.array([work], dtype=np.int64))[0])
         rdzv.barrier()
         rdzv.close()
     else:
-        plans, summed = [{"rank": 0, "device": 0, unit: mine}], work
+        plans, summed = [{"rank": 0, "device": 0, unit: mine, "librccl": rt["librccl"],
+                          "rccl_version": rt["rccl_version"], "one_runtime": rt["one_runtime"]}], work
     if rank == 0:
         print(json.dumps({"dry_run": True, "workload": args.workload, "n_gpus": world,
                           "scaling": "strong" if args.shard_fixed else "weak",
                           "id_broadcast_ok": got == token, "ranks_in_plan": sorted(p["rank"] for p in plans),
                           "devices": [p["device"] for p in plans], "plan": plans, "unit": unit,
                           "work_all_ranks": summed, "work_expected": total, "plan_covers_the_work": summed == total,
+                          "runtime": rt, "one_runtime_on_every_rank": all(p.get("one_runtime") for p in plans),
                           "rccl": False, "comm": "not started (dry run: control plane only)"}), flush=True)
     return 0
 
@@ -1382,6 +1388,42 @@ def launch_ranks(args):
         line["launcher"] = "bench.py (mdhelper_amd.launch: one fresh process per GPU)"
         print(json.dumps(line), flush=True)
     return rc
+
+
+def runtime_record(world):
+    """The user-mode ROCm stack libmdx.so ran on in this process (`mdhelper_amd._lib.runtime`: the files its HIP /
+    rocFFT / RCCL calls are bound to, versions, `one_runtime`) — rank 0's, plus whether every rank reported the
+    same (one number per rank through the communicator that is there anyway)."""
+    import zlib
+    from mdhelper_amd import _lib
+    rec = _lib.runtime_summary()
+    mine = float(zlib.crc32(json.dumps(rec, sort_keys=True).encode()))
+    rec["same_on_all_ranks"] = all(v == mine for v in world.gather(mine))
+    return rec
+
+
+def configs_summary(extra):
+    """BASELINE configs[2], [3] and C2(ii) in one compact object (<= 600 characters)."""
+    def brief(line, **more):
+        if not isinstance(line, dict) or "value" not in line:
+            return {"error": str((line or {}).get("error", "missing"))[:80]}
+        out = {"value": float(f"{line['value']:.4g}"), "unit": line.get("unit"),
+               "ms_per_step": round(line.get("ms_per_step", 0.0), 3),
+               "frac": round((line.get("roofline") or {}).get("frac") or 0.0, 4),
+               "bound": (line.get("roofline") or {}).get("bound"),
+               "cpu_value": float(f"{(line.get('cpu_baseline') or {}).get('value') or 0.0:.4g}")}
+        out.update(more)
+        return out
+    msd = extra.get("msd") or {}
+    ons = (msd.get("onsager") or {}) if isinstance(msd, dict) else {}
+    more = {}
+    for key in ("class_hbm_f64", "class_host_f32", "class_host_f32_pinned", "class_file"):
+        leg = ons.get(key)
+        if isinstance(leg, dict) and "ms_per_analysis" in leg:
+            more[key + "_ms"] = round(leg["ms_per_analysis"], 1)
+            if "link_bound_ms" in leg:
+                more[key + "_link_ms"] = round(leg["link_bound_ms"], 1)
+    return {"C3": brief(extra.get("sq")), "C4": brief(msd, **more), "C2ii": brief(extra.get("rdf_wide"))}
 
 
 def product_library():
@@ -1425,6 +1467,10 @@ def main():
         out["extra"] = run_extras(args, world)
         out["extra"]["ingest"] = run_ingest(args, world, out["frames_per_sec"])
     out["library"] = library
+    out["runtime"] = runtime_record(world)
+    if "extra" in out:
+        # LAST key of the line (the driver keeps a 2 000-character tail): C3 / C4 / C2(ii) in a few numbers each
+        out["configs"] = configs_summary(out["extra"])
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)
     os.close(saved_stdout)

@@ -65,17 +65,33 @@ int mdx_upload(int dev, void *d_dst, const void *src, size_t bytes);
  * range of particles out of every frame of float32[T][N][3] (row_bytes = 12 n_range, src_stride = 12 N) — what
  * Onsager streams per group while the group before is being transformed (transport.py:976-992). */
 int mdx_upload_rows(int dev, void *d_dst, const void *src, size_t row_bytes, size_t src_stride, size_t n_rows);
-/* Destroyed handles leave their device blocks in a per-device cache (at most 4 GiB, blocks up to 512 MiB) so
- * that an analysis object per call does not pay hipMalloc / hipFree each time; the cache is given back
- * automatically when an allocation of the library fails (handles' buffers, mdx_malloc) and here on request
- * (e.g. before another library allocates).  freed_bytes may be NULL. */
+/* Destroyed handles and mdx_free leave their device blocks (of any size) in a per-device, per-process cache so
+ * that an analysis object per call does not pay hipMalloc / hipFree each time (at C4 size: seconds inside
+ * hipMalloc every other analysis).  The cache holds at most MDX_CACHE_GB GiB when that variable is set, else a
+ * quarter of the memory that was FREE on the device when the cache was first used (at least 4 GiB).  It is given
+ * back automatically when an allocation of this library fails, and here on request: call mdx_trim_cache before
+ * handing the device to another library or process (rocFFT, another rank sharing the GPU) — nobody else can
+ * reclaim it.  mdx_device_info reports free memory WITHOUT the cached bytes (they are reported separately by
+ * mdx_cached_bytes).  freed_bytes may be NULL. */
 int mdx_trim_cache(int dev, size_t *freed_bytes);
+int mdx_cached_bytes(int dev, size_t *bytes);
+/* Which user-mode ROCm libraries this library's calls are bound to in THIS process — the files the dynamic
+ * linker resolved hipGetDeviceCount, rocfft_setup and ncclGetVersion to — with their versions and the ROCm root
+ * the library was built for, as "key=value\n" text (keys: rocm_root, libamdhip64, librocfft, librccl, libmdx,
+ * hip_runtime_version, hip_driver_version, rccl_version, rocfft_version).  Works without a device.  A process
+ * that loaded another copy of these libraries first (e.g. `import torch`, whose wheel bundles its own ROCm)
+ * binds libmdx.so to THAT copy; mdhelper_amd._lib refuses to run so (one process, one runtime). */
+int mdx_runtime_info(char *buf, size_t bytes);
 int mdx_device_synchronize(int dev);
 /* Page-lock a caller buffer (e.g. the float32[n_frames][n][3] array an MDAnalysis memory reader
  * holds — what `universe.trajectory[frame].positions` views, reference structure.py:753,796) so
  * that the host-buffer entry points below hand it to the DMA engine where it lies, without the
  * staging copy through the library's own pinned ring.  Optional: unregistered memory works, one
  * host copy slower.  The caller unregisters before freeing the buffer. */
+/* Whole pages are locked (the range is widened to page boundaries); a range that shares a page with one still
+ * registered is refused (MDX_ERR_STATE); mdx_host_unregister takes the pointer that was registered, waits for
+ * the device, and fails for a pointer it does not know.  A buffer only partly covered by a registration is
+ * treated as pageable by every entry point. */
 int mdx_host_register(int dev, void *ptr, size_t bytes);
 int mdx_host_unregister(int dev, void *ptr);
 
@@ -205,7 +221,11 @@ int mdx_sq_reset(mdx_sq_t h);
  * n_molecules <= 0 removes the grouping. */
 int mdx_sq_set_grouping(mdx_sq_t h, int64_t n_molecules, const int64_t *offsets, const double *masses);
 int mdx_sq_accumulate(mdx_sq_t h, const float *pos, int64_t n, int64_t n_frames);
+/* Positions already in HBM.  ASYNCHRONOUS on the handle's stream: the call may return while kernels still read
+ * d_pos; a producer that rewrites the buffer (an MD engine feeding batches) calls mdx_sq_synchronize first.
+ * mdx_sq_result and mdx_sq_destroy wait by themselves. */
 int mdx_sq_accumulate_device(mdx_sq_t h, const float *d_pos, int64_t n, int64_t n_frames);
+int mdx_sq_synchronize(mdx_sq_t h);
 /* float64[n_pairs][n_q] un-normalised sums over frames (structure.py:1494-1508). */
 int mdx_sq_result(mdx_sq_t h, double *ssf);
 int mdx_sq_allreduce(mdx_sq_t h, mdx_comm_t comm);
@@ -215,6 +235,18 @@ int mdx_sq_enable_timing(mdx_sq_t h, int on);
  * (accelerated.py:81-122): out = complex128[n_q] as (re, im) pairs; float64 positions. */
 int mdx_fourier_sum(int dev, const double *wavevectors, int64_t n_q, const double *positions,
                     int64_t n, double *out_re_im);
+/* Function-level drop-ins for the trigonometric forms (accelerated.py:167-247, :249-321, :323-627; the public
+ * static methods StructureFactor.ssf_trigonometric_2d / psf_trigonometric_2d_2d, structure.py:1238-1317):
+ *   mdx_inner         out[i][j] = q_i . r_j, float64[n_q][n]                      (inner_2d_2d)
+ *   mdx_trig_rowsums  cos_out[i] = sum_j cos(x[i][j]), sin_out[i] = sum_j sin(x[i][j]) for a caller-supplied
+ *                     float64[n_rows][n_cols] (either output may be NULL)         (cosine_sum_*, sine_sum_*,
+ *                     and, squared and added on the host, pythagorean_trigonometric_identity_*)
+ * x streams from host memory in row slabs (pinned ring / DMA) beside the kernels; the _device variant takes
+ * x and the outputs in HBM and returns when they are written. */
+int mdx_inner(int dev, const double *wavevectors, int64_t n_q, const double *positions, int64_t n, double *out);
+int mdx_trig_rowsums(int dev, const double *x, int64_t n_rows, int64_t n_cols, double *cos_out, double *sin_out);
+int mdx_trig_rowsums_device(int dev, const double *d_x, int64_t n_rows, int64_t n_cols, double *d_cos,
+                            double *d_sin);
 
 /* ------------------------------------------------- intermediate scattering function
  * Replaces IntermediateScatteringFunction._single_frame (structure.py:1956-2083): the
@@ -228,8 +260,12 @@ int mdx_isf_create(mdx_isf_t *out, int dev, const double *wavevectors, int64_t n
 int mdx_isf_destroy(mdx_isf_t h);
 int mdx_isf_reset(mdx_isf_t h);
 int mdx_isf_accumulate(mdx_isf_t h, const float *pos, int64_t n, int64_t n_frames);
-/* Same, positions already in HBM on the engine's device (float32[n_frames][n][3]). */
+/* Same, positions already in HBM on the engine's device (float32[n_frames][n][3]).  ASYNCHRONOUS on the
+ * handle's stream: the frames are copied into the engine's position ring by a device-to-device copy queued on
+ * that stream, and the call may return before the copy has run; a producer that rewrites d_pos calls
+ * mdx_isf_synchronize first (mdx_isf_result / mdx_isf_stats / mdx_isf_destroy wait by themselves). */
 int mdx_isf_accumulate_device(mdx_isf_t h, const float *d_pos, int64_t n, int64_t n_frames);
+int mdx_isf_synchronize(mdx_isf_t h);
 /* As mdx_sq_set_grouping; only before the first frame of a series. */
 int mdx_isf_set_grouping(mdx_isf_t h, int64_t n_molecules, const int64_t *offsets, const double *masses);
 /* cisf: float64[n_lags][n_pairs][n_q]; iisf (may be NULL): float64[n_lags][n_slots][n_q] with

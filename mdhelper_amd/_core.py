@@ -129,8 +129,13 @@ def device_info(dev: int = 0):
     total = c_size_t()
     free = c_size_t()
     check(lib().mdx_device_info(dev, name, 256, byref(cus), byref(total), byref(free)))
+    cached = c_size_t()
+    check(lib().mdx_cached_bytes(dev, byref(cached)))
+    # hbm_free_bytes: what the driver reports; hbm_cached_bytes: blocks of destroyed handles this process keeps
+    # (mdx_trim_cache) — the library's own allocations can take them, nobody else can
     return {"name": name.value.decode(), "compute_units": cus.value, "hbm_bytes": total.value,
-            "hbm_free_bytes": free.value}
+            "hbm_free_bytes": free.value, "hbm_cached_bytes": cached.value,
+            "hbm_available_bytes": free.value + cached.value}
 
 
 def synchronize(dev: int = 0):
@@ -367,7 +372,11 @@ class SqEngine(_Engine):
         check(lib().mdx_sq_accumulate(self.handle, _ptr(p), p.shape[1], p.shape[0]))
 
     def accumulate_device(self, d_pos, n, n_frames):
+        """Asynchronous on the engine's stream: ``synchronize()`` before the frames are overwritten."""
         check(lib().mdx_sq_accumulate_device(self.handle, d_pos, n, n_frames))
+
+    def synchronize(self):
+        check(lib().mdx_sq_synchronize(self.handle))
 
     def accumulate_traj(self, traj_file, frames, index=None):
         """Frames of a native trajectory file; ``index``: particles in concatenated-group order."""
@@ -439,8 +448,12 @@ class IsfEngine(_Engine):
         check(lib().mdx_isf_accumulate(self.handle, _ptr(p), p.shape[1], p.shape[0]))
 
     def accumulate_device(self, d_pos, n, n_frames):
-        """float32[n_frames][n][3] already in HBM (raw device pointer)."""
+        """float32[n_frames][n][3] already in HBM (raw device pointer).  Asynchronous on the engine's
+        stream: ``synchronize()`` before the frames are overwritten."""
         check(lib().mdx_isf_accumulate_device(self.handle, d_pos, n, n_frames))
+
+    def synchronize(self):
+        check(lib().mdx_isf_synchronize(self.handle))
 
     def accumulate_traj(self, traj_file, frames, index=None):
         """Frames (in analysis order) of a native trajectory file; ``index`` as for SqEngine."""
@@ -471,6 +484,31 @@ def fourier_sum_device(wavevectors, positions, dev=0):
     out = np.zeros(q.shape[0], dtype=np.complex128)
     check(lib().mdx_fourier_sum(dev, _ptr(q), q.shape[0], _ptr(r), r.shape[0], _ptr(out)))
     return out
+
+
+def inner_device(wavevectors, positions, dev=0):
+    """``mdx_inner``: float64[N_q, N] of q_i . r_j."""
+    q = np.ascontiguousarray(wavevectors, dtype=np.float64).reshape(-1, 3)
+    r = np.ascontiguousarray(positions, dtype=np.float64).reshape(-1, 3)
+    out = np.zeros((q.shape[0], r.shape[0]), dtype=np.float64)
+    if out.size:
+        for lo in range(0, q.shape[0], 65535):           # (one launch covers 65 535 wavevectors)
+            hi = min(q.shape[0], lo + 65535)
+            check(lib().mdx_inner(dev, _ptr(q[lo:hi]), hi - lo, _ptr(r), r.shape[0], _ptr(out[lo:hi])))
+    return out
+
+
+def trig_rowsums_device(xs, *, cos=True, sin=True, dev=0):
+    """``mdx_trig_rowsums``: ``(sum_j cos(xs[i, j]), sum_j sin(xs[i, j]))`` of a float64 matrix (``None`` for a
+    sum that was not asked for)."""
+    x = np.ascontiguousarray(xs, dtype=np.float64)
+    if x.ndim != 2:
+        raise ValueError("xs must be a two-dimensional array.")
+    c = np.zeros(x.shape[0]) if cos else None
+    s = np.zeros(x.shape[0]) if sin else None
+    if x.shape[0]:
+        check(lib().mdx_trig_rowsums(dev, _ptr(x), x.shape[0], x.shape[1], _ptr(c), _ptr(s)))
+    return c, s
 
 
 class MsdEngine(_Engine):

@@ -45,6 +45,8 @@ _SIGNATURES = {
     "mdx_upload": (c_int, [c_int, _vp, _vp, c_size_t]),
     "mdx_upload_rows": (c_int, [c_int, _vp, _vp, c_size_t, c_size_t, c_size_t]),
     "mdx_trim_cache": (c_int, [c_int, POINTER(c_size_t)]),
+    "mdx_cached_bytes": (c_int, [c_int, POINTER(c_size_t)]),
+    "mdx_runtime_info": (c_int, [c_char_p, c_size_t]),
     "mdx_device_synchronize": (c_int, [c_int]),
     "mdx_host_register": (c_int, [c_int, _vp, c_size_t]),
     "mdx_host_unregister": (c_int, [c_int, _vp]),
@@ -120,6 +122,11 @@ _SIGNATURES = {
     "mdx_rdf_accumulate_traj": (c_int, [_vp, _vp, _vp, c_int64, _vp, _vp, c_int64, _vp, c_int64]),
     "mdx_sq_set_grouping": (c_int, [_vp, c_int64, _vp, _vp]),
     "mdx_isf_accumulate_device": (c_int, [_vp, _vp, c_int64, c_int64]),
+    "mdx_inner": (c_int, [c_int, _vp, c_int64, _vp, c_int64, _vp]),
+    "mdx_trig_rowsums": (c_int, [c_int, _vp, c_int64, c_int64, _vp, _vp]),
+    "mdx_trig_rowsums_device": (c_int, [c_int, _vp, c_int64, c_int64, _vp, _vp]),
+    "mdx_isf_synchronize": (c_int, [_vp]),
+    "mdx_sq_synchronize": (c_int, [_vp]),
     "mdx_isf_set_grouping": (c_int, [_vp, c_int64, _vp, _vp]),
     "mdx_sq_accumulate_traj": (c_int, [_vp, _vp, _vp, c_int64, _vp, c_int64]),
     "mdx_isf_accumulate_traj": (c_int, [_vp, _vp, _vp, c_int64, _vp, c_int64]),
@@ -158,8 +165,90 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = restype
             fn.argtypes = argtypes
+        problems = runtime(handle)["problems"]
+        if problems and os.environ.get("MDX_ALLOW_FOREIGN_RUNTIME") != "1":
+            raise ImportError(
+                "libmdx.so is not running on the ROCm runtime it was built for: " + "; ".join(problems) +
+                ".  This happens when another copy of the HIP / rocFFT / RCCL libraries is loaded into the process "
+                "(e.g. `import torch`: the wheel bundles its own ROCm).  mdhelper_amd needs no torch; import it in "
+                "a process of its own, or set MDX_ALLOW_FOREIGN_RUNTIME=1 to run on the foreign runtime anyway.")
         _lib = handle
     return _lib
+
+
+_ROCM_LIBS = ("libamdhip64", "libhsa-runtime64", "librocfft", "librccl")
+
+
+def mapped_rocm_libraries() -> dict:
+    """``{stem: [files]}`` of the HIP / HSA / rocFFT / RCCL shared objects mapped into this process
+    (``/proc/self/maps``; real paths, each file once)."""
+    found = {stem: [] for stem in _ROCM_LIBS}
+    try:
+        with open("/proc/self/maps") as f:
+            lines = f.readlines()
+    except OSError:
+        return found
+    for line in lines:
+        parts = line.split(None, 5)
+        if len(parts) < 6:
+            continue
+        path = parts[5].strip()
+        base = os.path.basename(path)
+        for stem in _ROCM_LIBS:
+            if base.startswith(stem + ".so"):
+                real = os.path.realpath(path)
+                if real not in found[stem]:
+                    found[stem].append(real)
+    return found
+
+
+def runtime(handle=None) -> dict:
+    """
+    The user-mode ROCm stack ``libmdx.so`` runs on in this process: the files its HIP / rocFFT / RCCL calls are
+    bound to (``mdx_runtime_info``: ``dladdr`` of the resolved symbols), the versions they report, every copy of
+    these libraries mapped into the process, and ``problems``: a list that is empty exactly when each library is
+    mapped once and from the ROCm installation the library was built for.  One process, one runtime — what the
+    reference's single-process drivers have by construction (reference src/mdhelper/analysis/base.py:137-172).
+    """
+    h = handle if handle is not None else lib()
+    buf = ctypes.create_string_buffer(4096)
+    h.mdx_runtime_info.restype = c_int
+    h.mdx_runtime_info.argtypes = [c_char_p, c_size_t]
+    if h.mdx_runtime_info(buf, 4096) != MDX_OK:
+        raise RuntimeError("mdx_runtime_info failed")
+    info = dict(line.split("=", 1) for line in buf.value.decode().splitlines() if "=" in line)
+    root = os.path.realpath(info.get("rocm_root", "/opt/rocm"))
+    mapped = mapped_rocm_libraries()
+    problems = []
+    for key in ("libamdhip64", "librocfft", "librccl"):
+        bound = os.path.realpath(info.get(key, "?"))
+        info[key] = bound
+        if not bound.startswith(root + os.sep):
+            problems.append(f"{key} is bound to {bound}, not to {root}")
+    for stem, files in mapped.items():
+        if len(files) > 1:
+            problems.append(f"{stem} is mapped {len(files)} times ({', '.join(files)})")
+        for f in files:
+            if not f.startswith(root + os.sep) and not any(f in p for p in problems):
+                problems.append(f"{stem} is mapped from {f}, not from {root}")
+    for key in ("hip_runtime_version", "hip_driver_version", "rccl_version"):
+        if key in info:
+            info[key] = int(info[key])
+    info["rocm_root"] = root
+    info["mapped"] = mapped
+    info["problems"] = problems
+    return info
+
+
+def runtime_summary() -> dict:
+    """``runtime()`` without the per-library lists: what bench.py, smoke() and the launcher print per rank."""
+    r = runtime()
+    out = {k: r[k] for k in ("libamdhip64", "librocfft", "librccl", "hip_runtime_version", "rccl_version",
+                             "rocfft_version") if k in r}
+    hsa = r["mapped"].get("libhsa-runtime64") or []
+    out["libhsa-runtime64"] = hsa[0] if len(hsa) == 1 else hsa
+    out["one_runtime"] = not r["problems"]
+    return out
 
 
 def check(rc: int) -> None:

@@ -1,3 +1,3 @@
 """Algorithms of the hot path (mirrors ``mdhelper.algorithm``)."""
 
-from . import correlation, molecule, topology, unit, utility  # noqa: F401
+from . import accelerated, correlation, molecule, topology, unit, utility  # noqa: F401

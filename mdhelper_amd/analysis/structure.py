@@ -368,9 +368,12 @@ class RadialDistributionFunction(DynamicAnalysisBase):
                 d_boxes = _core.DeviceArray.from_host(
                     np.ascontiguousarray(np.broadcast_to(np.asarray(boxes, dtype=np.float32), (len(sel), 6))),
                     self._device)
-                self._engine.accumulate_device(resident.ptr, traj.n_atoms, None, traj.n_atoms, d_boxes.ptr, len(sel))
-                self._engine.synchronize()
-                d_boxes.free()
+                try:
+                    self._engine.accumulate_device(resident.ptr, traj.n_atoms, None, traj.n_atoms, d_boxes.ptr,
+                                                   len(sel))
+                    self._engine.synchronize()
+                finally:
+                    d_boxes.free()
                 continue
             pos = traj.frame_block(sel)
             p1 = pos if all1 else pos[:, i1]
@@ -468,6 +471,30 @@ class StructureFactor(NumbaAnalysisBase):
     formulations in the reference; both map onto the same fused GPU kernel.
     ``parallel`` is accepted and ignored.
     """
+
+    @staticmethod
+    def ssf_trigonometric_2d(qrs: np.ndarray) -> np.ndarray:
+        r"""
+        Static structure factors (un-normalised) from a caller-supplied array of
+        :math:`\mathbf q\cdot\mathbf r_j`, shape :math:`(N_q, N_r)`, in the trigonometric form
+        :math:`(\sum_j\cos)^2+(\sum_j\sin)^2` per row (reference structure.py:1238-1271).  The row sums run
+        on the device (``mdx_trig_rowsums``); the analysis itself never materialises ``qrs``.
+        """
+        c, s = _core.trig_rowsums_device(qrs)
+        return c * c + s * s
+
+    @staticmethod
+    def psf_trigonometric_2d_2d(qrs1: np.ndarray, qrs2: np.ndarray) -> np.ndarray:
+        r"""
+        Partial structure factors (un-normalised) from two arrays of :math:`\mathbf q\cdot\mathbf r`, shapes
+        :math:`(N_q, N_\alpha)` and :math:`(N_q, N_\beta)`:
+        :math:`2(\sum_j\cos\sum_k\cos+\sum_j\sin\sum_k\sin)` per row (reference structure.py:1273-1317).
+        """
+        if np.shape(qrs1)[0] != np.shape(qrs2)[0]:
+            raise ValueError("The two arrays must have one row per wavevector each.")
+        c1, s1 = _core.trig_rowsums_device(qrs1)
+        c2, s2 = _core.trig_rowsums_device(qrs2)
+        return 2 * (c1 * c2 + s1 * s2)
 
     def __init__(self, groups, groupings: Union[str, tuple] = "atoms", *, mode: str = None,
                  form: str = "exp", dimensions=None, n_points: int = 32, n_surfaces: int = None,

@@ -559,7 +559,7 @@ class Onsager(SerialAnalysisBase):
         largest = max(c for _f, c in spans)
         n_chunks = max(2, -(-largest * 12 * T // (3 << 29)))
         chunk = max(16, -(-(-(-largest // n_chunks)) // 16) * 16)
-        free = _core.device_info(self._device)["hbm_free_bytes"]
+        free = _core.device_info(self._device)["hbm_available_bytes"]
         if 2 * 12 * T * chunk > self._hbm_share * free:
             return False
         bufs = [_core.DeviceArray((T, chunk, 3), np.float32, self._device) for _ in range(2)]
@@ -603,7 +603,7 @@ class Onsager(SerialAnalysisBase):
         elif self._comm.world_size > 1:
             return None
         need = len(numbers) * traj.n_atoms * 12
-        if self._hbm_share <= 0 or need > self._hbm_share * _core.device_info(dev)["hbm_free_bytes"]:
+        if self._hbm_share <= 0 or need > self._hbm_share * _core.device_info(dev)["hbm_available_bytes"]:
             return None
         if native is not None:
             out = _core.DeviceArray((len(numbers), traj.n_atoms, 3), np.float32, dev)

@@ -6,10 +6,9 @@ Communicators for frame- / particle-sharded runs (one process per GPU).
                        accumulators are all-reduced in HBM (``engine.allreduce``).
 * ``launch.SocketComm`` — host all-reduce over the node-local rendezvous socket (no torch,
                        no RCCL): ranks that share one GPU in tests.
-* ``TorchDistComm``  — any initialised ``torch.distributed`` process group
-                       (``gloo`` on CPU, ``nccl`` = RCCL on GPUs); the host copies
-                       of the accumulators are all-reduced.  Used by the
-                       world_size-2 CPU tests and wherever a process group exists.
+
+No torch here (one process, one ROCm runtime: ``_lib.runtime()``); the gloo communicator
+of the world_size-2 CPU tests lives with them (``tests/helpers/torch_comm.py``).
 
 The reference's counterpart is the per-frame gather-and-sum of
 ``ParallelAnalysisBase.run`` (reference src/mdhelper/analysis/base.py:396-501,
@@ -38,34 +37,6 @@ class SerialComm:
 
     def barrier(self):
         pass
-
-
-class TorchDistComm:
-    """Host-side all-reduce over an existing ``torch.distributed`` process group."""
-
-    device_collectives = False
-
-    def __init__(self, group=None):
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            raise RuntimeError("torch.distributed is not initialised.")
-        self._dist = dist
-        self._group = group
-        self.rank = dist.get_rank(group)
-        self.world_size = dist.get_world_size(group)
-
-    def allreduce(self, arr, op="sum"):
-        import torch
-        a = np.ascontiguousarray(arr)
-        t = torch.from_numpy(a.copy())
-        if self._dist.get_backend(self._group) == "nccl":
-            t = t.cuda()
-        red = self._dist.ReduceOp.SUM if op == "sum" else self._dist.ReduceOp.MAX
-        self._dist.all_reduce(t, op=red, group=self._group)
-        return t.cpu().numpy().astype(a.dtype, copy=False)
-
-    def barrier(self):
-        self._dist.barrier(group=self._group)
 
 
 def rccl_comm_from_env(device: int | None = None, rdzv=None):

@@ -9,9 +9,15 @@
 #include "mdx_common.hpp"
 #include "mdx_internal.hpp"
 
+#include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <rocfft/rocfft.h>
 
 using namespace mdx;
+
+#ifndef MDX_ROCM_ROOT
+#define MDX_ROCM_ROOT "/opt/rocm"
+#endif
 
 struct mdx_comm {
     int dev = 0;
@@ -29,7 +35,37 @@ struct mdx_comm {
     } while (0)
 
 
+// the file a symbol this library calls is bound to (its own GOT entry, i.e. what the dynamic linker chose)
+static const char *bound_file(const void *fn)
+{
+    Dl_info info;
+    if (fn && dladdr(fn, &info) && info.dli_fname)
+        return info.dli_fname;
+    return "?";
+}
+
 extern "C" {
+
+int mdx_runtime_info(char *buf, size_t bytes)
+{
+    MDX_REQUIRE(buf && bytes > 0, "NULL buffer");
+    int hip_rt = 0, hip_drv = 0, rccl = 0;
+    if (hipRuntimeGetVersion(&hip_rt) != hipSuccess)
+        (void)hipGetLastError();
+    if (hipDriverGetVersion(&hip_drv) != hipSuccess)
+        (void)hipGetLastError();
+    (void)ncclGetVersion(&rccl);
+    char fftv[64] = "?";
+    (void)rocfft_get_version_string(fftv, sizeof fftv);
+    const int n = snprintf(buf, bytes,
+                           "rocm_root=%s\nlibamdhip64=%s\nlibrocfft=%s\nlibrccl=%s\nlibmdx=%s\n"
+                           "hip_runtime_version=%d\nhip_driver_version=%d\nrccl_version=%d\nrocfft_version=%s\n",
+                           MDX_ROCM_ROOT, bound_file((const void *)&hipGetDeviceCount),
+                           bound_file((const void *)&rocfft_setup), bound_file((const void *)&ncclGetVersion),
+                           bound_file((const void *)&mdx_runtime_info), hip_rt, hip_drv, rccl, fftv);
+    MDX_REQUIRE(n > 0 && size_t(n) < bytes, "buffer too small");
+    return MDX_OK;
+}
 
 int mdx_comm_unique_id(unsigned char id[MDX_COMM_ID_BYTES])
 {

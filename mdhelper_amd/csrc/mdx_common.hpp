@@ -160,6 +160,8 @@ struct HostStager {
 // allocations and stream creation are milliseconds, an analysis object per call (the reference's usage:
 // RadialDistributionFunction(...).run()) must not pay them every time.  Users hold `lock` while they queue.
 HostStager &device_stager(int dev);
+// caller memory page-locked through mdx_host_register: 1 covered whole, -1 touched but not covered, 0 unknown
+int host_range_registered(const void *ptr, size_t bytes);
 
 // Double-buffered staging between a producer on a copy stream and the kernels on a handle's
 // compute stream: the fill of slab k+1 overlaps the kernels of slab k.  A buffer is refilled

@@ -658,6 +658,14 @@ int mdx_isf_result(mdx_isf_t h, double *cisf, double *iisf)
     return MDX_OK;
 }
 
+int mdx_isf_synchronize(mdx_isf_t h)
+{
+    MDX_REQUIRE(h, "NULL handle");
+    MDX_TRY(set_device(h->dev));
+    MDX_HIP(hipStreamSynchronize(h->stream));
+    return MDX_OK;
+}
+
 int mdx_isf_stats(mdx_isf_t h, int64_t *launches, double *kernel_ms, int64_t *frames)
 {
     MDX_REQUIRE(h, "NULL handle");

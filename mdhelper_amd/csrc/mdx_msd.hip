@@ -306,13 +306,15 @@ __global__ void cross_pad_kernel(const double *__restrict__ traj, int64_t n_rows
 }
 
 // Q[p * B + b][f] = sum_k 2 Re(conj(F_i) F_j): the spectrum of corr(a, b)(m) + corr(b, a)(m), summed over xyz
+// (rows [row0, row0 + gridDim.y) of the n_pairs * B (pair, block) rows; Q holds this batch only)
 __global__ void cross_product_kernel(const double2 *__restrict__ F, const int *__restrict__ pairs, int n_blocks,
-                                     int64_t nc, double2 *__restrict__ Q)
+                                     int64_t nc, int64_t row0, double2 *__restrict__ Q)
 {
     const int64_t f = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (f >= nc)
         return;
-    const int p = blockIdx.y / n_blocks, b = blockIdx.y - p * n_blocks;
+    const int64_t row = row0 + blockIdx.y;
+    const int p = int(row / n_blocks), b = int(row - int64_t(p) * n_blocks);
     const int gi = pairs[2 * p], gj = pairs[2 * p + 1];
     const double2 *A = F + (int64_t(gi) * n_blocks + b) * 3 * nc + f;
     const double2 *Bv = F + (int64_t(gj) * n_blocks + b) * 3 * nc + f;
@@ -1331,29 +1333,37 @@ int mdx_msd_result_acf(mdx_msd_t h, double *acf_sum)
 int mdx_msd_cross(mdx_msd_t h, const int32_t *pairs, int64_t n_pairs, double *out)
 {
     MDX_REQUIRE(h && pairs && out, "NULL argument");
-    MDX_REQUIRE(n_pairs >= 1 && n_pairs <= 65535 / h->n_blocks, "pair count out of range");
+    MDX_REQUIRE(n_pairs >= 1 && n_pairs < (int64_t(1) << 28), "pair count out of range");
     for (int64_t p = 0; p < 2 * n_pairs; ++p)
         MDX_REQUIRE(pairs[p] >= 0 && pairs[p] < h->n_groups, "group %d out of range", pairs[p]);
     MDX_TRY(set_device(h->dev));
     const int B = h->n_blocks;
     const int64_t Tb = h->t_block, GB = int64_t(h->n_groups) * B, PB = n_pairs * B;
+    // (pair, block) rows go through the products and the inverse transforms in batches: the grid's y extent
+    // (65 535) and ~1 GiB of inverse-transform buffers bound a batch, not the number of pairs (36 groups at 100
+    // blocks, 12 at 1 000 used to be refused)
+    const int64_t rows_max = std::max<int64_t>(1, std::min<int64_t>(65535, (int64_t(1) << 30) / (24 * h->n_fft)));
+    const int64_t rows_batch = std::min(PB, rows_max);
     MDX_TRY(h->d_series.ensure(size_t(8) * GB * 3 * h->n_fft));
-    MDX_TRY(h->d_inv_in.ensure(size_t(16) * std::max(GB * 3, PB) * h->nc));
-    MDX_TRY(h->d_inv_out.ensure(size_t(8) * std::max(GB, PB) * h->n_fft));
+    MDX_TRY(h->d_inv_in.ensure(size_t(16) * std::max(GB * 3, rows_batch) * h->nc));
+    MDX_TRY(h->d_inv_out.ensure(size_t(8) * std::max(GB, rows_batch) * h->n_fft));
     MDX_TRY(h->d_cross_f.ensure(size_t(16) * GB * 3 * h->nc));
     MDX_TRY(h->d_index.ensure(size_t(8) * n_pairs));
     MDX_HIP(hipMemcpyAsync(h->d_index.ptr, pairs, size_t(8) * n_pairs, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(cross_pad_kernel, dim3((unsigned)ceil_div(GB * 3 * h->n_fft, 256)), dim3(256), 0, h->stream,
                        h->d_traj.as<double>(), GB, Tb, h->n_fft, h->d_series.as<double>());
     MDX_TRY(h->fft.exec(0, GB * 3, h->d_series.ptr, h->d_cross_f.ptr, h->stream));
-    hipLaunchKernelGGL(cross_product_kernel, dim3((unsigned)ceil_div(h->nc, 256), (unsigned)PB), dim3(256), 0,
-                       h->stream, h->d_cross_f.as<double2>(), h->d_index.as<int>(), B, h->nc,
-                       h->d_inv_in.as<double2>());
-    MDX_TRY(h->fft.exec(1, PB, h->d_inv_in.ptr, h->d_inv_out.ptr, h->stream));
-    MDX_HIP(hipGetLastError());
     std::vector<double> corr(size_t(PB) * Tb), tr(size_t(h->traj_len()));
-    MDX_HIP(hipMemcpy2DAsync(corr.data(), size_t(Tb) * 8, h->d_inv_out.ptr, size_t(h->n_fft) * 8,
-                             size_t(Tb) * 8, (size_t)PB, hipMemcpyDeviceToHost, h->stream));
+    for (int64_t r0 = 0; r0 < PB; r0 += rows_batch) {
+        const int64_t nr = std::min(rows_batch, PB - r0);
+        hipLaunchKernelGGL(cross_product_kernel, dim3((unsigned)ceil_div(h->nc, 256), (unsigned)nr), dim3(256), 0,
+                           h->stream, h->d_cross_f.as<double2>(), h->d_index.as<int>(), B, h->nc, r0,
+                           h->d_inv_in.as<double2>());
+        MDX_TRY(h->fft.exec(1, nr, h->d_inv_in.ptr, h->d_inv_out.ptr, h->stream));
+        MDX_HIP(hipGetLastError());
+        MDX_HIP(hipMemcpy2DAsync(corr.data() + size_t(r0) * Tb, size_t(Tb) * 8, h->d_inv_out.ptr, size_t(h->n_fft) * 8,
+                                 size_t(Tb) * 8, (size_t)nr, hipMemcpyDeviceToHost, h->stream));
+    }
     MDX_HIP(hipMemcpyAsync(tr.data(), h->d_traj.ptr, size_t(8) * h->traj_len(), hipMemcpyDeviceToHost, h->stream));
     MDX_HIP(hipStreamSynchronize(h->stream));
     const double inv_n = 1.0 / double(h->n_fft);
@@ -1475,33 +1485,44 @@ int mdx_correlate(int dev, const double *a, const double *b, int64_t n_series, i
     chunk = std::min(chunk, n_series);
     FftCache fft;
     fft.n_fft = n_fft;
-    DeviceBuffer d_in, d_pad, d_fa, d_fb;
+    // everything of the call — uploads, padding, transforms, products, the copy back — is ordered on ONE stream;
+    // the two inputs have their own device buffers (`b` used to be uploaded into the buffer the
+    // padding kernel of `a` might still be reading, on another stream)
+    DeviceBuffer d_a, d_b, d_pad, d_fa, d_fb;
     std::vector<double> host(size_t(chunk) * n_fft);
+    hipStream_t stream = nullptr;
     int rc = MDX_OK;
     auto run = [&]() -> int {
-        MDX_TRY(d_in.ensure(size_t(chunk) * n_t * 8));
+        MDX_TRY(stream_acquire(&stream));
+        MDX_TRY(d_a.ensure(size_t(chunk) * n_t * 8));
         MDX_TRY(d_pad.ensure(size_t(chunk) * n_fft * 8));
         MDX_TRY(d_fa.ensure(size_t(chunk) * nc * 16));
-        if (b)
+        if (b) {
+            MDX_TRY(d_b.ensure(size_t(chunk) * n_t * 8));
             MDX_TRY(d_fb.ensure(size_t(chunk) * nc * 16));
+        }
+        HostStager &ring = device_stager(dev);
         for (int64_t s0 = 0; s0 < n_series; s0 += chunk) {
             const int64_t c = std::min(chunk, n_series - s0);
             const unsigned gp = (unsigned)ceil_div(c * n_fft, 256);
-            MDX_TRY(mdx_memcpy_h2d(dev, d_in.ptr, a + s0 * n_t, size_t(c) * n_t * 8));
-            hipLaunchKernelGGL(corr_pad_kernel, dim3(gp), dim3(256), 0, 0, d_in.as<double>(), c, n_t,
+            MDX_TRY(ring.upload(dev, stream, d_a.ptr, a + s0 * n_t, size_t(c) * n_t * 8));
+            if (b)
+                MDX_TRY(ring.upload(dev, stream, d_b.ptr, b + s0 * n_t, size_t(c) * n_t * 8));
+            hipLaunchKernelGGL(corr_pad_kernel, dim3(gp), dim3(256), 0, stream, d_a.as<double>(), c, n_t,
                                n_fft, d_pad.as<double>());
-            MDX_TRY(fft.exec(0, c, d_pad.ptr, d_fa.ptr, nullptr));
+            MDX_TRY(fft.exec(0, c, d_pad.ptr, d_fa.ptr, stream));
             if (b) {
-                MDX_TRY(mdx_memcpy_h2d(dev, d_in.ptr, b + s0 * n_t, size_t(c) * n_t * 8));
-                hipLaunchKernelGGL(corr_pad_kernel, dim3(gp), dim3(256), 0, 0, d_in.as<double>(), c,
+                hipLaunchKernelGGL(corr_pad_kernel, dim3(gp), dim3(256), 0, stream, d_b.as<double>(), c,
                                    n_t, n_fft, d_pad.as<double>());
-                MDX_TRY(fft.exec(0, c, d_pad.ptr, d_fb.ptr, nullptr));
+                MDX_TRY(fft.exec(0, c, d_pad.ptr, d_fb.ptr, stream));
             }
             hipLaunchKernelGGL(corr_product_kernel, dim3((unsigned)ceil_div(c * nc, 256)), dim3(256),
-                               0, 0, d_fa.as<double2>(), b ? d_fb.as<double2>() : nullptr, c * nc,
+                               0, stream, d_fa.as<double2>(), b ? d_fb.as<double2>() : nullptr, c * nc,
                                d_fa.as<double2>());
-            MDX_TRY(fft.exec(1, c, d_fa.ptr, d_pad.ptr, nullptr));
-            MDX_TRY(mdx_memcpy_d2h(dev, host.data(), d_pad.ptr, size_t(c) * n_fft * 8));     // (waits for the device)
+            MDX_TRY(fft.exec(1, c, d_fa.ptr, d_pad.ptr, stream));
+            MDX_HIP(hipGetLastError());
+            // (returns when the bytes are in `host`: the ring's copy stream waits for `stream`, the call for the ring)
+            MDX_TRY(ring.download(dev, stream, host.data(), d_pad.ptr, size_t(c) * n_fft * 8));
             const double inv_n = 1.0 / double(n_fft);
             for (int64_t s = 0; s < c; ++s) {
                 const double *r = host.data() + s * n_fft;
@@ -1520,8 +1541,11 @@ int mdx_correlate(int dev, const double *a, const double *b, int64_t n_series, i
     };
     rc = run();
     (void)hipDeviceSynchronize();
+    if (stream)
+        stream_release(stream);
     fft.destroy();
-    d_in.recycle();
+    d_a.recycle();
+    d_b.recycle();
     d_pad.recycle();
     d_fa.recycle();
     d_fb.recycle();

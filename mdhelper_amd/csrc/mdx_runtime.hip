@@ -2,6 +2,8 @@
 // stream timers and the synthetic-trajectory generator used by bench.py/tests.
 #include "mdx_common.hpp"
 
+#include <unistd.h>
+
 #include <unordered_map>
 
 namespace mdx {
@@ -53,7 +55,7 @@ BlockCache &block_cache()
     return *c;
 }
 
-// at most a quarter of the device's memory (and at least 4 GiB) stays cached; MDX_CACHE_GB overrides
+// at most a quarter of the device's free memory at first use (and at least 4 GiB) stays cached; MDX_CACHE_GB overrides
 size_t cache_limit(BlockCache &c, int dev)
 {
     if (c.limit[dev] == 0) {
@@ -61,9 +63,11 @@ size_t cache_limit(BlockCache &c, int dev)
         if (const char *e = getenv("MDX_CACHE_GB")) {
             lim = size_t(atoll(e) < 0 ? 0 : atoll(e)) << 30;
         } else {
+            // a quarter of what is FREE now (first use: nothing of ours is cached yet), not of the total: another
+            // rank or library sharing the device keeps its share
             size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b / 4 > lim)
-                lim = total_b / 4;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 4 > lim)
+                lim = free_b / 4;
             else
                 (void)hipGetLastError();
         }
@@ -491,6 +495,24 @@ HostStager &device_stager(int dev)
     return *rings[i];
 }
 
+// Memory the DMA engine can read where it lies: a range registered through mdx_host_register that covers
+// [src, src + bytes) whole, or memory this library knows nothing about whose two ends the runtime reports as host
+// allocations (hipHostMalloc, a caller's own hipHostRegister).  A range that only touches a registration of ours
+// is pageable as far as the copy is concerned: a DMA that runs off the registered object faults.
+static bool host_is_device_readable(const void *src, size_t bytes)
+{
+    const int known = host_range_registered(src, bytes);
+    if (known != 0)
+        return known > 0;
+    hipPointerAttribute_t attr, attr_end;
+    if (hipPointerGetAttributes(&attr, src) == hipSuccess && attr.type == hipMemoryTypeHost &&
+        hipPointerGetAttributes(&attr_end, static_cast<const uint8_t *>(src) + bytes - 1) == hipSuccess &&
+        attr_end.type == hipMemoryTypeHost)
+        return true;
+    (void)hipGetLastError();
+    return false;
+}
+
 int HostStager::upload(int device, hipStream_t consumer, void *d_dst, const void *src, size_t bytes)
 {
     if (bytes == 0)
@@ -500,14 +522,10 @@ int HostStager::upload(int device, hipStream_t consumer, void *d_dst, const void
     // mdx_host_register): one DMA, no staging copy
     // (both ends are asked: a caller may have registered a shorter range than [src, src + bytes), and a DMA
     // that runs off the registered object faults; such a buffer goes through the ring like pageable memory)
-    hipPointerAttribute_t attr, attr_end;
-    if (hipPointerGetAttributes(&attr, src) == hipSuccess && attr.type == hipMemoryTypeHost &&
-        hipPointerGetAttributes(&attr_end, static_cast<const uint8_t *>(src) + bytes - 1) == hipSuccess &&
-        attr_end.type == hipMemoryTypeHost) {
+    if (host_is_device_readable(src, bytes)) {
         MDX_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, consumer));
         return MDX_OK;
     }
-    (void)hipGetLastError();
     if (bytes < (size_t(1) << 20)) {
         // small: the runtime's own staging is as good
         MDX_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, consumer));
@@ -594,14 +612,10 @@ int HostStager::upload_rows(int device, hipStream_t consumer, void *d_dst, const
     std::lock_guard<std::mutex> guard(lock);
     const uint8_t *from = static_cast<const uint8_t *>(src);
     // page-locked / registered memory (both ends of the strided range): one 2-D DMA where it lies
-    hipPointerAttribute_t attr, attr_end;
-    if (hipPointerGetAttributes(&attr, src) == hipSuccess && attr.type == hipMemoryTypeHost &&
-        hipPointerGetAttributes(&attr_end, from + (n_rows - 1) * src_stride + row_bytes - 1) == hipSuccess &&
-        attr_end.type == hipMemoryTypeHost) {
+    if (host_is_device_readable(src, (n_rows - 1) * src_stride + row_bytes)) {
         MDX_HIP(hipMemcpy2DAsync(d_dst, row_bytes, src, src_stride, row_bytes, n_rows, hipMemcpyHostToDevice, consumer));
         return MDX_OK;
     }
-    (void)hipGetLastError();
     // pageable: whole rows gathered into the pinned ring by the copy threads, 16 MB at a time
     const size_t chunk = size_t(16) << 20;
     const size_t rows_per = std::max<size_t>(1, chunk / row_bytes);
@@ -858,6 +872,14 @@ int mdx_upload_rows(int dev, void *d_dst, const void *src, size_t row_bytes, siz
     return MDX_OK;
 }
 
+int mdx_cached_bytes(int dev, size_t *bytes)
+{
+    MDX_REQUIRE(bytes, "NULL argument");
+    MDX_REQUIRE(dev >= 0 && dev < 64, "bad device");
+    *bytes = cached_device_bytes(dev);
+    return MDX_OK;
+}
+
 int mdx_trim_cache(int dev, size_t *freed_bytes)
 {
     MDX_TRY(set_device(dev));
@@ -882,15 +904,17 @@ int mdx_upload(int dev, void *d_dst, const void *src, size_t bytes)
     return MDX_OK;
 }
 
-// Large copies between pageable host memory and HBM go through the library's own pinned ring, not through the
-// runtime's pageable path (which pins the caller's pages on the fly): one large pageable hipMemcpy D2H aborted the
-// process once in the round-4 test runs, inside the runtime, with nothing of this library in flight; the ring's
-// buffers are allocated once, and its copies are plain pinned DMAs.
+// Large copies between pageable host memory and HBM go through the library's own pinned ring (its copy threads
+// keep the link at 50 GB/s where the runtime's single-threaded staging gives ~15; NOTES round 5 for what the one
+// aborted run of round 4 does and does not say about the runtime's pageable path).  hipMemcpy's ordering is kept:
+// the copy starts after everything queued on the device before the call and has ended when the call returns.
 int mdx_memcpy_h2d(int dev, void *dst, const void *src, size_t bytes)
 {
     MDX_TRY(set_device(dev));
-    if (bytes >= (size_t(1) << 20))
+    if (bytes >= (size_t(1) << 20)) {
+        MDX_HIP(hipDeviceSynchronize());
         return mdx_upload(dev, dst, src, bytes);
+    }
     MDX_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
     return MDX_OK;
 }
@@ -914,11 +938,76 @@ int mdx_memset(int dev, void *dst, int value, size_t bytes)
     return MDX_OK;
 }
 
+}  // extern "C"
+
+// Caller memory page-locked through this library: whole pages (the runtime locks pages; a range that starts or
+// ends inside a page would leave its neighbours' state to the runtime), one registration per page, looked up by
+// the caller's own pointer at unregistration.  The host-buffer entry points decide "DMA where it lies" from this
+// table first (host_range_registered), so a buffer that is only partly covered never reaches the DMA engine.
+namespace {
+struct HostRange {
+    uintptr_t lo, hi;        // page-aligned [lo, hi)
+    uintptr_t user;          // the pointer the caller registered
+    int dev;
+};
+struct HostRegistry {
+    std::mutex m;
+    std::vector<HostRange> ranges;
+};
+HostRegistry &host_registry()
+{
+    static HostRegistry *r = new HostRegistry();
+    return *r;
+}
+uintptr_t page_bytes()
+{
+    static const uintptr_t p = [] {
+        const long v = sysconf(_SC_PAGESIZE);
+        return uintptr_t(v > 0 ? v : 4096);
+    }();
+    return p;
+}
+}  // namespace
+
+namespace mdx {
+// 1: [ptr, ptr + bytes) lies inside one range registered through mdx_host_register; -1: it touches one without
+// lying inside it (must NOT be handed to the DMA engine); 0: this library knows nothing about it
+int host_range_registered(const void *ptr, size_t bytes)
+{
+    if (!ptr || bytes == 0)
+        return 0;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(ptr), b = a + bytes;
+    HostRegistry &r = host_registry();
+    std::lock_guard<std::mutex> lk(r.m);
+    int state = 0;
+    for (const HostRange &h : r.ranges) {
+        if (a >= h.lo && b <= h.hi)
+            return 1;
+        if (a < h.hi && h.lo < b)
+            state = -1;
+    }
+    return state;
+}
+}  // namespace mdx
+
+extern "C" {
+
 int mdx_host_register(int dev, void *ptr, size_t bytes)
 {
     MDX_REQUIRE(ptr && bytes, "NULL buffer");
     MDX_TRY(set_device(dev));
-    MDX_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    const uintptr_t page = page_bytes();
+    const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+    const uintptr_t lo = a & ~(page - 1), hi = (a + bytes + page - 1) & ~(page - 1);
+    HostRegistry &r = host_registry();
+    std::lock_guard<std::mutex> lk(r.m);
+    for (const HostRange &h : r.ranges)
+        if (lo < h.hi && h.lo < hi)
+            return fail(MDX_ERR_STATE,
+                        "mdx_host_register: [%p, +%zu) shares pages with a range that is still registered "
+                        "(%p); unregister that one first", ptr, bytes, reinterpret_cast<void *>(h.user));
+    MDX_HIP(hipHostRegister(reinterpret_cast<void *>(lo), size_t(hi - lo), hipHostRegisterDefault));
+    r.ranges.push_back({lo, hi, a, dev});
     return MDX_OK;
 }
 
@@ -926,8 +1015,20 @@ int mdx_host_unregister(int dev, void *ptr)
 {
     MDX_REQUIRE(ptr, "NULL buffer");
     MDX_TRY(set_device(dev));
-    MDX_HIP(hipHostUnregister(ptr));
-    return MDX_OK;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+    HostRegistry &r = host_registry();
+    std::lock_guard<std::mutex> lk(r.m);
+    for (size_t i = 0; i < r.ranges.size(); ++i)
+        if (r.ranges[i].user == a) {
+            // nothing of this library may still read the pages: the entry points that hand registered memory to
+            // the DMA engine return before their copies end only on handles' streams
+            MDX_HIP(hipDeviceSynchronize());
+            MDX_HIP(hipHostUnregister(reinterpret_cast<void *>(r.ranges[i].lo)));
+            r.ranges[i] = r.ranges.back();
+            r.ranges.pop_back();
+            return MDX_OK;
+        }
+    return fail(MDX_ERR_INVALID_VALUE, "mdx_host_unregister: %p was not registered through mdx_host_register", ptr);
 }
 
 int mdx_device_synchronize(int dev)

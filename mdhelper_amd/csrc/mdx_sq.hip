@@ -119,6 +119,80 @@ __global__ __launch_bounds__(SQ_THREADS) void sq_fourier_sum_f64_kernel(
         part[int64_t(sp) * n_q + qi] = make_double2(ac, as);
 }
 
+
+// Row sums of cos / sin of a caller-supplied matrix x[n_rows][n_cols] (the `q . r` arrays the reference's
+// trigonometric forms and its ISF take: accelerated.py:249-321, :323-627; structure.py:1238-1317).
+// HBM-streaming: one block walks a column segment of one row with coalesced 8-byte loads, one float64 sincos per
+// element; the partial (sum cos, sum sin) of every segment is written once — no atomics, fixed summation order.
+constexpr int TRIG_THREADS = 256;
+__global__ __launch_bounds__(TRIG_THREADS) void trig_rowsums_kernel(const double *__restrict__ x, int64_t n_cols,
+                                                                    int n_split, double2 *__restrict__ part)
+{
+    __shared__ double2 red[TRIG_THREADS / 64];
+    const int64_t row = blockIdx.y;
+    const int sp = blockIdx.x;
+    const int64_t per = ((n_cols + n_split - 1) / n_split + TRIG_THREADS - 1) / TRIG_THREADS * TRIG_THREADS;
+    const int64_t lo = sp * per, hi = min(n_cols, lo + per);
+    const double *__restrict__ xr = x + row * n_cols;
+    double ac = 0.0, as = 0.0;
+    for (int64_t c = lo + threadIdx.x; c < hi; c += TRIG_THREADS) {
+        double sn, cs;
+        const double v = xr[c];
+        if (fabs(v) < 1.0e8)
+            sincos_f64(v, sn, cs);
+        else                      // caller-supplied phases of any size: the library's full-range reduction
+            sincos(v, &sn, &cs);
+        ac += cs;
+        as += sn;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        ac += __shfl_down(ac, off, 64);
+        as += __shfl_down(as, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0)
+        red[threadIdx.x >> 6] = make_double2(ac, as);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double2 t = red[0];
+        for (int w = 1; w < TRIG_THREADS / 64; ++w) {
+            t.x += red[w].x;
+            t.y += red[w].y;
+        }
+        part[row * n_split + sp] = t;
+    }
+}
+
+__global__ void trig_fold_kernel(const double2 *__restrict__ part, int64_t n_rows, int n_split,
+                                 double *__restrict__ cos_out, double *__restrict__ sin_out)
+{
+    const int64_t row = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (row >= n_rows)
+        return;
+    double c = 0.0, s = 0.0;
+    for (int k = 0; k < n_split; ++k) {
+        c += part[row * n_split + k].x;
+        s += part[row * n_split + k].y;
+    }
+    if (cos_out) cos_out[row] = c;
+    if (sin_out) sin_out[row] = s;
+}
+
+// out[i][j] = q_i . r_j (accelerated.py:167-247: a[0] b[0] + a[1] b[1] + a[2] b[2], in that order)
+__global__ void inner_kernel(const double *__restrict__ q, int64_t n_q, const double *__restrict__ r, int64_t n,
+                             double *__restrict__ out)
+{
+    const int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t i = blockIdx.y;
+    if (j >= n)
+        return;
+    {
+#pragma clang fp contract(off)   // the reference's three products and two sums, no FMA
+        const double q0 = q[3 * i], q1 = q[3 * i + 1], q2 = q[3 * i + 2];
+        out[i * n + j] = (q0 * r[3 * j] + q1 * r[3 * j + 1]) + q2 * r[3 * j + 2];
+    }
+}
+
 }  // namespace
 
 struct mdx_sq {
@@ -455,6 +529,14 @@ int mdx_sq_result(mdx_sq_t h, double *ssf)
     return MDX_OK;
 }
 
+int mdx_sq_synchronize(mdx_sq_t h)
+{
+    MDX_REQUIRE(h, "NULL handle");
+    MDX_TRY(set_device(h->dev));
+    MDX_HIP(hipStreamSynchronize(h->stream));
+    return MDX_OK;
+}
+
 int mdx_sq_stats(mdx_sq_t h, int64_t *launches, double *kernel_ms)
 {
     MDX_REQUIRE(h, "NULL handle");
@@ -530,5 +612,117 @@ int mdx_fourier_sum(int dev, const double *wavevectors, int64_t n_q, const doubl
     }
     return MDX_OK;
 }
+
+// ---- row sums of cos / sin of caller-supplied phase matrices (accelerated.py:249-321, :323-627)
+static int trig_rowsums_device(int dev, const double *d_x, int64_t n_rows, int64_t n_cols, double *d_cos,
+                               double *d_sin, hipStream_t stream, DeviceBuffer &d_part)
+{
+    // enough blocks to fill the chip, whole 256-column pieces, at most 65 535 rows per launch
+    int n_split = 1;
+    while (n_rows * n_split < 2048 && n_split < 1024 && n_cols / (2 * n_split) >= 4 * TRIG_THREADS)
+        n_split *= 2;
+    const int64_t rows_max = 65535;
+    MDX_TRY(d_part.ensure(size_t(16) * std::min(n_rows, rows_max) * n_split));
+    for (int64_t r0 = 0; r0 < n_rows; r0 += rows_max) {
+        const int64_t nr = std::min(rows_max, n_rows - r0);
+        hipLaunchKernelGGL(trig_rowsums_kernel, dim3((unsigned)n_split, (unsigned)nr), dim3(TRIG_THREADS), 0, stream,
+                           d_x + r0 * n_cols, n_cols, n_split, d_part.as<double2>());
+        hipLaunchKernelGGL(trig_fold_kernel, dim3((unsigned)ceil_div(nr, 256)), dim3(256), 0, stream,
+                           d_part.as<double2>(), nr, n_split, d_cos ? d_cos + r0 : nullptr,
+                           d_sin ? d_sin + r0 : nullptr);
+    }
+    MDX_HIP(hipGetLastError());
+    return MDX_OK;
+}
+
+int mdx_trig_rowsums_device(int dev, const double *d_x, int64_t n_rows, int64_t n_cols, double *d_cos,
+                            double *d_sin)
+{
+    MDX_REQUIRE(d_x && (d_cos || d_sin), "NULL argument");
+    MDX_REQUIRE(n_rows >= 1 && n_cols >= 0, "bad size");
+    MDX_TRY(set_device(dev));
+    DeviceBuffer d_part;
+    const int rc = trig_rowsums_device(dev, d_x, n_rows, n_cols, d_cos, d_sin, nullptr, d_part);
+    const hipError_t e = hipDeviceSynchronize();
+    d_part.recycle();
+    MDX_TRY(rc);
+    MDX_HIP(e);
+    return MDX_OK;
+}
+
+int mdx_trig_rowsums(int dev, const double *x, int64_t n_rows, int64_t n_cols, double *cos_out, double *sin_out)
+{
+    MDX_REQUIRE(x && (cos_out || sin_out), "NULL argument");
+    MDX_REQUIRE(n_rows >= 1 && n_cols >= 0, "bad size");
+    MDX_TRY(set_device(dev));
+    // row slabs of <= 1 GiB: the upload of slab k + 1 (pinned ring, or one DMA out of page-locked memory) is
+    // queued behind the kernels of slab k on the same stream, the copy stream of the ring runs ahead of them
+    const int64_t slab_rows = std::max<int64_t>(1, std::min<int64_t>(n_rows, (int64_t(1) << 30) / std::max<int64_t>(8, 8 * n_cols)));
+    DeviceBuffer d_x[2], d_out, d_part;
+    hipStream_t stream = nullptr;
+    std::vector<double> host(size_t(2) * n_rows);
+    auto run = [&]() -> int {
+        MDX_TRY(stream_acquire(&stream));
+        MDX_TRY(d_out.ensure(size_t(16) * n_rows));
+        double *d_cos = d_out.as<double>(), *d_sin = d_cos + n_rows;
+        int k = 0;
+        for (int64_t r0 = 0; r0 < n_rows; r0 += slab_rows, ++k) {
+            const int64_t nr = std::min(slab_rows, n_rows - r0);
+            DeviceBuffer &buf = d_x[k & 1];
+            MDX_TRY(buf.ensure(size_t(8) * std::max<int64_t>(1, nr * n_cols)));
+            if (n_cols > 0)
+                MDX_TRY(device_stager(dev).upload(dev, stream, buf.ptr, x + r0 * n_cols, size_t(8) * nr * n_cols));
+            MDX_TRY(trig_rowsums_device(dev, buf.as<double>(), nr, n_cols, d_cos + r0, d_sin + r0, stream, d_part));
+        }
+        MDX_HIP(hipMemcpyAsync(host.data(), d_out.ptr, size_t(16) * n_rows, hipMemcpyDeviceToHost, stream));
+        MDX_HIP(hipStreamSynchronize(stream));
+        return MDX_OK;
+    };
+    const int rc = run();
+    (void)hipDeviceSynchronize();
+    if (stream)
+        stream_release(stream);
+    d_x[0].recycle();
+    d_x[1].recycle();
+    d_out.recycle();
+    d_part.recycle();
+    MDX_TRY(rc);
+    if (cos_out)
+        memcpy(cos_out, host.data(), size_t(8) * n_rows);
+    if (sin_out)
+        memcpy(sin_out, host.data() + n_rows, size_t(8) * n_rows);
+    return MDX_OK;
+}
+
+int mdx_inner(int dev, const double *wavevectors, int64_t n_q, const double *positions, int64_t n, double *out)
+{
+    MDX_REQUIRE(wavevectors && positions && out, "NULL argument");
+    MDX_REQUIRE(n_q >= 1 && n >= 1 && n_q <= 65535, "bad size");
+    MDX_TRY(set_device(dev));
+    DeviceBuffer dq, dp, dout;
+    hipStream_t stream = nullptr;
+    auto run = [&]() -> int {
+        MDX_TRY(stream_acquire(&stream));
+        MDX_TRY(dq.ensure(size_t(24) * n_q));
+        MDX_TRY(dp.ensure(size_t(24) * n));
+        MDX_TRY(dout.ensure(size_t(8) * n_q * n));
+        HostStager &ring = device_stager(dev);
+        MDX_TRY(ring.upload(dev, stream, dq.ptr, wavevectors, size_t(24) * n_q));
+        MDX_TRY(ring.upload(dev, stream, dp.ptr, positions, size_t(24) * n));
+        hipLaunchKernelGGL(inner_kernel, dim3((unsigned)ceil_div(n, 256), (unsigned)n_q), dim3(256), 0, stream,
+                           dq.as<double>(), n_q, dp.as<double>(), n, dout.as<double>());
+        MDX_HIP(hipGetLastError());
+        return ring.download(dev, stream, out, dout.ptr, size_t(8) * n_q * n);
+    };
+    const int rc = run();
+    (void)hipDeviceSynchronize();
+    if (stream)
+        stream_release(stream);
+    dq.recycle();
+    dp.recycle();
+    dout.recycle();
+    return rc;
+}
+
 
 }  // extern "C"

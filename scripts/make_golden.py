@@ -119,6 +119,21 @@ def make_fourier(acc):
     out["out_pythag"] = np.array([acc.pythagorean_trigonometric_identity_1d(row) for row in qr])
     out["out_pythag_cross"] = np.array(
         [acc.pythagorean_trigonometric_identity_1d_1d(r1, r2) for r1, r2 in zip(qr, qr2)])
+    # the row sums the trigonometric forms and the ISF are built from (accelerated.py:323-627), every variant
+    out["out_inner_parallel"] = acc.inner_parallel_2d_2d(qs, rs2)
+    out["out_cosine_sum_1d"] = np.array(acc.cosine_sum_1d(qr[3]))
+    out["out_sine_sum_1d"] = np.array(acc.sine_sum_1d(qr[3]))
+    out["out_cosine_sum_2d"] = acc.cosine_sum_2d(qr)
+    out["out_sine_sum_2d"] = acc.sine_sum_2d(qr)
+    out["out_cosine_sum_parallel_2d"] = acc.cosine_sum_parallel_2d(qr2)
+    out["out_sine_sum_parallel_2d"] = acc.sine_sum_parallel_2d(qr2)
+    for name in ("cosine_sum_inplace_2d", "cosine_sum_inplace_parallel_2d", "sine_sum_inplace_2d",
+                 "sine_sum_inplace_parallel_2d"):
+        hold = np.full(len(qs), np.nan)
+        getattr(acc, name)(qr2, hold)
+        out["out_" + name] = hold
+    out["out_dot_1d_1d"] = np.array(acc.dot_1d_1d(qs[5], rs[7]))
+    out["out_delta_1d_1d"] = np.array(acc.delta_fourier_transform_1d_1d(qs[5], rs[7]))
     np.savez_compressed(OUT / "fourier_ref.npz", **out)
     print("fourier:", len(out), "arrays")
 

@@ -17,3 +17,36 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def _runtime_problems():
+    """One process, one ROCm runtime: the HIP / HSA / rocFFT / RCCL libraries are each mapped
+    once, from the installation libmdx.so was built for — the stack bench.py and smoke() run on."""
+    if "torch" in sys.modules:
+        return ["`torch` was imported into the pytest process (its wheel bundles another ROCm runtime)"]
+    from mdhelper_amd import _lib
+    if _lib._lib is None:                   # nothing loaded the library (yet): nothing to check
+        return []
+    return _lib.runtime()["problems"]
+
+
+def pytest_collection_finish(session):
+    # collection imports every test module: none of them may have brought a second runtime in
+    problems = _runtime_problems()
+    if problems:
+        pytest.exit("ROCm runtime check failed after collection: " + "; ".join(problems), returncode=3)
+
+
+@pytest.fixture(autouse=True)
+def _one_rocm_runtime(request):
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        problems = _runtime_problems()
+        assert not problems, "ROCm runtime check: " + "; ".join(problems)
+
+
+def pytest_terminal_summary(terminalreporter):
+    from mdhelper_amd import _lib
+    if _lib._lib is not None:
+        r = _lib.runtime_summary()
+        terminalreporter.write_line("libmdx runtime: " + ", ".join(f"{k}={v}" for k, v in r.items()))

@@ -77,3 +77,32 @@ def test_product_never_imports_the_oracle():
             text = path.read_text()
             assert "import oracle" not in text and "from oracle" not in text, path
             assert "rdf_oracle" not in text and "oracle/" not in text, path
+
+
+def test_one_rocm_runtime_and_a_foreign_one_is_refused():
+    """One process, one runtime (reference src/mdhelper/analysis/base.py:137-172 runs in one process by
+    construction): libmdx.so's HIP / rocFFT / RCCL calls are bound to the installation it was built for and every
+    library is mapped once; a process that loaded another copy first (torch's wheel bundles one) is refused with an
+    ImportError that says so; nothing under mdhelper_amd/ or bench.py / __graft_entry__.py imports torch."""
+    import subprocess
+    import sys
+    from mdhelper_amd import _lib
+    r = _lib.runtime()
+    assert r["problems"] == [], r["problems"]
+    root = r["rocm_root"]
+    for key in ("libamdhip64", "librocfft", "librccl"):
+        assert r[key].startswith(root + "/"), (key, r[key])
+        assert r["mapped"][key.split(".")[0]] == [r[key]]
+    assert r["rccl_version"] > 20000 and r["hip_runtime_version"] > 0
+    s = _lib.runtime_summary()
+    assert s["one_runtime"] is True and isinstance(s["libhsa-runtime64"], str)
+    child = subprocess.run(
+        [sys.executable, "-c",
+         "import torch, sys; sys.path.insert(0, %r)\n"
+         "from mdhelper_amd import _lib\n"
+         "try:\n    _lib.lib()\nexcept ImportError as e:\n    print('REFUSED', e)\n" % str(ROOT)],
+        capture_output=True, text=True, timeout=600)
+    assert "REFUSED" in child.stdout and "torch/lib/libamdhip64" in child.stdout, child.stdout + child.stderr
+    for path in [*(ROOT / "mdhelper_amd").rglob("*.py"), ROOT / "bench.py", ROOT / "__graft_entry__.py"]:
+        text = path.read_text()
+        assert not re.search(r"^\s*(import torch|from torch)", text, flags=re.M), path

@@ -205,21 +205,30 @@ def test_rdf_cell_random_walk_frames_match_filter():
         eng.close()
 
 
-def test_rdf_reference_test_geometry():
-    """tests/test_analysis_structure.py:21-40 of the reference, through mdx_radial_histogram."""
-    rng = np.random.default_rng(11)
-    L = 20
-    half_L = L // 2
-    dims = np.array((L, L, L, 90, 90, 90), dtype=int)
-    origin = half_L * np.ones(3)
-    norm = half_L * rng.random(1000)
-    neighbors = rng.random((1000, 3))
-    neighbors *= norm[:, None] / np.linalg.norm(neighbors, axis=1, keepdims=True)
-    neighbors += dims[:3] / 2
+@pytest.mark.parametrize("seed", (0, 5, 11, 17, 23, 39))
+def test_rdf_reference_test_geometry(seed):
+    """The reference's own exact-count test (reference tests/test_analysis_structure.py:21-40), asserted as the
+    reference asserts it — ``np.array_equal(np.histogram(norm, ...)[0], radial_histogram(origin, neighbors, ...))`` —
+    on the HIP path: through ``mdx_radial_histogram``, through the module function with the reference's argument
+    forms (``pos1`` of shape (3,), integer ``dims``), and through the class on a one-frame universe.  Seeds and the
+    reason a float32 coordinate cannot move a count there: tests/test_oracle_rdf.py::reference_test_geometry."""
+    import mdhelper_amd
+    from mdhelper_amd.analysis import RadialDistributionFunction, structure
+    from test_oracle_rdf import reference_test_geometry
+    origin, neighbors, half_L, dims, counts, margin = reference_test_geometry(seed)
+    assert margin > 1e-5 and counts.sum() == 1000
     edges = np.linspace(0, half_L + 1, half_L + 1)
-    got = _core.radial_histogram_device(origin, neighbors, half_L, edges, dims)
-    want = orf.radial_histogram_ref(origin, neighbors, half_L, (0, half_L + 1), dims)
-    assert np.array_equal(got, want) and got.sum() == 1000
+    assert np.array_equal(counts, _core.radial_histogram_device(origin, neighbors, half_L, edges, dims))
+    assert np.array_equal(counts, structure.radial_histogram(origin, neighbors, n_bins=half_L,
+                                                             range=(0, half_L + 1), dims=dims))
+    for algo in ALGOS:
+        got = _gpu_hist(origin[None].astype(np.float32), neighbors.astype(np.float32), half_L, (0, half_L + 1),
+                        dims.astype(np.float32), None, algo)
+        assert np.array_equal(counts, got), algo
+    u = mdhelper_amd.ArrayUniverse(np.concatenate([origin[None], neighbors])[None].astype(np.float32),
+                                   dims.astype(np.float32))
+    rdf = RadialDistributionFunction(u.atoms[:1], u.atoms[1:], n_bins=half_L, range=(0, half_L + 1)).run()
+    assert np.array_equal(counts, rdf.results.counts)
 
 
 def test_rdf_bad_cell_rejected_and_empty():
@@ -250,6 +259,64 @@ def test_fourier_sum_matches_golden(golden_dir):
     g = np.load(golden_dir / "fourier_ref.npz")
     got = _core.fourier_sum_device(g["qs"], g["rs"])
     assert np.allclose(got, g["out_fourier_sum"], rtol=1e-9, atol=1e-9)
+
+
+def test_accelerated_drop_ins_match_the_reference_vectors(golden_dir):
+    """Every function of the reference's ``algorithm/accelerated.py`` (:12-627) by its own name, and the public
+    static methods ``StructureFactor.ssf_trigonometric_2d`` / ``psf_trigonometric_2d_2d`` (structure.py:1238-1317),
+    computed on the device, against vectors the reference's own loop bodies produced (scripts/make_golden.py)."""
+    from mdhelper_amd.algorithm import accelerated as acc
+    from mdhelper_amd.analysis import StructureFactor
+    g = np.load(golden_dir / "fourier_ref.npz")
+    qs, rs, rs2 = g["qs"], g["rs"], g["rs2"]
+    tol = dict(rtol=1e-10, atol=1e-10)
+    assert np.allclose(acc.delta_fourier_transform_sum_2d_2d(qs, rs), g["out_fourier_sum"], **tol)
+    assert np.allclose(acc.delta_fourier_transform_sum_parallel_2d_2d(qs, rs2), g["out_fourier_sum_parallel"], **tol)
+    qr = acc.inner_2d_2d(qs, rs)
+    qr2 = acc.inner_parallel_2d_2d(qs, rs2)
+    assert np.allclose(qr, g["out_inner"], rtol=0, atol=1e-12)
+    assert np.allclose(qr2, g["out_inner_parallel"], rtol=0, atol=1e-12)
+    assert np.allclose(StructureFactor.ssf_trigonometric_2d(g["out_inner"]), g["out_pythag"], **tol)
+    assert np.allclose(StructureFactor.psf_trigonometric_2d_2d(g["out_inner"], g["out_inner_parallel"]),
+                       g["out_pythag_cross"], **tol)
+    assert np.allclose([acc.pythagorean_trigonometric_identity_1d(row) for row in qr[:5]], g["out_pythag"][:5], **tol)
+    assert np.allclose([acc.pythagorean_trigonometric_identity_1d_1d(a, b) for a, b in zip(qr[:5], qr2[:5])],
+                       g["out_pythag_cross"][:5], **tol)
+    assert np.allclose(acc.cosine_sum_2d(qr), g["out_cosine_sum_2d"], **tol)
+    assert np.allclose(acc.sine_sum_2d(qr), g["out_sine_sum_2d"], **tol)
+    assert np.allclose(acc.cosine_sum_parallel_2d(qr2), g["out_cosine_sum_parallel_2d"], **tol)
+    assert np.allclose(acc.sine_sum_parallel_2d(qr2), g["out_sine_sum_parallel_2d"], **tol)
+    assert np.isclose(acc.cosine_sum_1d(qr[3]), g["out_cosine_sum_1d"], **tol)
+    assert np.isclose(acc.sine_sum_1d(qr[3]), g["out_sine_sum_1d"], **tol)
+    for name in ("cosine_sum_inplace_2d", "cosine_sum_inplace_parallel_2d", "sine_sum_inplace_2d",
+                 "sine_sum_inplace_parallel_2d"):
+        hold = np.full(len(qs), np.nan)
+        getattr(acc, name)(qr2, hold)
+        assert np.allclose(hold, g["out_" + name], **tol), name
+    assert np.isclose(acc.dot_1d_1d(qs[5], rs[7]), g["out_dot_1d_1d"], rtol=1e-15)
+    assert np.isclose(acc.delta_fourier_transform_1d_1d(qs[5], rs[7]), g["out_delta_1d_1d"], rtol=1e-14)
+    with pytest.raises(ValueError):
+        StructureFactor.psf_trigonometric_2d_2d(qr, qr2[:3])
+
+
+def test_trig_rowsums_at_size_and_at_large_phases():
+    """mdx_trig_rowsums beyond the fixture: ragged columns split across blocks, more rows than one launch's grid
+    holds, row slabs, an empty row set of columns, and phases past the fast reduction's range — against numpy."""
+    rng = np.random.default_rng(77)
+    for shape in ((3, 100_003), (70_000, 7), (257, 4099), (5, 0), (1, 1)):
+        x = rng.uniform(-300.0, 300.0, size=shape)
+        c, s = _core.trig_rowsums_device(x)
+        assert np.allclose(c, np.cos(x).sum(axis=1), rtol=1e-10, atol=1e-9 * max(1, shape[1]) ** 0.5), shape
+        assert np.allclose(s, np.sin(x).sum(axis=1), rtol=1e-10, atol=1e-9 * max(1, shape[1]) ** 0.5), shape
+    x = rng.uniform(-1e12, 1e12, size=(4, 1000))
+    c, s = _core.trig_rowsums_device(x)
+    assert np.allclose(c, np.cos(x).sum(axis=1), atol=1e-9) and np.allclose(s, np.sin(x).sum(axis=1), atol=1e-9)
+    only_c, none = _core.trig_rowsums_device(x, sin=False)
+    assert none is None and np.array_equal(only_c, c)
+    q = rng.normal(size=(40, 3))
+    r = rng.normal(size=(1234, 3)) * 10
+    want = (q[:, None, 0] * r[None, :, 0] + q[:, None, 1] * r[None, :, 1]) + q[:, None, 2] * r[None, :, 2]
+    assert np.allclose(_core.inner_device(q, r), want, rtol=0, atol=1e-12)
 
 
 def test_sq_engine_partial_and_total():

@@ -125,3 +125,84 @@ def test_engine_cross_msd_equals_the_oracle():
         want = oc.msd_fft_ref(sums[i], axis=1) if i == j else oc.msd_fft_ref(sums[i], sums[j], axis=1)
         scale = np.sqrt(np.abs(oc.msd_fft_ref(sums[i], axis=1) * oc.msd_fft_ref(sums[j], axis=1))).max()
         assert np.allclose(got[k], want, rtol=1e-8, atol=1e-9 * scale), (i, j)
+
+
+def test_host_registration_is_page_aligned_tracked_and_exclusive():
+    """registrations are widened to whole pages and tracked; a range that shares a page with a live
+    registration is refused, an unknown pointer cannot be unregistered, and a buffer that starts in the middle of
+    a page (what malloc / numpy hand out) registers, uploads by DMA and unregisters cleanly."""
+    raw = np.zeros((6 << 20) + 4096, dtype=np.uint8)
+    off = (-raw.ctypes.data) % 4096 + 40                  # 40 bytes into a page
+    h = raw[off:off + (6 << 20)].view(np.float32)
+    h[:] = np.arange(h.size, dtype=np.float32)
+    assert h.ctypes.data % 4096 == 40
+    check(lib().mdx_host_register(0, h.ctypes.data, h.nbytes))
+    try:
+        # the same pages again, and a neighbour inside the first page: refused while the first one lives
+        with pytest.raises(RuntimeError, match="shares pages"):
+            check(lib().mdx_host_register(0, h.ctypes.data, h.nbytes))
+        with pytest.raises(RuntimeError, match="shares pages"):
+            check(lib().mdx_host_register(0, h.ctypes.data - 32, 16))
+        with pytest.raises(ValueError, match="was not registered"):
+            check(lib().mdx_host_unregister(0, h.ctypes.data + 4096))
+        d = _core.DeviceArray.upload(h)
+        assert np.array_equal(d.to_host(), h)
+        d.free()
+    finally:
+        check(lib().mdx_host_unregister(0, h.ctypes.data))
+    with pytest.raises(ValueError, match="was not registered"):
+        check(lib().mdx_host_unregister(0, h.ctypes.data))
+    # the pages are ordinary pageable memory again: a fresh registration of an overlapping range works
+    check(lib().mdx_host_register(0, raw.ctypes.data, raw.nbytes))
+    check(lib().mdx_host_unregister(0, raw.ctypes.data))
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_cross_correlation_of_large_inputs_is_ordered(pinned):
+    """mdx_correlate with inputs >= 1 MiB each — `b` used to be uploaded, on another stream, into the
+    buffer the padding kernel of `a` was still reading (page-locked `b`: the DMA starts at once).  Both inputs have
+    their own buffers now and the whole call is ordered on one stream.  Checked against the oracle's restatement
+    of correlation.py:185-197 for cross-correlations, positive and negative lags."""
+    from oracle import correlation as oc
+    rng = np.random.default_rng(41)
+    n_series, n_t = 96, 4096                               # 3 MiB per input
+    a = np.cumsum(rng.normal(size=(n_series, n_t)), axis=1)
+    b = rng.normal(size=(n_series, n_t))
+    if pinned:
+        check(lib().mdx_host_register(0, a.ctypes.data, a.nbytes))
+        check(lib().mdx_host_register(0, b.ctypes.data, b.nbytes))
+    try:
+        for _ in range(3):
+            pos, neg = _core.correlate_device(a, b, negative=True)
+    finally:
+        if pinned:
+            check(lib().mdx_host_unregister(0, a.ctypes.data))
+            check(lib().mdx_host_unregister(0, b.ctypes.data))
+    w = n_t - np.arange(n_t)
+    full = oc.correlation_fft_ref(a.T, b.T, axis=0)       # [2 n_t - 1, n_series], lags -(n_t-1) .. n_t-1, per-lag mean
+    want_pos = full[n_t - 1:].T * w
+    want_neg = full[n_t - 1::-1].T * w
+    scale = np.abs(want_pos).max()
+    assert np.allclose(pos, want_pos, rtol=1e-9, atol=1e-10 * scale)
+    assert np.allclose(neg, want_neg, rtol=1e-9, atol=1e-10 * scale)
+
+
+def test_cross_msd_of_more_rows_than_one_grid_holds():
+    """mdx_msd_cross batches its (pair, block) rows: 13 groups at 1 000 blocks = 91 pairs x 1 000 rows
+    (> 65 535, the grid's y extent) used to be refused.  Spot rows against the oracle."""
+    from oracle import correlation as oc
+    rng = np.random.default_rng(43)
+    B, Tb, G = 1000, 6, 13
+    pos = np.cumsum(rng.normal(0, 0.3, (B * Tb, G, 3)), axis=0)
+    eng = _core.MsdEngine(Tb, B, G)
+    for g in range(G):
+        eng.push(g, pos, g, 1)
+    pairs = [(i, j) for i in range(G) for j in range(i, G)]
+    assert len(pairs) * B > 65535
+    got = eng.cross(pairs)
+    eng.close()
+    sums = [pos[:, g].reshape(B, Tb, 3) for g in range(G)]
+    for k in (0, 1, 12, 13, 45, 90):
+        i, j = pairs[k]
+        want = oc.msd_fft_ref(sums[i], axis=1) if i == j else oc.msd_fft_ref(sums[i], sums[j], axis=1)
+        assert np.allclose(got[k], want, rtol=1e-8, atol=1e-9 * np.abs(want).max()), (i, j)

@@ -179,7 +179,8 @@ def test_direct_correlations_match_oracle():
 
 
 def test_correlation_argument_errors():
-    """tests/test_algorithm_correlation.py:49-65, 445-461 of the reference (raised before any GPU work)."""
+    """tests/test_algorithm_correlation.py:49-65, 162-178 (ACF), 238-260, 324-346 (CCF), 445-461, 504-520 (MSD) of
+    the reference: every error case, raised before any GPU work."""
     for fn in (correlation.correlation_fft, correlation.correlation_shift):
         with pytest.raises(ValueError):
             fn(np.empty(0))
@@ -189,6 +190,17 @@ def test_correlation_argument_errors():
             fn(np.empty((2, 2, 2, 2, 2)))
         with pytest.raises(ValueError):
             fn(np.empty((2, 2, 2)), axis=2)
+        # cross-correlations (:238-260, :324-346)
+        with pytest.raises(ValueError):
+            fn(np.empty(0), np.empty(0))
+        with pytest.raises(ValueError):
+            fn(np.empty((0, 3)), np.empty((0, 3)))
+        with pytest.raises(ValueError):
+            fn(np.empty((2, 2, 2, 2, 2)), np.empty((2, 2, 2, 2, 2)))
+        with pytest.raises(ValueError):
+            fn(np.empty((2, 3)), np.empty((3, 2)))
+        with pytest.raises(ValueError):
+            fn(np.empty((2, 2, 2)), np.empty((2, 2, 2)), axis=2)
     for fn in (correlation.msd_fft, correlation.msd_shift):
         with pytest.raises(ValueError):
             fn(np.empty(0))
