@@ -265,6 +265,59 @@ __global__ void msd_real_to_complex_kernel(const double *__restrict__ P, int64_t
         C[i] = make_double2(P[i], 0.0);
 }
 
+// MSD_m = S_m - 2 A_m of one (group, block) row on the device (correlation.py:621-648, summed over the particles):
+//   S_m (T_b - m) = 2 sum_k D_k - sum_{k=1..m} (D_{k-1} + D_{T_b-k}),   A_m = acf[m] / n_fft,
+// out[m] = (2 total - run_m) / (T_b - m) - 2 A_m / (T_b - m).  One block per row: a block-wide sum for `total`, then
+// thread t owns the lags [t L, (t + 1) L) — segment sums, an exclusive scan of the 1 024 segment sums in LDS, and a
+// second walk that writes the row.  (The host used to do this after a pageable copy of acf and D: ~1 ms per analysis
+// at C4 size, against ~0.1 ms here plus the copy of the finished row.)
+constexpr int FINISH_THREADS = 1024;
+__global__ __launch_bounds__(FINISH_THREADS) void msd_finish_kernel(const double *__restrict__ acf, int64_t acf_stride,
+                                                                   const double *__restrict__ D, int64_t t_block,
+                                                                   double inv_n, double *__restrict__ out)
+{
+    __shared__ double red[FINISH_THREADS];
+    const int tid = threadIdx.x;
+    const int64_t row = blockIdx.x;
+    const double *d = D + row * t_block;
+    const double *a = acf + row * acf_stride;
+    double *o = out + row * t_block;
+    const int64_t L = (t_block + FINISH_THREADS - 1) / FINISH_THREADS;
+    const int64_t lo = min<int64_t>(int64_t(tid) * L, t_block), hi = min<int64_t>(lo + L, t_block);
+    double part = 0.0, seg = 0.0;
+    for (int64_t m = lo; m < hi; ++m) {
+        part += d[m];
+        if (m > 0)
+            seg += d[m - 1] + d[t_block - m];
+    }
+    // total of D: tree over the threads
+    red[tid] = part;
+    __syncthreads();
+    for (int w = FINISH_THREADS / 2; w > 0; w >>= 1) {
+        if (tid < w)
+            red[tid] += red[tid + w];
+        __syncthreads();
+    }
+    const double total = red[0];
+    __syncthreads();
+    // exclusive scan of the segment sums (Hillis-Steele on 1 024 values)
+    red[tid] = seg;
+    __syncthreads();
+    for (int w = 1; w < FINISH_THREADS; w <<= 1) {
+        const double v = tid >= w ? red[tid - w] : 0.0;
+        __syncthreads();
+        red[tid] += v;
+        __syncthreads();
+    }
+    double run = red[tid] - seg;
+    for (int64_t m = lo; m < hi; ++m) {
+        if (m > 0)
+            run += d[m - 1] + d[t_block - m];
+        const double w = double(t_block - m);
+        o[m] = (2.0 * total - run) / w - 2.0 * (a[m] * inv_n) / w;
+    }
+}
+
 // [n_series][n_t] -> zero-padded [n_series][n_fft]
 __global__ void corr_pad_kernel(const double *__restrict__ in, int64_t n_series, int64_t n_t,
                                 int64_t n_fft, double *__restrict__ out)
@@ -336,7 +389,7 @@ struct mdx_msd {
     int n_blocks = 0, n_groups = 0;
     FftCache fft;
     // accumulators: power [G][B][nc] + D [G][B*T_b] contiguous (one all-reduce), traj [G][B*T_b][3]
-    DeviceBuffer d_acc, d_traj, d_series, d_spec, d_stage, d_inv_in, d_inv_out;
+    DeviceBuffer d_acc, d_traj, d_series, d_spec, d_stage, d_inv_in, d_inv_out, d_finish;
     DeviceBuffer d_f32, d_index, d_prev, d_image;   // trajectory-file path: frames, unwrap state
     DeviceBuffer d_cross_f;                         // spectra of the summed trajectories (mdx_msd_cross)
     DeviceBuffer d_xstart, d_seg;                   // ... of the segment-parallel walk (msd_launch_unwrap)
@@ -348,6 +401,7 @@ struct mdx_msd {
     DeviceBuffer d_mol_offsets, d_mol_masses, d_mol_total, d_mol_com;
     bool own_fft = false;                           // n_fft is one of the shapes of mdx_msd_fft.hpp
     bool fused_sums = false;                        // pass A of this shape also forms the per-frame sums
+    bool single = false;                            // <= 800 frames per block: one pass, no Y (msd_fft_single400_kernel)
     DeviceBuffer d_part;                            // its partial-sum records
     msdfft::Shape shape;
     DeviceBuffer d_tw, d_pfull;                     // twiddle tables [2][512], full-spectrum sums [B][N]
@@ -373,10 +427,11 @@ static int msd_push_device(mdx_msd *h, int group, const double *d_pos, int64_t n
     // free memory only when the buffers the handle already holds do not take the whole push as one chunk:
     // hipMemGetInfo costs the host 1 - 2 ms, and right after a synchronisation point (every analysis starts with
     // one) the device idles for as long.
-    const int64_t per_atom = h->own_fft ? 3 * B * h->n_fft * 8   // Y: one complex per two reals
-                                        : 3 * B * (h->n_fft * 8 + h->nc * 16);
+    const int64_t per_atom = h->single    ? 0                    // nothing but the accumulators
+                             : h->own_fft ? 3 * B * h->n_fft * 8   // Y: one complex per two reals
+                                          : 3 * B * (h->n_fft * 8 + h->nc * 16);
     int64_t chunk = count;
-    if (size_t(count + 6) * per_atom > h->d_series.bytes + h->d_spec.bytes) {
+    if (!h->single && size_t(count + 6) * per_atom > h->d_series.bytes + h->d_spec.bytes) {
         size_t free_b = 0, total_b = 0;
         MDX_HIP(hipMemGetInfo(&free_b, &total_b));
         free_b += h->d_series.bytes + h->d_spec.bytes + cached_device_bytes(h->dev);
@@ -386,7 +441,9 @@ static int msd_push_device(mdx_msd *h, int group, const double *d_pos, int64_t n
     // a handful of equal chunks keeps the rocFFT plan cache small
     const int64_t n_chunks = ceil_div(count, chunk);
     chunk = ceil_div(count, n_chunks);
-    if (h->own_fft) {
+    if (h->single) {
+        MDX_TRY(h->d_part.ensure(msdfft::single_part_bytes(h->shape, B)));
+    } else if (h->own_fft) {
         const int64_t pmul = int64_t(msdfft::PG) * msdfft::pair_group_multiple(h->shape);
         const int64_t p_pad_max = ceil_div(ceil_div(chunk * 3 + 15, 2), pmul) * pmul;   // (+ 15: head)
         MDX_TRY(h->d_spec.ensure(size_t(B) * h->n_fft * p_pad_max * 16));
@@ -400,7 +457,7 @@ static int msd_push_device(mdx_msd *h, int group, const double *d_pos, int64_t n
     for (int64_t a0 = 0; a0 < count; a0 += chunk) {
         const int64_t c = std::min(chunk, count - a0);
         const int64_t n_elem = c * 3;
-        if (!h->fused_sums)
+        if (!h->fused_sums && !h->single)
             hipLaunchKernelGGL(msd_sums_kernel, dim3((unsigned)(B * h->t_block)), dim3(192), 0, h->stream,
                                d_pos, n_total, first + a0, c, zero_dims, h->traj(group), h->dsq(group));
         if (h->own_fft) {
@@ -412,13 +469,24 @@ static int msd_push_device(mdx_msd *h, int group, const double *d_pos, int64_t n
             // rows whose length is a multiple of 128 bytes (and positions from hipMalloc): a chunk that starts
             // in the middle of a line is entered `head` coordinates early, so that pass A's 128-byte pieces
             // are whole lines (msd_fft_cols400_fused_kernel); the head is staged as zeros
-            const int head = (h->fused_sums && msdfft::aligns_head(h->shape) && (n_total * 3) % 16 == 0 &&
+            const int head = ((h->single || (h->fused_sums && msdfft::aligns_head(h->shape))) && (n_total * 3) % 16 == 0 &&
                               (reinterpret_cast<uintptr_t>(d_pos) & 127u) == 0)
                                  ? int(((first + a0) * 3) % 16)
                                  : 0;
             const int64_t ne = c * 3 + head;
             const int64_t pmul = int64_t(msdfft::PG) * msdfft::pair_group_multiple(h->shape);
             const int p_pad = (int)(ceil_div(ceil_div(ne, 2), pmul) * pmul);
+            if (h->single) {
+                // one pass: positions -> |F|^2 sums and per-frame sums, nothing written in between
+                const int parts = msdfft::launch_single(h->shape, h->stream, d_pos, n_total, first + a0, ne, h->t_block, B,
+                                                        zero_dims, p_pad, tw_r1, twN, h->d_pfull.as<double>(),
+                                                        h->d_part.as<double2>(), h->traj(group), h->dsq(group), head);
+                hipLaunchKernelGGL(msdfft::msd_power_fold_kernel, dim3((unsigned)ceil_div(h->nc, 256), (unsigned)B),
+                                   dim3(256), 0, h->stream, h->d_pfull.as<double>(), h->shape.r1, h->shape.r2, parts,
+                                   h->nc, h->power(group));
+                h->bytes_moved += c * 3 * B * h->t_block * 8;      // the positions, once
+                continue;
+            }
             msdfft::launch(h->shape, h->stream, d_pos, n_total, first + a0, ne, h->t_block, B, zero_dims, p_pad,
                            tw_r1, tw_r2, twN, h->d_spec.as<double2>(), h->d_pfull.as<double>(), 0,
                            h->fused_sums ? h->d_part.as<double2>() : nullptr, h->traj(group), h->dsq(group), head);
@@ -961,9 +1029,9 @@ int mdx_msd_create(mdx_msd_t *out, int dev, int64_t n_frames_block, int n_blocks
         while (p < 2 * n_frames_block)
             p <<= 1;
         int64_t own_len = 0;
-        if (!getenv("MDX_MSD_ROCFFT") && n_frames_block > 200) {
+        if (!getenv("MDX_MSD_ROCFFT")) {
             // the shortest own length that covers 2 N_t
-            static const int64_t lengths[] = {800, 1600, 3200, 6400, int64_t(1) << 13, 12800, int64_t(1) << 14, 25600, int64_t(1) << 15, 51200,
+            static const int64_t lengths[] = {400, 800, 1600, 3200, 6400, int64_t(1) << 13, 12800, int64_t(1) << 14, 25600, int64_t(1) << 15, 51200,
                                               int64_t(1) << 16, 102400, 204800, int64_t(1) << 18, 409600, int64_t(1) << 19,
                                               int64_t(1) << 20};
             for (int64_t len : lengths)
@@ -989,6 +1057,9 @@ int mdx_msd_create(mdx_msd_t *out, int dev, int64_t n_frames_block, int n_blocks
         h->shape = msdfft::shape_for(h->n_fft);
         h->own_fft = h->shape.r1 != 0 && !getenv("MDX_MSD_ROCFFT");
         h->fused_sums = h->own_fft && msdfft::fuses_sums(h->shape);
+        // blocks of <= 800 frames: the single-pass kernel (MDX_MSD_TWO_PASS=1, test hook: the two-pass pipeline for
+        // 800 and 1 600 points; 400 points has no two-pass form)
+        h->single = h->own_fft && msdfft::single_pass(h->shape) && (h->shape.r2 == 1 || !getenv("MDX_MSD_TWO_PASS"));
         if (h->own_fft) {
             const int r1 = h->shape.r1, r2 = h->shape.r2;
             std::vector<double> tw;
@@ -1008,7 +1079,8 @@ int mdx_msd_create(mdx_msd_t *out, int dev, int64_t n_frames_block, int n_blocks
                 break;
             }
             if ((rc = h->d_pfull.ensure(size_t(8) * n_blocks * h->n_fft *
-                                        msdfft::rows_parts(h->shape, n_blocks))) != MDX_OK) break;
+                                        (h->single ? msdfft::single_splits(n_blocks)
+                                                   : msdfft::rows_parts(h->shape, n_blocks)))) != MDX_OK) break;
         }
     } while (0);
     if (rc != MDX_OK) {
@@ -1029,7 +1101,7 @@ int mdx_msd_destroy(mdx_msd_t h)
     h->timer.destroy();
     h->fft.destroy();
     // (the stream has been synchronised: the blocks and the stream go back to the per-device pools)
-    for (DeviceBuffer *b : {&h->d_acc, &h->d_traj, &h->d_series, &h->d_spec, &h->d_stage,
+    for (DeviceBuffer *b : {&h->d_acc, &h->d_traj, &h->d_series, &h->d_spec, &h->d_stage, &h->d_finish,
                             &h->d_inv_in, &h->d_inv_out, &h->d_f32, &h->d_index, &h->d_prev, &h->d_xstart, &h->d_seg,
                             &h->d_image, &h->d_tw, &h->d_pfull, &h->d_part, &h->d_masses, &h->d_com_x,
                             &h->d_shift, &h->d_mol_offsets, &h->d_mol_masses, &h->d_mol_total,
@@ -1411,6 +1483,19 @@ static int msd_result(mdx_msd_t h, double *msd_self_sum, double *acf_sum, double
                        h->d_inv_in.as<double2>());
     MDX_TRY(h->fft.exec(1, GB, h->d_inv_in.ptr, h->d_inv_out.ptr, h->stream));
     h->timer.end(ev);
+    const double inv_n = 1.0 / double(h->n_fft);
+    if (!acf_sum) {
+        // the S_m recurrence on the device; the finished rows come back in one copy through the pinned ring
+        MDX_TRY(h->d_finish.ensure(size_t(8) * GB * Tb));
+        hipEvent_t ev2 = h->timer.begin();
+        hipLaunchKernelGGL(msd_finish_kernel, dim3((unsigned)GB), dim3(FINISH_THREADS), 0, h->stream,
+                           h->d_inv_out.as<double>(), h->n_fft, h->dsq(0), Tb, inv_n, h->d_finish.as<double>());
+        h->timer.end(ev2);
+        MDX_HIP(hipGetLastError());
+        MDX_TRY(device_stager(h->dev).download(h->dev, h->stream, msd_self_sum, h->d_finish.ptr, size_t(8) * GB * Tb));
+        h->timer.collect();
+        return MDX_OK;
+    }
     std::vector<double> acf(size_t(GB) * Tb), D(size_t(GB) * Tb);
     MDX_HIP(hipMemcpy2DAsync(acf.data(), size_t(Tb) * 8, h->d_inv_out.ptr, size_t(h->n_fft) * 8,
                              size_t(Tb) * 8, (size_t)GB, hipMemcpyDeviceToHost, h->stream));
@@ -1418,7 +1503,6 @@ static int msd_result(mdx_msd_t h, double *msd_self_sum, double *acf_sum, double
     MDX_HIP(hipStreamSynchronize(h->stream));
     h->timer.collect();
     // MSD_m = S_m - 2 A_m   (correlation.py:621-648, summed over the particles)
-    const double inv_n = 1.0 / double(h->n_fft);
     if (acf_sum)   // sum over particles and dimensions of sum_k x(k) x(k+m), not normalised
         for (int64_t i = 0; i < GB * Tb; ++i)
             acf_sum[i] = acf[size_t(i)] * inv_n;

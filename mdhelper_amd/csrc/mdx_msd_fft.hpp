@@ -1250,6 +1250,256 @@ __global__ __launch_bounds__(256) void msd_power_fold_kernel(const double *__res
     P[int64_t(b) * nc + k] += s;
 }
 
+
+// ------------------------------------------------------------------------------ single pass (N = 400, 800, 1 600)
+// Blocks of at most 800 frames: the whole transform of a pair fits in LDS, so `Y` never exists — the positions are
+// read ONCE from HBM and nothing else moves (the two-pass pipeline moves 5.1 x that; blocks of <= 200 frames went
+// through rocFFT at ~17 x).  N = 400 R2 (R2 = 1, 2, 4), at most LIVE = 200 R2 live frames.  Decimation in frequency
+// over the zero-padded input: X[R2 j + r] = DFT_400(y_r)[j] with
+//     y_r[n] = (sum_{q < R2 / 2} x[n + 400 q] (-i)^(q r)) W_N^(r n),   n < 400
+// (q >= R2 / 2: the padding), so a pair costs R2 in-place 400-point transforms (the dif stages 10, 10, 4 of pass A)
+// by ONE wave, and |X|^2 is added up in registers over all the pair groups a block walks — slot lane + 64 i of
+// sub-transform r; the bit-reversal is undone once, when the block writes its sums.
+//
+// grid (splits, blocks of the trajectory): block (s, b) takes pair groups s, s + splits, ... of trajectory block b.
+// Per pair group: 512 threads load the LIVE rows of 128 B (8 pairs) into registers (the NEXT pair group's rows are
+// issued before the current one is transformed), stage them pair-major in LDS, every wave adds up the per-frame
+// sums (x^2 and the coordinate sums: registers, one record per frame at the end), then wave w transforms pair w.
+//   R2 = 1: in place on the staged rows (first stage skips the zero half);
+//   R2 = 2: the wave keeps its pair's rows in registers, transforms in place (r = 0), re-stages x W_800^n (r = 1);
+//   R2 = 4: y_r is formed from the staged rows into a wave-private work buffer, four times.
+// Pfull[split][b][k1][k2] (k = k1 + 400 k2) as the row kernels leave it: msd_power_fold_kernel folds the splits.
+constexpr int single_live(int r2) { return 200 * r2; }
+
+template <int R2>
+__global__ __launch_bounds__(THREADS, R2 == 4 ? 1 : 2) void msd_fft_single400_kernel(
+    const double *__restrict__ pos, int64_t n_total, int64_t first, int64_t n_elem, int64_t t_block,
+    int zero_dims, int p_pad, const double2 *__restrict__ tw_r1, const double2 *__restrict__ twN,
+    double *__restrict__ Pfull, double2 *__restrict__ part, int head)
+{
+    static_assert(R2 == 1 || R2 == 2 || R2 == 4, "single-pass lengths");
+    constexpr int R1 = 400, LIVE = 200 * R2;
+    constexpr int LOADS = (LIVE + 63) / 64;          // row rounds of 64 rows (a lane loads a PAIR: 16 bytes)
+    constexpr int SL = (R1 + 63) / 64;               // 7 slot rounds of a 400-point transform
+    constexpr int XS = (R2 == 4 ? LIVE : R1) + 1;    // staged row of a pair (+ 1: the 8 pairs of a frame on different banks)
+    constexpr int PASSES = (LIVE + THREADS - 1) / THREADS;   // per-frame sums: a thread owns frames tid + 512 k
+    __shared__ double2 zb[PG][XS];
+    __shared__ double2 zw[R2 == 4 ? PG : 1][R2 == 4 ? R1 + 1 : 1];
+    __shared__ double2 s_h[R1];                      // exp(-2 pi i m / 400), m < 400
+    const int b = blockIdx.y, n_pg = p_pad / PG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < R1; i += THREADS)
+        s_h[i] = tw_r1[i];
+    const int dshift = (3 - head % 3) % 3;           // dimension of chunk coordinate e: (e + dshift) % 3
+    const int lp = tid & 7, s = 2 * lp, row0 = tid >> 3;
+    const double *base = pos + (int64_t(b) * t_block * n_total + first) * 3 - head;
+    const int64_t row_stride = n_total * 3;
+    const int t_lim = int(min<int64_t>(t_block, LIVE));
+    struct alignas(8) Pair { double x, y; };
+    Pair x[LOADS];
+    // dead rows re-read the block's last live row and coordinates past the chunk the chunk's first pair (valid
+    // memory; zeros are staged for them); a pair whose second coordinate lies past the chunk is read one coordinate
+    // earlier (its first one arrives in .y).  The row offsets are formed per load from an opaque copy of row0: hoisted
+    // out of the loop they were 26 registers for R2 = 4, spilled, and reloaded from scratch in front of every load.
+#define MDX_SINGLE_LOAD(PG_, I0, I1)                                                                 \
+    {                                                                                                \
+        const int64_t e0_ = int64_t(16) * (PG_) + s;                                                 \
+        const double *c_ = e0_ < n_elem ? base + e0_ - (e0_ + 1 < n_elem ? 0 : 1) : base;            \
+        int r0_ = row0;                                                                              \
+        asm volatile("" : "+v"(r0_));                                                                \
+        _Pragma("unroll") for (int i = (I0); i < (I1); ++i)                                          \
+        {                                                                                            \
+            const int row_ = min(r0_ + 64 * i, t_lim - 1);                                           \
+            x[i] = *reinterpret_cast<const Pair *>(c_ + int64_t(row_) * row_stride);                 \
+        }                                                                                            \
+    }
+    // rounds [0, EARLY) of the next pair group are issued early — R2 < 4: all of them, right after the staging, so that
+    // they are in flight while the current pair group is transformed; R2 = 4: none (the last sub-transform alone needs
+    // ~250 registers beside |X|^2 and the per-frame sums: any row kept beside it spilled — 7 rounds 28, 4 rounds 12, 3
+    // rounds 5 registers — and a scratch reload waits for every load issued before it), its rows are loaded at the
+    // top of their own iteration
+    constexpr int EARLY = R2 == 4 ? 0 : LOADS;
+    double P[R2][SL];
+#pragma unroll
+    for (int r = 0; r < R2; ++r)
+#pragma unroll
+        for (int i = 0; i < SL; ++i)
+            P[r][i] = 0.0;
+    double sd[PASSES], sx[PASSES], sy[PASSES], sz[PASSES];
+#pragma unroll
+    for (int k = 0; k < PASSES; ++k)
+        sd[k] = sx[k] = sy[k] = sz[k] = 0.0;
+    // W_N^n = W_400^(n / R2) W_N^(n % R2)
+    const double2 wn1 = twN[R2 > 1 ? 1 : 0], wn2 = twN[R2 > 2 ? 2 : 0], wn3 = twN[R2 > 2 ? 3 : 0];
+
+    int pg = blockIdx.x;
+    if (pg < n_pg)
+        MDX_SINGLE_LOAD(pg, 0, EARLY)
+    __syncthreads();
+    for (; pg < n_pg; pg += gridDim.x) {
+        if (EARLY < LOADS)
+            MDX_SINGLE_LOAD(pg, EARLY, LOADS)
+        {   // stage the rows pair-major
+            const int64_t e0 = int64_t(16) * pg + s;
+            const bool shifted = !(e0 + 1 < n_elem);
+            const bool ok0 = e0 < n_elem && e0 >= head && !((zero_dims >> int((e0 + dshift) % 3)) & 1);
+            const bool ok1 = e0 + 1 < n_elem && e0 + 1 >= head && !((zero_dims >> int((e0 + 1 + dshift) % 3)) & 1);
+#pragma unroll
+            for (int i = 0; i < LOADS; ++i) {
+                const int row = row0 + 64 * i;
+                if (LIVE % 64 == 0 || row < LIVE) {
+                    const bool live = row < t_lim;
+                    const double v0 = shifted ? x[i].y : x[i].x;
+                    zb[lp][row] = make_double2(ok0 && live ? v0 : 0.0, ok1 && live ? x[i].y : 0.0);
+                }
+            }
+        }
+        // the next pair group's rows are in flight while this one is transformed
+        if (R2 < 4 && pg + int(gridDim.x) < n_pg)
+            MDX_SINGLE_LOAD(pg + int(gridDim.x), 0, LOADS)
+        __syncthreads();
+        {   // per-frame sums of the pair group's 16 coordinates: thread t owns frames t, t + 512, ... (consecutive
+            // threads read consecutive rows of one pair: no bank conflict); coordinate 2 j (+ 1) of pair group pg has
+            // dimension (pg + 2 j (+ 1) + dshift) % 3 (16 = 1 mod 3)
+            const int rot = int((int64_t(pg) + dshift) % 3);
+#pragma unroll
+            for (int k = 0; k < PASSES; ++k) {
+                const int row = THREADS * k + tid;
+                if (LIVE % THREADS == 0 || row < LIVE) {
+                    double c0 = 0.0, c1 = 0.0, c2 = 0.0, d = 0.0;
+#pragma unroll
+                    for (int j = 0; j < PG; ++j) {
+                        const double2 v = zb[j][row];
+                        d = fma(v.x, v.x, fma(v.y, v.y, d));
+                        if ((2 * j) % 3 == 0) c0 += v.x; else if ((2 * j) % 3 == 1) c1 += v.x; else c2 += v.x;
+                        if ((2 * j + 1) % 3 == 0) c0 += v.y; else if ((2 * j + 1) % 3 == 1) c1 += v.y; else c2 += v.y;
+                    }
+                    sd[k] += d;
+                    sx[k] += rot == 0 ? c0 : rot == 1 ? c2 : c1;
+                    sy[k] += rot == 0 ? c1 : rot == 1 ? c0 : c2;
+                    sz[k] += rot == 0 ? c2 : rot == 1 ? c1 : c0;
+                }
+            }
+        }
+        __syncthreads();   // the sums read every pair's rows; the transforms below overwrite them
+        double2 *z = zb[wave];
+        if (R2 == 1) {
+            dif_stage<R1, 400, 10, true>(z, s_h, lane);
+            dif_stage<R1, 40, 10, false>(z, s_h, lane);
+            dif_stage<R1, 4, 4, false>(z, s_h, lane);
+#pragma unroll
+            for (int i = 0; i < SL; ++i)
+                if (i < SL - 1 || lane + 64 * i < R1) {
+                    const double2 v = z[lane + 64 * i];
+                    P[0][i] = fma(v.x, v.x, fma(v.y, v.y, P[0][i]));
+                }
+        } else if (R2 == 2) {
+            double2 xr[SL];
+#pragma unroll
+            for (int i = 0; i < SL; ++i)
+                xr[i] = (i < SL - 1 || lane + 64 * i < R1) ? z[lane + 64 * i] : make_double2(0.0, 0.0);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                if (r == 1) {
+#pragma unroll
+                    for (int i = 0; i < SL; ++i)
+                        if (i < SL - 1 || lane + 64 * i < R1) {
+                            const int n = lane + 64 * i;
+                            const double2 w0 = s_h[n >> 1];
+                            z[n] = cmul(xr[i], (n & 1) ? cmul(w0, wn1) : w0);
+                        }
+                    wave_lds_fence();
+                }
+                dif_stage<R1, 400, 10, false>(z, s_h, lane);
+                dif_stage<R1, 40, 10, false>(z, s_h, lane);
+                dif_stage<R1, 4, 4, false>(z, s_h, lane);
+#pragma unroll
+                for (int i = 0; i < SL; ++i)
+                    if (i < SL - 1 || lane + 64 * i < R1) {
+                        const double2 v = z[lane + 64 * i];
+                        P[r][i] = fma(v.x, v.x, fma(v.y, v.y, P[r][i]));
+                    }
+            }
+        } else {
+            double2 *w = zw[R2 == 4 ? wave : 0];
+#pragma unroll
+            for (int r = 0; r < R2; ++r) {
+                if (R2 == 4 && r == R2 - 1 && pg + int(gridDim.x) < n_pg)
+                    MDX_SINGLE_LOAD(pg + int(gridDim.x), 0, EARLY)
+                // (not unrolled: seven slots' operands and twiddles in flight at once were ~110 registers on top
+                // of the ~140 the kernel keeps — rows in flight, |X|^2 and per-frame sums — and spilled)
+#pragma unroll 1
+                for (int i = 0; i < SL; ++i)
+                    if (i < SL - 1 || lane + 64 * i < R1) {
+                        const int n = lane + 64 * i;
+                        const double2 a = z[n], c = z[n + R1];
+                        // a + (-i)^r c
+                        const double2 t = r == 0   ? cadd(a, c)
+                                          : r == 1 ? cadd(a, mul_mi(c))
+                                          : r == 2 ? csub(a, c)
+                                                   : csub(a, mul_mi(c));
+                        if (r == 0) {
+                            w[n] = t;
+                        } else {
+                            const int m = n & 3;
+                            const double2 w0 = s_h[n >> 2];
+                            const double2 w1 = m == 0 ? w0 : cmul(w0, m == 1 ? wn1 : m == 2 ? wn2 : wn3);
+                            const double2 w2 = cmul(w1, w1);
+                            w[n] = cmul(t, r == 1 ? w1 : r == 2 ? w2 : cmul(w2, w1));
+                        }
+                    }
+                wave_lds_fence();
+                __builtin_amdgcn_sched_barrier(0);
+                dif_stage<R1, 400, 10, false>(w, s_h, lane);
+                dif_stage<R1, 40, 10, false>(w, s_h, lane);
+                dif_stage<R1, 4, 4, false>(w, s_h, lane);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < SL; ++i)
+                    if (i < SL - 1 || lane + 64 * i < R1) {
+                        const double2 v = w[lane + 64 * i];
+                        P[r][i] = fma(v.x, v.x, fma(v.y, v.y, P[r][i]));
+                    }
+            }
+        }
+        __syncthreads();   // the next staging overwrites the rows
+    }
+#undef MDX_SINGLE_LOAD
+    // per-frame records of this block: [split][b][frame][(x^2, x), (y, z)]
+#pragma unroll
+    for (int k = 0; k < PASSES; ++k) {
+        const int row = THREADS * k + tid;
+        if (LIVE % THREADS == 0 || row < LIVE) {
+            double2 *o = part + ((int64_t(blockIdx.x) * gridDim.y + b) * LIVE + row) * 2;
+            o[0] = make_double2(sd[k], sx[k]);
+            o[1] = make_double2(sy[k], sz[k]);
+        }
+    }
+    // |X|^2 over the block's pairs: the eight waves' sums meet in LDS (the staging rows are free now)
+    double *red = reinterpret_cast<double *>(&zb[0][0]);      // [wave][r][slot]: 8 x R2 x 400 doubles <= sizeof(zb)
+    static_assert(sizeof(double) * PG * R2 * R1 <= sizeof(double2) * PG * XS, "reduction buffer");
+#pragma unroll
+    for (int r = 0; r < R2; ++r)
+#pragma unroll
+        for (int i = 0; i < SL; ++i)
+            if (i < SL - 1 || lane + 64 * i < R1)
+                red[(wave * R2 + r) * R1 + lane + 64 * i] = P[r][i];
+    __syncthreads();
+    double *pf = Pfull + (int64_t(blockIdx.x) * gridDim.y + b) * (int64_t(R1) * R2);
+    for (int idx = tid; idx < R2 * R1; idx += THREADS) {
+        const int r = idx / R1, slot = idx - r * R1;
+        double total = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < PG; ++wv)
+            total += red[(wv * R2 + r) * R1 + slot];
+        // slot 40 ka + 4 kb + kc holds X_r[j], j = ka + 10 kb + 100 kc (dif_slot_400); k = R2 j + r = k1 + 400 k2
+        const int ka = slot / 40, rem = slot - 40 * ka, kb = rem >> 2, kc = rem & 3;
+        const int k = R2 * (ka + 10 * kb + 100 * kc) + r;
+        pf[(k % R1) * R2 + k / R1] = total;
+    }
+}
+
+
 // ------------------------------------------------------------------------------ host side
 
 struct Shape {
@@ -1268,6 +1518,8 @@ inline Shape shape_for(int64_t n_fft)
         s.r1 = 64, s.r2 = 512;
     else if (n_fft == (int64_t(1) << 16))
         s.r1 = 64, s.r2 = 1024;
+    else if (n_fft == 400)
+        s.r1 = 400, s.r2 = 1;
     else if (n_fft == 800)
         s.r1 = 400, s.r2 = 2;
     else if (n_fft == 1600)
@@ -1352,6 +1604,39 @@ inline size_t fused_part_bytes(const Shape &sh, int p_pad, int n_blocks)
     // records per block: 400-point factor r2 x 200 rows; short factors (r2 / nc groups) x 256 frames = r2 x r1 / 2
     const size_t per_b = sh.r1 == 400 ? size_t(sh.r2) * SUMS_ROWS : size_t(sh.r2) * (sh.r1 / 2);
     return size_t(fused_super_groups(p_pad)) * n_blocks * per_b * 32;
+}
+
+// splits of the single-pass grid: >= 2 048 blocks where the pair groups allow it
+inline int single_splits(int n_blocks) { return std::max(1, std::min(64, (2048 + n_blocks - 1) / n_blocks)); }
+inline bool single_pass(const Shape &sh) { return sh.r1 == 400 && sh.r2 <= 4; }
+inline size_t single_part_bytes(const Shape &sh, int n_blocks)
+{
+    return size_t(single_splits(n_blocks)) * n_blocks * single_live(sh.r2) * 32;
+}
+
+// one launch of the single-pass pipeline for a chunk; returns the number of Pfull parts written
+inline int launch_single(const Shape &sh, hipStream_t stream, const double *pos, int64_t n_total, int64_t first,
+                         int64_t n_elem, int64_t t_block, int n_blocks, int zero_dims, int p_pad,
+                         const double2 *tw_r1, const double2 *twN, double *Pfull, double2 *part, double *traj,
+                         double *dsq, int head)
+{
+    const int splits = std::min(single_splits(n_blocks), p_pad / PG);
+    const dim3 grid((unsigned)splits, (unsigned)n_blocks);
+#define MDX_MSDFFT_SINGLE(R2_)                                                                                   \
+    hipLaunchKernelGGL((msd_fft_single400_kernel<R2_>), grid, dim3(THREADS), 0, stream, pos, n_total, first, n_elem, \
+                       t_block, zero_dims, p_pad, tw_r1, twN, Pfull, part, head)
+    if (sh.r2 == 1) {
+        MDX_MSDFFT_SINGLE(1);
+    } else if (sh.r2 == 2) {
+        MDX_MSDFFT_SINGLE(2);
+    } else {
+        MDX_MSDFFT_SINGLE(4);
+    }
+#undef MDX_MSDFFT_SINGLE
+    const int live = single_live(sh.r2);
+    hipLaunchKernelGGL(msd_partials_reduce_kernel, dim3((unsigned)((live + 255) / 256), (unsigned)n_blocks), dim3(256),
+                       0, stream, part, splits, 1, 1, live, t_block, traj, dsq);
+    return splits;
 }
 
 // pass B of shape R1 x R2: the register-staged kernel for 512-point rows, the general one for 1024

@@ -22,6 +22,12 @@ while time.time() < t_end:
     t_block = int(rng.choice(edges)) if rng.random() < 0.6 else int(rng.integers(2, 70000))
     n_blocks = int(rng.integers(1, 5))
     n_atoms = int(rng.integers(1, 24))
+    if t_block <= 800 and rng.random() < 0.7:
+        # the single-pass kernel (<= 800 frames per block): many blocks, several pair groups per block of the grid
+        n_blocks = int(rng.integers(1, 400))
+        n_atoms = int(rng.integers(1, 400))
+        if n_blocks * t_block * n_atoms > 6_000_000:
+            n_atoms = max(1, 6_000_000 // (n_blocks * t_block))
     if rng.random() < 0.3:
         # rows of whole 128-byte lines (16 | 3 n_atoms): pushes that start inside a line enter their chunk early
         # (the `head` of msd_fft_cols400_fused_kernel, blocks of 32 769 ... 102 400 frames)

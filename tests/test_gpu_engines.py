@@ -612,8 +612,10 @@ def test_rdf_mixed_orthorhombic_and_triclinic_frames_in_one_batch():
                                   (100000, 1, 29, 0), (102400, 1, 8, 3), (102401, 1, 8, 0), (32769, 3, 17, 0),
                                   # 25 600 = 400 x 64 points: blocks of 8 193 .. 12 800 frames
                                   (12800, 2, 19, 0), (12801, 2, 19, 0), (9000, 11, 37, 6), (12500, 8, 16, 1),
-                                  # 800 = 400 x 2 and 1 600 = 400 x 4: 201 .. 400 and 401 .. 800 (shorter blocks: rocFFT)
+                                  # single pass — 400, 800 = 400 x 2, 1 600 = 400 x 4 points: <= 200, 201 .. 400, 401 .. 800
                                   (400, 5, 23, 0), (401, 5, 23, 0), (201, 12, 70, 4), (800, 3, 11, 0), (500, 40, 9, 1),
+                                  (200, 7, 23, 0), (199, 30, 41, 2), (64, 100, 33, 5), (37, 300, 16, 0), (2, 50, 9, 0),
+                                  (1, 9, 7, 0), (300, 70, 129, 0), (640, 90, 64, 3), (400, 250, 48, 0),
                                   # 3 200 = 400 x 8: 801 .. 1 600
                                   (1600, 4, 21, 0), (1601, 4, 21, 0), (801, 7, 30, 3), (1000, 50, 9, 0),
                                   # 6 400 = 400 x 16 and 12 800 = 400 x 32 points: 2 049 .. 3 200 and 4 097 .. 6 400
@@ -641,7 +643,7 @@ def test_msd_own_two_pass_transform_equals_rocfft(case, monkeypatch):
         else:
             monkeypatch.delenv("MDX_MSD_ROCFFT", raising=False)
         eng = _core.MsdEngine(t_block, n_blocks, 2)
-        want = (800 if t_block <= 400 else 1600 if t_block <= 800 else 3200 if t_block <= 1600 else 6400 if t_block <= 3200 else 8192 if t_block <= 4096 else 12800 if t_block <= 6400
+        want = (400 if t_block <= 200 else 800 if t_block <= 400 else 1600 if t_block <= 800 else 3200 if t_block <= 1600 else 6400 if t_block <= 3200 else 8192 if t_block <= 4096 else 12800 if t_block <= 6400
                 else 16384 if t_block <= 8192 else 25600 if t_block <= 12800
                 else 32768 if t_block <= 16384 else 51200 if t_block <= 25600
                 else 65536 if t_block <= 32768 else 102400 if t_block <= 51200 else 204800 if t_block <= 102400
@@ -658,15 +660,39 @@ def test_msd_own_two_pass_transform_equals_rocfft(case, monkeypatch):
         # the two pipelines add up the per-frame sums D_t in different orders; at the last lags
         # S_m = (2 sum D - cumulative sums) / (T - m) cancels ~10 digits of them, so a few 1e-10 of
         # the largest value is the rounding floor of either
+        # (a block of ONE frame has lag 0 only: S_0 - 2 A_0 = 0 up to a few ulps of sum x^2 in either pipeline)
         scale = np.abs(b).max()
-        assert np.allclose(a, b, rtol=1e-10, atol=5e-10 * scale)
+        assert np.allclose(a, b, rtol=1e-10, atol=5e-10 * scale + 2e-14 * float((pos ** 2).sum()) / n_blocks)
     # and against the direct definition on a few lags
     msd = out["own"][0][0, 0] / n_atoms
     keep = [k for k in range(3) if not (zero_dims >> k) & 1]
     p = pos[:t_block][:, :, keep]
-    for m in (1, 17, min(4096, t_block // 2), t_block - 3):
+    for m in sorted({m for m in (1, 17, min(4096, t_block // 2), t_block - 3) if 0 < m < t_block}):
         d = p[m:] - p[:-m]
         assert np.isclose(msd[m], (d * d).sum(-1).mean(), rtol=1e-8)
+
+
+@pytest.mark.parametrize("case", [(400, 6, 27, 0), (201, 9, 70, 4), (800, 3, 11, 1), (401, 14, 33, 0), (777, 5, 16, 2)])
+def test_msd_single_pass_equals_the_two_pass_pipeline(case, monkeypatch):
+    """800 and 1 600 points: the single-pass kernel (no `Y`) against the two-pass pipeline it replaced for blocks
+    of 201 .. 800 frames (MDX_MSD_TWO_PASS=1), same engine, same pushes."""
+    t_block, n_blocks, n_atoms, zero_dims = case
+    rng = np.random.default_rng(8)
+    pos = np.cumsum(rng.normal(0, 0.3, (t_block * n_blocks, n_atoms, 3)), axis=0) + rng.uniform(0, 50, (1, n_atoms, 3))
+    out = {}
+    for mode in ("single", "two_pass"):
+        if mode == "two_pass":
+            monkeypatch.setenv("MDX_MSD_TWO_PASS", "1")
+        else:
+            monkeypatch.delenv("MDX_MSD_TWO_PASS", raising=False)
+        eng = _core.MsdEngine(t_block, n_blocks, 2)
+        assert eng.n_fft == (800 if t_block <= 400 else 1600)
+        eng.push(0, pos, 0, n_atoms, zero_dims)
+        eng.push(1, pos, 2, n_atoms - 3, zero_dims)
+        out[mode] = eng.result()
+        eng.close()
+    for a, b in zip(out["single"], out["two_pass"]):
+        assert np.allclose(a, b, rtol=1e-10, atol=5e-10 * np.abs(b).max())
 
 
 @pytest.mark.parametrize("mode", [None, "partial"])
