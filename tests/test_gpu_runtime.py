@@ -157,6 +157,13 @@ def test_host_registration_is_page_aligned_tracked_and_exclusive():
     check(lib().mdx_host_unregister(0, raw.ctypes.data))
 
 
+def _page_aligned(shape, dtype=np.float64):
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    raw = np.empty(n + 2 * 4096, dtype=np.uint8)
+    off = -raw.ctypes.data % 4096
+    return raw[off:off + n].view(dtype).reshape(shape)
+
+
 @pytest.mark.parametrize("pinned", [False, True])
 def test_cross_correlation_of_large_inputs_is_ordered(pinned):
     """mdx_correlate with inputs >= 1 MiB each — `b` used to be uploaded, on another stream, into the
@@ -166,8 +173,11 @@ def test_cross_correlation_of_large_inputs_is_ordered(pinned):
     from oracle import correlation as oc
     rng = np.random.default_rng(41)
     n_series, n_t = 96, 4096                               # 3 MiB per input
-    a = np.cumsum(rng.normal(size=(n_series, n_t)), axis=1)
-    b = rng.normal(size=(n_series, n_t))
+    # (page-aligned with a page of slack behind: two malloc'd arrays can share a page, and a registration takes
+    # whole pages exclusively — the second mdx_host_register is then refused, as the header says)
+    a, b = _page_aligned((n_series, n_t)), _page_aligned((n_series, n_t))
+    a[:] = np.cumsum(rng.normal(size=(n_series, n_t)), axis=1)
+    b[:] = rng.normal(size=(n_series, n_t))
     if pinned:
         check(lib().mdx_host_register(0, a.ctypes.data, a.nbytes))
         check(lib().mdx_host_register(0, b.ctypes.data, b.nbytes))
