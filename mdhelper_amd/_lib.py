@@ -119,6 +119,7 @@ _SIGNATURES = {
     "mdx_traj_read_boxes": (c_int, [_vp, _vp, c_int64, _vp]),
     "mdx_traj_read_times": (c_int, [_vp, _vp, c_int64, _vp]),
     "mdx_traj_load_device": (c_int, [_vp, c_int, _vp, c_int64, _vp, c_int64, _vp]),
+    "mdx_traj_load_columns_device": (c_int, [_vp, c_int, _vp, c_int64, c_int64, c_int64, _vp]),
     "mdx_rdf_accumulate_traj": (c_int, [_vp, _vp, _vp, c_int64, _vp, _vp, c_int64, _vp, c_int64]),
     "mdx_sq_set_grouping": (c_int, [_vp, c_int64, _vp, _vp]),
     "mdx_isf_accumulate_device": (c_int, [_vp, _vp, c_int64, c_int64]),

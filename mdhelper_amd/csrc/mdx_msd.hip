@@ -744,7 +744,8 @@ template <typename In> struct HostFrames final : FrameSource {
     }
     int stage(mdx_msd *h, int64_t a0, int64_t c, int64_t f0, int64_t nf, void *d_out) override
     {
-        // (through the pinned ring, or one 2-D DMA out of page-locked memory: not the runtime's pageable path)
+        // (one 2-D DMA where the rows lie — page-locked memory, or pageable rows of >= 4 KB through the runtime's copy —
+        // or the pinned ring's gather for short rows: HostStager::upload_rows)
         const size_t row = 3 * sizeof(In);
         return device_stager(h->dev).upload_rows(h->dev, h->stream, d_out, pos + (f0 * n_sel + a0) * 3, row * c,
                                                  row * n_sel, (size_t)nf);

@@ -609,6 +609,22 @@ int HostStager::upload_rows(int device, hipStream_t consumer, void *d_dst, const
         return MDX_OK;
     if (src_stride == row_bytes)
         return upload(device, consumer, d_dst, src, row_bytes * n_rows);
+    // Pageable rows of a few KB and more: the runtime's own 2-D copy.  It locks the pages it is handed and the DMA
+    // engine reads the rows where they lie — 57 GB/s for 15 .. 30 KB rows 120 KB apart (the link's own rate), where
+    // the copy threads' gather into the ring reaches 34 .. 40 (profiles/r05_host_feed_rates.txt,
+    // r05_mmap_feed_rates.json: no host core touches the data).  It follows what the consumer queued before, and
+    // the call returns when the copy has ended (the caller may reuse the source, as with the ring):
+    // copy_rows_pageable.  Short rows keep the gather: a DMA descriptor per 12-byte row is no way to move a
+    // particle's track.
+    // MDX_RING_ROWS=1 (A/B hook) keeps the ring for every row length.
+    static const bool ring_rows = getenv("MDX_RING_ROWS") != nullptr;
+    if (row_bytes >= 4096 && !ring_rows && host_range_registered(src, (n_rows - 1) * src_stride + row_bytes) == 0) {
+        hipPointerAttribute_t attr;
+        const bool pageable = hipPointerGetAttributes(&attr, src) != hipSuccess || attr.type == hipMemoryTypeUnregistered;
+        (void)hipGetLastError();
+        if (pageable)
+            return copy_rows_pageable(device, consumer, d_dst, src, row_bytes, src_stride, n_rows, false);
+    }
     std::lock_guard<std::mutex> guard(lock);
     const uint8_t *from = static_cast<const uint8_t *>(src);
     // page-locked / registered memory (both ends of the strided range): one 2-D DMA where it lies
@@ -638,6 +654,83 @@ int HostStager::upload_rows(int device, hipStream_t consumer, void *d_dst, const
         MDX_TRY(send(b, to + r0 * row_bytes, nr * row_bytes));
     }
     return finish(consumer);
+}
+
+// n_rows rows of row_bytes, src_stride apart in PAGEABLE host memory (anonymous memory, or a read-only mapping of a
+// file in the page cache) -> contiguous rows in HBM by the runtime's own 2-D copies: the runtime locks the pages it
+// is handed, maps them for the device and lets the DMA engine read them where they lie.  The rows are cut into
+// slices of ~128 MB that the copy threads issue side by side, each on a stream of its own: what a slice costs before
+// its DMA starts — locking and mapping its pages (a first copy out of fresh memory runs at 46 - 49 GB/s against
+// 57.5 for a repeated one), and with touch_pages the population of a fresh file mapping's page tables (a first copy
+// out of an untouched mapping: 30 GB/s; profiles/r05_mmap_pretouch.json) — then runs beside the DMA of other slices.
+// Ordering: the copies start after what `consumer` has queued so far, and all of them have ended when the call
+// returns.
+int HostStager::copy_rows_pageable(int device, hipStream_t consumer, void *d_dst, const void *src, size_t row_bytes,
+                                   size_t src_stride, size_t n_rows, bool touch_pages)
+{
+    if (row_bytes == 0 || n_rows == 0)
+        return MDX_OK;
+    std::lock_guard<std::mutex> guard(lock);
+    if (dev >= 0 && dev != device)
+        return fail(MDX_ERR_STATE, "staging ring is bound to device %d", dev);
+    dev = device;
+    workers.start(io_threads());
+    hipEvent_t ev_ready = nullptr;
+    if (consumer) {
+        MDX_HIP(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
+        const hipError_t e = hipEventRecord(ev_ready, consumer);
+        if (e != hipSuccess) {
+            (void)hipEventDestroy(ev_ready);
+            MDX_HIP(e);
+        }
+    }
+    const size_t rows_per = std::max<size_t>(1, (size_t(128) << 20) / row_bytes);
+    const int n_slices = int((n_rows + rows_per - 1) / rows_per);
+    const uint8_t *from = static_cast<const uint8_t *>(src);
+    uint8_t *to = static_cast<uint8_t *>(d_dst);
+    std::mutex err_lock;
+    hipError_t first_err = hipSuccess;
+    static volatile uint8_t sink;
+    const std::function<void(int)> one = [&](int k) {
+        const size_t r0 = size_t(k) * rows_per, nr = std::min(rows_per, n_rows - r0);
+        hipError_t e = hipSetDevice(device);
+        hipStream_t s = nullptr;
+        if (e == hipSuccess && stream_acquire(&s) != MDX_OK)
+            e = hipErrorUnknown;
+        if (e == hipSuccess && touch_pages) {
+            uint8_t acc = 0;
+            for (size_t r = r0; r < r0 + nr; ++r) {
+                const uintptr_t a = reinterpret_cast<uintptr_t>(from + r * src_stride), b = a + row_bytes;
+                for (uintptr_t p = a; p < b; p = (p | 4095) + 1)
+                    acc ^= *reinterpret_cast<const volatile uint8_t *>(p);
+            }
+            sink = acc;
+        }
+        if (e == hipSuccess && ev_ready)
+            e = hipStreamWaitEvent(s, ev_ready, 0);
+        if (e == hipSuccess)
+            e = hipMemcpy2DAsync(to + r0 * row_bytes, row_bytes, from + r0 * src_stride, src_stride, row_bytes, nr,
+                                 hipMemcpyHostToDevice, s);
+        if (s) {
+            const hipError_t e2 = hipStreamSynchronize(s);      // also after an error: no copy outlives the call
+            if (e == hipSuccess)
+                e = e2;
+            stream_release(s);
+        }
+        if (e != hipSuccess) {
+            std::lock_guard<std::mutex> lk(err_lock);
+            if (first_err == hipSuccess)
+                first_err = e;
+        }
+    };
+    workers.parallel_for(n_slices, one);
+    if (ev_ready)
+        (void)hipEventDestroy(ev_ready);
+    if (first_err != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(MDX_ERR_HIP, "2-D copy out of pageable memory failed: %s", hipGetErrorString(first_err));
+    }
+    return MDX_OK;
 }
 
 void HostStager::destroy()
@@ -904,9 +997,11 @@ int mdx_upload(int dev, void *d_dst, const void *src, size_t bytes)
     return MDX_OK;
 }
 
-// Large copies between pageable host memory and HBM go through the library's own pinned ring (its copy threads
-// keep the link at 50 GB/s where the runtime's single-threaded staging gives ~15; NOTES round 5 for what the one
-// aborted run of round 4 does and does not say about the runtime's pageable path).  hipMemcpy's ordering is kept:
+// Large whole-array copies between pageable host memory and HBM go through the library's own pinned ring: its
+// copies are asynchronous to the engines' streams, which the staging pipelines are built on (the runtime's own
+// pageable path moves the same bytes at 56 GB/s against the ring's 54 H2D / 43 D2H, profiles/r05_pageable_vs_ring.json
+// — a performance choice either way, not a detour around a fault: NOTES round 5 on the one aborted run of round 4).
+// Strided rows take the runtime's 2-D copy (HostStager::upload_rows).  hipMemcpy's ordering is kept:
 // the copy starts after everything queued on the device before the call and has ended when the call returns.
 int mdx_memcpy_h2d(int dev, void *dst, const void *src, size_t bytes)
 {
