@@ -345,14 +345,6 @@ int mdx_traj_read_times(mdx_traj_t h, const int64_t *frames, int64_t n, double *
  * particle indices, or NULL for the first n_sel particles (n_sel <= 0: all). */
 int mdx_traj_load_device(mdx_traj_t h, int dev, const int64_t *frames, int64_t n,
                          const int32_t *d_index, int64_t n_sel, float *d_out);
-/* Particles [first, first + count) of the listed frames into HBM: d_out float32[n][count][3] — what one group of
- * an MSD analysis needs of every frame (reference transport.py:976-992 reads the whole frame for it).  NetCDF files
- * are mapped read-only and the DMA engine reads the rows where the page cache holds them, runs of equally spaced
- * frames as one 2-D copy each; the byte swap happens on the device.  DCD files, rows under 4 KB and irregular frame
- * lists go through the pinned ring (whole frames, the particles picked on the device).  mdx_traj_load_device
- * without an index takes the same route.  Returns when d_out is complete. */
-int mdx_traj_load_columns_device(mdx_traj_t h, int dev, const int64_t *frames, int64_t n, int64_t first,
-                                 int64_t count, float *d_out);
 /* RDF over frames of a trajectory file.  boxes: host float32[n_frames][6] of those frames
  * (mdx_traj_read_boxes) or NULL; index1/index2: host int32 particle selections (ag.indices),
  * NULL = all particles; index2 == NULL with n2 == 0 = the same group twice. */

@@ -119,7 +119,6 @@ _SIGNATURES = {
     "mdx_traj_read_boxes": (c_int, [_vp, _vp, c_int64, _vp]),
     "mdx_traj_read_times": (c_int, [_vp, _vp, c_int64, _vp]),
     "mdx_traj_load_device": (c_int, [_vp, c_int, _vp, c_int64, _vp, c_int64, _vp]),
-    "mdx_traj_load_columns_device": (c_int, [_vp, c_int, _vp, c_int64, c_int64, c_int64, _vp]),
     "mdx_rdf_accumulate_traj": (c_int, [_vp, _vp, _vp, c_int64, _vp, _vp, c_int64, _vp, c_int64]),
     "mdx_sq_set_grouping": (c_int, [_vp, c_int64, _vp, _vp]),
     "mdx_isf_accumulate_device": (c_int, [_vp, _vp, c_int64, c_int64]),
@@ -161,6 +160,10 @@ def lib():
                 f"{LIB_PATH} not found: build the HIP library first "
                 "(`make -C mdhelper_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`). "
                 "mdhelper_amd has no CPU fallback.")
+        # the HIP runtime reads its flags at its first call: the library's own load-time initialiser sets this one as
+        # well (csrc/mdx_runtime.hip, mdx_process_init — why: the runtime must never page-lock caller memory on its
+        # own); here for a runtime that something else in the process initialises between now and then
+        os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "1048576")
         handle = ctypes.CDLL(str(LIB_PATH))
         for name, (restype, argtypes) in _SIGNATURES.items():
             fn = getattr(handle, name)

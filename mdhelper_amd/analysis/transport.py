@@ -532,39 +532,30 @@ class Onsager(SerialAnalysisBase):
 
     def _stream_host_groups(self, eng, numbers, native, zero_mask, unwrap_dims) -> bool:
         """
-        Plain atom groups over consecutive particles of an in-memory float32 trajectory or of an AMBER NetCDF
-        file, nothing to centre: a group's particles are all the engine needs of a frame, so they travel in column
-        chunks — particles [a, a + c) of every frame through ``mdx_upload_rows`` / ``mdx_traj_load_columns_device``
-        (2-D copies the DMA engine reads out of the caller's pages or the page cache) into one of two device
-        blocks — and the chunk before is unwrapped, widened and transformed on the device meanwhile.  The analysis
-        then takes the time of the host link plus one chunk (C4 from pageable memory: 225 ms, the link alone
-        208 - 222 ms) instead of upload + transforms.  Returns False when the case is another one (the caller
-        brings whole frames into HBM).
+        Plain atom groups over consecutive particles of an in-memory float32 trajectory, nothing to centre: a
+        group's particles are all the engine needs of a frame, so they travel in column chunks — particles
+        [a, a + c) of every frame through ``mdx_upload_rows`` (2-D copies the DMA engine reads out of the caller's
+        pages) into one of two device blocks — and the chunk before is unwrapped, widened and transformed on the
+        device meanwhile.  The analysis then takes the time of the host link plus one chunk (C4 from pageable
+        memory: 225 - 235 ms, the link alone 208 ms) instead of upload + transforms.  Returns False when the case is
+        another one (the caller brings whole frames into HBM; trajectory files: NOTES round 5 on why their pages
+        are not handed to the DMA engine).
         """
         traj = self._trajectory
-        if (not self._stream_columns or self._center or self._comm.world_size != 1
+        if (not self._stream_columns or native is not None or self._center or self._comm.world_size != 1
                 or hasattr(traj, "device_block")
                 or self._hbm_share <= 0 or any(gr != "atoms" for gr in self._groupings)):
             return False
-        if native is not None:
-            # an AMBER NetCDF file: the same column chunks, read by the DMA engine out of the mapped file
-            # (mdx_traj_load_columns_device); DCD planes take the whole-frame route
-            if getattr(native, "format", None) != "NETCDF":
-                return False
-            block = None
-            shape = (len(numbers), native.n_atoms)
-        else:
-            block = traj.frame_block(numbers)
-            if not (isinstance(block, np.ndarray) and block.dtype == np.float32 and block.flags.c_contiguous):
-                return False
-            shape = block.shape[:2]
+        block = traj.frame_block(numbers)
+        if not (isinstance(block, np.ndarray) and block.dtype == np.float32 and block.flags.c_contiguous):
+            return False
         spans = []
         for grp in self._groups:
             idx = np.asarray(grp.indices)
             if len(idx) == 0 or not np.array_equal(idx, np.arange(idx[0], idx[0] + len(idx))):
                 return False
             spans.append((int(idx[0]), len(idx)))
-        T, n_atoms = shape
+        T, n_atoms = block.shape[0], block.shape[1]
         # ~1.5 GB per chunk, at least two chunks per group (the second upload hides the first chunk's transforms),
         # equal chunks of whole groups of 16 particles
         largest = max(c for _f, c in spans)
@@ -582,10 +573,7 @@ class Onsager(SerialAnalysisBase):
                     c = min(chunk, count - a)
                     # (a ragged last chunk: the same block, viewed as [T, c, 3])
                     buf = bufs[k & 1] if c == chunk else _core.DeviceArray.view(bufs[k & 1], (T, c, 3))
-                    if block is None:
-                        native.load_columns_device(numbers, first + a, c, buf.ptr, dev=self._device)
-                    else:
-                        buf.upload_columns(block, first + a, c)
+                    buf.upload_columns(block, first + a, c)
                     # the chunk pushed before this upload ran beside it; once it is done, the block it read is free
                     # for the upload after this one, and this chunk's kernels run beside that upload
                     eng.synchronize()

@@ -148,10 +148,10 @@ struct HostStager {
     // (a range of particles out of frames [T][N][3]: what one group of an MSD analysis needs of every frame)
     int upload_rows(int device, hipStream_t consumer, void *d_dst, const void *src, size_t row_bytes,
                     size_t src_stride, size_t n_rows);
-    // the pageable case of upload_rows for rows of >= 4 KB, and the route of a mapped trajectory file (touch_pages:
-    // the slices' pages are read once by the copy threads first): the runtime's 2-D copies, in slices, side by side
-    int copy_rows_pageable(int device, hipStream_t consumer, void *d_dst, const void *src, size_t row_bytes,
-                           size_t src_stride, size_t n_rows, bool touch_pages);
+    // the pageable case of upload_rows for rows of >= 4 KB, >= 2 pages apart, in anonymous memory: slices locked,
+    // copied by 2-D DMA and unlocked by the copy threads, side by side
+    int copy_rows_locked(int device, hipStream_t consumer, void *d_dst, const void *src, size_t row_bytes,
+                         size_t src_stride, size_t n_rows);
     // dst[0, bytes) <- d_src (HBM -> pageable host memory) through the pinned buffers, the copy of chunk k + 1 in
     // flight while chunk k leaves its buffer; returns when dst is complete.  `producer`: the stream whose queued
     // work wrote d_src (nullptr: the caller has synchronised)

@@ -274,7 +274,8 @@ __global__ void msd_real_to_complex_kernel(const double *__restrict__ P, int64_t
 constexpr int FINISH_THREADS = 1024;
 __global__ __launch_bounds__(FINISH_THREADS) void msd_finish_kernel(const double *__restrict__ acf, int64_t acf_stride,
                                                                    const double *__restrict__ D, int64_t t_block,
-                                                                   double inv_n, double *__restrict__ out)
+                                                                   double inv_n, double *__restrict__ out,
+                                                                   double acf_factor = 2.0)
 {
     __shared__ double red[FINISH_THREADS];
     const int tid = threadIdx.x;
@@ -314,8 +315,25 @@ __global__ __launch_bounds__(FINISH_THREADS) void msd_finish_kernel(const double
         if (m > 0)
             run += d[m - 1] + d[t_block - m];
         const double w = double(t_block - m);
-        o[m] = (2.0 * total - run) / w - 2.0 * (a[m] * inv_n) / w;
+        o[m] = (2.0 * total - run) / w - acf_factor * (a[m] * inv_n) / w;
     }
+}
+
+// D[row][t] = r_i(t) . r_j(t) of the summed trajectories of a (pair, block) row (mdx_msd_cross): the per-frame
+// products the S_m recurrence of a cross displacement starts from (correlation.py:621-648 with r1 != r2)
+__global__ __launch_bounds__(256) void cross_dot_kernel(const double *__restrict__ traj, const int *__restrict__ pairs,
+                                                        int n_blocks, int64_t t_block, int64_t row0,
+                                                        double *__restrict__ D)
+{
+    const int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (t >= t_block)
+        return;
+    const int64_t row = row0 + blockIdx.y;
+    const int p = int(row / n_blocks), b = int(row - int64_t(p) * n_blocks);
+    const double *a = traj + ((int64_t(pairs[2 * p]) * n_blocks + b) * t_block + t) * 3;
+    const double *c = traj + ((int64_t(pairs[2 * p + 1]) * n_blocks + b) * t_block + t) * 3;
+    D[int64_t(blockIdx.y) * t_block + t] = __dadd_rn(__dadd_rn(__dmul_rn(a[0], c[0]), __dmul_rn(a[1], c[1])),
+                                                     __dmul_rn(a[2], c[2]));
 }
 
 // [n_series][n_t] -> zero-padded [n_series][n_fft]
@@ -1426,40 +1444,26 @@ int mdx_msd_cross(mdx_msd_t h, const int32_t *pairs, int64_t n_pairs, double *ou
     hipLaunchKernelGGL(cross_pad_kernel, dim3((unsigned)ceil_div(GB * 3 * h->n_fft, 256)), dim3(256), 0, h->stream,
                        h->d_traj.as<double>(), GB, Tb, h->n_fft, h->d_series.as<double>());
     MDX_TRY(h->fft.exec(0, GB * 3, h->d_series.ptr, h->d_cross_f.ptr, h->stream));
-    std::vector<double> corr(size_t(PB) * Tb), tr(size_t(h->traj_len()));
+    // per batch: spectrum products, inverse transforms, the per-frame products r_i . r_j and the S_m recurrence —
+    // all on the device (the host used to copy the correlations and the summed trajectories back through the
+    // runtime's pageable path and walk them); the finished rows come back in one copy through the pinned ring
+    MDX_TRY(h->d_finish.ensure(size_t(8) * PB * Tb));
+    MDX_TRY(h->d_stage.ensure(size_t(8) * rows_batch * Tb));
+    const double inv_n = 1.0 / double(h->n_fft);
     for (int64_t r0 = 0; r0 < PB; r0 += rows_batch) {
         const int64_t nr = std::min(rows_batch, PB - r0);
         hipLaunchKernelGGL(cross_product_kernel, dim3((unsigned)ceil_div(h->nc, 256), (unsigned)nr), dim3(256), 0,
                            h->stream, h->d_cross_f.as<double2>(), h->d_index.as<int>(), B, h->nc, r0,
                            h->d_inv_in.as<double2>());
         MDX_TRY(h->fft.exec(1, nr, h->d_inv_in.ptr, h->d_inv_out.ptr, h->stream));
+        hipLaunchKernelGGL(cross_dot_kernel, dim3((unsigned)ceil_div(Tb, 256), (unsigned)nr), dim3(256), 0, h->stream,
+                           h->d_traj.as<double>(), h->d_index.as<int>(), B, Tb, r0, h->d_stage.as<double>());
+        hipLaunchKernelGGL(msd_finish_kernel, dim3((unsigned)nr), dim3(FINISH_THREADS), 0, h->stream,
+                           h->d_inv_out.as<double>(), h->n_fft, h->d_stage.as<double>(), Tb, inv_n,
+                           h->d_finish.as<double>() + r0 * Tb, 1.0);
         MDX_HIP(hipGetLastError());
-        MDX_HIP(hipMemcpy2DAsync(corr.data() + size_t(r0) * Tb, size_t(Tb) * 8, h->d_inv_out.ptr, size_t(h->n_fft) * 8,
-                                 size_t(Tb) * 8, (size_t)nr, hipMemcpyDeviceToHost, h->stream));
     }
-    MDX_HIP(hipMemcpyAsync(tr.data(), h->d_traj.ptr, size_t(8) * h->traj_len(), hipMemcpyDeviceToHost, h->stream));
-    MDX_HIP(hipStreamSynchronize(h->stream));
-    const double inv_n = 1.0 / double(h->n_fft);
-    std::vector<double> d((size_t)Tb);
-    for (int64_t p = 0; p < n_pairs; ++p)
-        for (int b = 0; b < B; ++b) {
-            const double *a = tr.data() + (int64_t(pairs[2 * p]) * B + b) * Tb * 3;
-            const double *c = tr.data() + (int64_t(pairs[2 * p + 1]) * B + b) * Tb * 3;
-            double total = 0.0;
-            for (int64_t t = 0; t < Tb; ++t) {
-                d[size_t(t)] = (a[3 * t] * c[3 * t] + a[3 * t + 1] * c[3 * t + 1]) + a[3 * t + 2] * c[3 * t + 2];
-                total += d[size_t(t)];
-            }
-            const double *r = corr.data() + (p * B + b) * Tb;
-            double *o = out + (p * B + b) * Tb;
-            double run = 0.0;
-            for (int64_t m = 0; m < Tb; ++m) {
-                if (m > 0)
-                    run += d[size_t(m - 1)] + d[size_t(Tb - m)];
-                const double w = double(Tb - m);
-                o[m] = (2.0 * total - run) / w - (r[m] * inv_n) / w;
-            }
-        }
+    MDX_TRY(device_stager(h->dev).download(h->dev, h->stream, out, h->d_finish.ptr, size_t(8) * PB * Tb));
     return MDX_OK;
 }
 

@@ -2,6 +2,9 @@
 // stream timers and the synthetic-trajectory generator used by bench.py/tests.
 #include "mdx_common.hpp"
 
+#include <execinfo.h>
+#include <signal.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <unordered_map>
@@ -22,6 +25,72 @@ int fail(int code, const char *fmt, ...)
     va_end(ap);
     return code;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Process-level settings, made when the library is loaded — before this library's first HIP call, which is when the
+// runtime reads its flags.
+//
+// (1) The runtime never page-locks caller memory on its own.  For a copy of more than GPU_PINNED_MIN_XFER_SIZE MiB
+// between pageable memory and the device the HIP runtime locks the caller's pages for the DMA engine AND KEEPS the
+// last few locked ranges, keyed by (host address, size), for the next copy out of the same buffer.  The entries are
+// not dropped when the caller frees that memory.  When the allocator hands the same addresses out again — a new numpy
+// array, a std::vector — a later copy finds the stale entry and lets the DMA engine use a registration whose pages
+// are gone: the process aborts inside that copy.  This is what the two aborted test runs on record look like (round
+// 4: a 52.8 MB hipMemcpy into a fresh numpy array after copies out of arrays that had been freed; round 5: the
+// 4.4 MB copy of mdx_msd_cross into a std::vector, in the first build that handed pageable rows to the runtime
+// again; both one run in several, each time in a copy INTO freshly allocated host memory; NOTES.md round 5), and a
+// file mapping that loses its tail while such an entry exists blocks every later GPU call of the process
+// (scripts/diag/mmap_truncate_probe.py).  With the threshold out of reach every pageable copy of the runtime goes
+// through its own staging buffers; everything large in this library moves through the pinned ring or through pages
+// it locks and unlocks itself around the copy (HostStager::copy_rows_locked).  A value the user has set stays.
+//
+// (2) MDX_ABORT_TRACE=<fd> (the test suite sets it; 1 or 2 = stderr): a SIGABRT handler that writes the native call
+// stack to that descriptor before the handler that was there (Python's faulthandler) runs — an abort inside a runtime
+// library then names the library.  When the descriptor is not 2 and descriptor 2 is a regular file (pytest's capture
+// file, which dies with the process), the last 4 KB written to it — the runtime's own last words, e.g. "Memory
+// access fault by GPU node ..." — are copied over first.
+namespace {
+struct sigaction g_prev_abort;
+int g_abort_fd = 2;
+void abort_trace(int sig)
+{
+    if (g_abort_fd != 2) {
+        struct stat st;
+        if (fstat(2, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+            static char tail[4096];
+            const off_t from = st.st_size > off_t(sizeof tail) ? st.st_size - off_t(sizeof tail) : 0;
+            const ssize_t got = pread(2, tail, sizeof tail, from);
+            if (got > 0) {
+                static const char h1[] = "\nlibmdx: SIGABRT; last output on the captured stderr:\n";
+                (void)!write(g_abort_fd, h1, sizeof h1 - 1);
+                (void)!write(g_abort_fd, tail, size_t(got));
+            }
+        }
+    }
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    static const char head[] = "\nlibmdx: SIGABRT; native call stack (module(+offset)):\n";
+    (void)!write(g_abort_fd, head, sizeof head - 1);
+    backtrace_symbols_fd(frames, n, g_abort_fd);
+    sigaction(SIGABRT, &g_prev_abort, nullptr);
+    raise(sig);
+}
+__attribute__((constructor)) void mdx_process_init()
+{
+    setenv("GPU_PINNED_MIN_XFER_SIZE", "1048576", 0);       // MiB
+    const char *t = getenv("MDX_ABORT_TRACE");
+    if (t && *t && *t != '0') {
+        const int fd = atoi(t);
+        g_abort_fd = fd > 2 ? fd : 2;
+        struct sigaction sa;
+        memset(&sa, 0, sizeof sa);
+        sa.sa_handler = abort_trace;
+        sigemptyset(&sa.sa_mask);
+        sa.sa_flags = SA_NODEFER;
+        sigaction(SIGABRT, &sa, &g_prev_abort);
+    }
+}
+}  // namespace
 
 int set_device(int dev)
 {
@@ -602,6 +671,35 @@ int HostStager::download(int device, hipStream_t producer, void *dst, const void
     return retire();
 }
 
+// [ptr, ptr + bytes) lies in anonymous private memory (malloc / numpy / mmap(MAP_ANONYMOUS)) as /proc/self/maps
+// tells it: no path, or [heap] / [stack] / [anon:...]; every page of the range covered.  Anything the table does not
+// vouch for is treated as file-backed.
+static bool host_range_is_anonymous(const void *ptr, size_t bytes)
+{
+    FILE *f = fopen("/proc/self/maps", "r");
+    if (!f)
+        return false;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(ptr), b = a + bytes;
+    uintptr_t covered_to = a;
+    bool ok = true;
+    char line[512];
+    while (ok && covered_to < b && fgets(line, sizeof line, f)) {
+        unsigned long lo = 0, hi = 0, off = 0, ino = 0;
+        char perms[8] = {0}, devs[16] = {0}, path[256] = {0};
+        const int n = sscanf(line, "%lx-%lx %7s %lx %15s %lu %255s", &lo, &hi, perms, &off, devs, &ino, path);
+        if (n < 6 || hi <= covered_to)
+            continue;
+        if (lo > covered_to)
+            ok = false;                               // a hole in the range
+        else if (ino != 0 || (n >= 7 && path[0] == '/') || perms[3] != 'p')
+            ok = false;                               // file-backed or shared
+        else
+            covered_to = hi;
+    }
+    fclose(f);
+    return ok && covered_to >= b;
+}
+
 int HostStager::upload_rows(int device, hipStream_t consumer, void *d_dst, const void *src, size_t row_bytes,
                             size_t src_stride, size_t n_rows)
 {
@@ -609,21 +707,22 @@ int HostStager::upload_rows(int device, hipStream_t consumer, void *d_dst, const
         return MDX_OK;
     if (src_stride == row_bytes)
         return upload(device, consumer, d_dst, src, row_bytes * n_rows);
-    // Pageable rows of a few KB and more: the runtime's own 2-D copy.  It locks the pages it is handed and the DMA
-    // engine reads the rows where they lie — 57 GB/s for 15 .. 30 KB rows 120 KB apart (the link's own rate), where
-    // the copy threads' gather into the ring reaches 34 .. 40 (profiles/r05_host_feed_rates.txt,
-    // r05_mmap_feed_rates.json: no host core touches the data).  It follows what the consumer queued before, and
-    // the call returns when the copy has ended (the caller may reuse the source, as with the ring):
-    // copy_rows_pageable.  Short rows keep the gather: a DMA descriptor per 12-byte row is no way to move a
-    // particle's track.
-    // MDX_RING_ROWS=1 (A/B hook) keeps the ring for every row length.
+    // Pageable rows of a few KB and more, a couple of pages apart, in anonymous memory: locked slice by slice and
+    // read by the DMA engine where they lie (copy_rows_locked: 53 - 54 GB/s for 15 .. 30 KB rows 120 KB apart, where
+    // the copy threads' gather into the ring reaches 34 - 40; no host core touches the data).  Short rows keep the
+    // gather: a DMA descriptor per 12-byte row is no way to move a particle's track.  MDX_RING_ROWS=1 (A/B hook)
+    // keeps the ring for every row length.
     static const bool ring_rows = getenv("MDX_RING_ROWS") != nullptr;
-    if (row_bytes >= 4096 && !ring_rows && host_range_registered(src, (n_rows - 1) * src_stride + row_bytes) == 0) {
+    if (row_bytes >= 4096 && src_stride >= row_bytes + 8192 && !ring_rows &&
+        host_range_registered(src, (n_rows - 1) * src_stride + row_bytes) == 0) {
         hipPointerAttribute_t attr;
         const bool pageable = hipPointerGetAttributes(&attr, src) != hipSuccess || attr.type == hipMemoryTypeUnregistered;
         (void)hipGetLastError();
-        if (pageable)
-            return copy_rows_pageable(device, consumer, d_dst, src, row_bytes, src_stride, n_rows, false);
+        if (pageable && host_range_is_anonymous(src, (n_rows - 1) * src_stride + row_bytes)) {
+            const int rc = copy_rows_locked(device, consumer, d_dst, src, row_bytes, src_stride, n_rows);
+            if (rc <= 0)
+                return rc;
+        }
     }
     std::lock_guard<std::mutex> guard(lock);
     const uint8_t *from = static_cast<const uint8_t *>(src);
@@ -656,17 +755,21 @@ int HostStager::upload_rows(int device, hipStream_t consumer, void *d_dst, const
     return finish(consumer);
 }
 
-// n_rows rows of row_bytes, src_stride apart in PAGEABLE host memory (anonymous memory, or a read-only mapping of a
-// file in the page cache) -> contiguous rows in HBM by the runtime's own 2-D copies: the runtime locks the pages it
-// is handed, maps them for the device and lets the DMA engine read them where they lie.  The rows are cut into
-// slices of ~128 MB that the copy threads issue side by side, each on a stream of its own: what a slice costs before
-// its DMA starts — locking and mapping its pages (a first copy out of fresh memory runs at 46 - 49 GB/s against
-// 57.5 for a repeated one), and with touch_pages the population of a fresh file mapping's page tables (a first copy
-// out of an untouched mapping: 30 GB/s; profiles/r05_mmap_pretouch.json) — then runs beside the DMA of other slices.
+// n_rows rows of row_bytes, src_stride apart in pageable anonymous host memory -> contiguous rows in HBM, read by
+// the DMA engine where they lie: the rows are cut into slices of ~128 MB, and every slice is page-locked
+// (hipHostRegister on the whole pages its rows span), copied by ONE 2-D DMA on a stream of its own and unlocked
+// again (hipHostUnregister) by one of the copy threads, several slices side by side.  Locking is cheap (0.25 ms per
+// 128 MB) and nothing stays registered when the call returns — unlike the runtime's own pageable path, whose kept
+// registrations are what mdx_process_init switches off.  Measured on the 12 GB of C4 in quarter-column chunks:
+// 53 - 54 GB/s with 2 .. 8 threads (the runtime's implicit route 57.5, the ring's gather 34 - 40;
+// profiles/r05_register_slices.json).
+// Callers guarantee (upload_rows checks): rows of >= 4 KB that lie >= 2 pages apart, so the page spans of two slices
+// never share a page; anonymous private memory (rows of a file mapping go through the ring: a registration is not
+// something to hold on pages another program can truncate); no page of the range registered by the caller.
 // Ordering: the copies start after what `consumer` has queued so far, and all of them have ended when the call
 // returns.
-int HostStager::copy_rows_pageable(int device, hipStream_t consumer, void *d_dst, const void *src, size_t row_bytes,
-                                   size_t src_stride, size_t n_rows, bool touch_pages)
+int HostStager::copy_rows_locked(int device, hipStream_t consumer, void *d_dst, const void *src, size_t row_bytes,
+                                 size_t src_stride, size_t n_rows)
 {
     if (row_bytes == 0 || n_rows == 0)
         return MDX_OK;
@@ -688,23 +791,35 @@ int HostStager::copy_rows_pageable(int device, hipStream_t consumer, void *d_dst
     const int n_slices = int((n_rows + rows_per - 1) / rows_per);
     const uint8_t *from = static_cast<const uint8_t *>(src);
     uint8_t *to = static_cast<uint8_t *>(d_dst);
+    const uintptr_t page = uintptr_t(sysconf(_SC_PAGESIZE) > 0 ? sysconf(_SC_PAGESIZE) : 4096);
     std::mutex err_lock;
     hipError_t first_err = hipSuccess;
-    static volatile uint8_t sink;
+    std::atomic<bool> not_lockable{false};
     const std::function<void(int)> one = [&](int k) {
+        if (not_lockable.load())
+            return;
         const size_t r0 = size_t(k) * rows_per, nr = std::min(rows_per, n_rows - r0);
+        const uintptr_t a = reinterpret_cast<uintptr_t>(from + r0 * src_stride);
+        const uintptr_t b = a + (nr - 1) * src_stride + row_bytes;
+        void *lo = reinterpret_cast<void *>(a & ~(page - 1));
+        const size_t span = size_t(((b + page - 1) & ~(page - 1)) - (a & ~(page - 1)));
         hipError_t e = hipSetDevice(device);
         hipStream_t s = nullptr;
         if (e == hipSuccess && stream_acquire(&s) != MDX_OK)
             e = hipErrorUnknown;
-        if (e == hipSuccess && touch_pages) {
-            uint8_t acc = 0;
-            for (size_t r = r0; r < r0 + nr; ++r) {
-                const uintptr_t a = reinterpret_cast<uintptr_t>(from + r * src_stride), b = a + row_bytes;
-                for (uintptr_t p = a; p < b; p = (p | 4095) + 1)
-                    acc ^= *reinterpret_cast<const volatile uint8_t *>(p);
+        bool locked = false;
+        if (e == hipSuccess) {
+            e = hipHostRegister(lo, span, hipHostRegisterDefault);
+            locked = e == hipSuccess;
+            if (!locked) {
+                // pages that cannot be locked (a limit, a kind of memory the table did not tell apart): the caller
+                // takes the ring for the whole range
+                (void)hipGetLastError();
+                not_lockable.store(true);
+                if (s)
+                    stream_release(s);
+                return;
             }
-            sink = acc;
         }
         if (e == hipSuccess && ev_ready)
             e = hipStreamWaitEvent(s, ev_ready, 0);
@@ -712,10 +827,15 @@ int HostStager::copy_rows_pageable(int device, hipStream_t consumer, void *d_dst
             e = hipMemcpy2DAsync(to + r0 * row_bytes, row_bytes, from + r0 * src_stride, src_stride, row_bytes, nr,
                                  hipMemcpyHostToDevice, s);
         if (s) {
-            const hipError_t e2 = hipStreamSynchronize(s);      // also after an error: no copy outlives the call
+            const hipError_t e2 = hipStreamSynchronize(s);      // also after an error: no copy outlives its pages' lock
             if (e == hipSuccess)
                 e = e2;
             stream_release(s);
+        }
+        if (locked) {
+            const hipError_t e3 = hipHostUnregister(lo);
+            if (e == hipSuccess)
+                e = e3;
         }
         if (e != hipSuccess) {
             std::lock_guard<std::mutex> lk(err_lock);
@@ -728,9 +848,9 @@ int HostStager::copy_rows_pageable(int device, hipStream_t consumer, void *d_dst
         (void)hipEventDestroy(ev_ready);
     if (first_err != hipSuccess) {
         (void)hipGetLastError();
-        return fail(MDX_ERR_HIP, "2-D copy out of pageable memory failed: %s", hipGetErrorString(first_err));
+        return fail(MDX_ERR_HIP, "copy of page-locked row slices failed: %s", hipGetErrorString(first_err));
     }
-    return MDX_OK;
+    return not_lockable.load() ? 1 : MDX_OK;          // 1: nothing went wrong, but the rows are not (all) there
 }
 
 void HostStager::destroy()
@@ -998,10 +1118,10 @@ int mdx_upload(int dev, void *d_dst, const void *src, size_t bytes)
 }
 
 // Large whole-array copies between pageable host memory and HBM go through the library's own pinned ring: its
-// copies are asynchronous to the engines' streams, which the staging pipelines are built on (the runtime's own
-// pageable path moves the same bytes at 56 GB/s against the ring's 54 H2D / 43 D2H, profiles/r05_pageable_vs_ring.json
-// — a performance choice either way, not a detour around a fault: NOTES round 5 on the one aborted run of round 4).
-// Strided rows take the runtime's 2-D copy (HostStager::upload_rows).  hipMemcpy's ordering is kept:
+// copies are asynchronous to the engines' streams, which the staging pipelines are built on, and the runtime's own
+// path for them page-locks caller memory and keeps the registrations (mdx_process_init above switches it off: the
+// runtime stages what is left to it).
+// Strided rows are locked and copied slice by slice (HostStager::copy_rows_locked).  hipMemcpy's ordering is kept:
 // the copy starts after everything queued on the device before the call and has ended when the call returns.
 int mdx_memcpy_h2d(int dev, void *dst, const void *src, size_t bytes)
 {

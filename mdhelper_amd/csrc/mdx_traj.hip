@@ -5,7 +5,6 @@
 #include "mdx_internal.hpp"
 
 #include <fcntl.h>
-#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -496,13 +495,8 @@ void Trajectory::close()
                 (void)hipStreamSynchronize(ring.io);
         }
         d_raw.release();
-        d_cols.release();
         dev = -1;
     }
-    if (map)
-        (void)munmap(const_cast<uint8_t *>(map), map_bytes);     // (load_columns waits for its copies: none is in flight)
-    map = nullptr;
-    map_bytes = 0;
     if (fd >= 0)
         ::close(fd);
     fd = -1;
@@ -826,96 +820,6 @@ int Trajectory::unpack_async(hipStream_t stream, const void *d_raw_in, int64_t n
     return MDX_OK;
 }
 
-__global__ __launch_bounds__(256) void traj_bswap_kernel(uint32_t *__restrict__ w, int64_t n)
-{
-    for (int64_t i = blockIdx.x * int64_t(256) + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256)
-        w[i] = __builtin_bswap32(w[i]);
-}
-
-__global__ __launch_bounds__(256) void traj_iota_kernel(int *__restrict__ idx, int first, int64_t n)
-{
-    const int64_t i = blockIdx.x * int64_t(256) + threadIdx.x;
-    if (i < n)
-        idx[i] = first + int(i);
-}
-
-int Trajectory::load_columns(int device, hipStream_t stream, const int64_t *frames, int64_t n, int64_t first,
-                             int64_t count, float *d_out)
-{
-    MDX_TRY(check_frames(*this, frames, n));
-    MDX_REQUIRE(first >= 0 && count >= 1 && first + count <= n_atoms, "particle range out of bounds");
-    if (n == 0)
-        return MDX_OK;
-    MDX_REQUIRE(d_out, "NULL output");
-    if (dev >= 0 && dev != device)
-        return fail(MDX_ERR_STATE, "trajectory handle is bound to device %d", dev);
-    MDX_TRY(set_device(device));
-    dev = device;
-    const int64_t row_bytes = 12 * count;
-    // maximal runs of equally spaced frames (a slice start:stop:step of the trajectory is one run)
-    struct Run { int64_t i0, len, step; };
-    std::vector<Run> runs;
-    for (int64_t i = 0; i < n;) {
-        int64_t j = i + 1;
-        const int64_t step = j < n ? frames[j] - frames[i] : 1;
-        if (step > 0)
-            while (j < n && frames[j] - frames[j - 1] == step)
-                ++j;
-        runs.push_back({i, j - i, step > 0 ? step : 1});
-        i = j;
-    }
-    bool mapped = format == TRAJ_NETCDF && row_bytes >= 4096 && !map_failed && !getenv("MDX_TRAJ_NO_MMAP") &&
-                  int64_t(runs.size()) * 64 <= n + 63;
-    if (mapped && !map) {
-        void *m = mmap(nullptr, size_t(file_bytes), PROT_READ, MAP_SHARED, fd, 0);
-        if (m == MAP_FAILED) {
-            map_failed = true;       // (an address space or a file system that does not map: the ring serves)
-            mapped = false;
-        } else {
-            map = static_cast<const uint8_t *>(m);
-            map_bytes = size_t(file_bytes);
-        }
-    }
-    if (mapped) {
-        // the file as it is NOW: a mapping read past the end of a file that lost its tail is a bus error, not an errno
-        struct stat st;
-        if (fstat(fd, &st) != 0)
-            return fail(MDX_ERR_IO, "cannot stat the trajectory: %s", strerror(errno));
-        int64_t last = 0;
-        for (int64_t i = 0; i < n; ++i)
-            last = std::max(last, frames[i]);
-        const int64_t need = coord_first + last * frame_stride + 12 * (first + count);
-        if (int64_t(st.st_size) < need)
-            return fail(MDX_ERR_IO, "trajectory read failed: the file ends at byte %lld, frame %lld needs %lld "
-                        "(truncated after it was opened?)", (long long)st.st_size, (long long)last, (long long)need);
-        HostStager &ring = device_stager(device);
-        for (const Run &r : runs) {
-            const uint8_t *src = map + coord_first + frames[r.i0] * frame_stride + 12 * first;
-            MDX_TRY(ring.copy_rows_pageable(device, stream, reinterpret_cast<uint8_t *>(d_out) + r.i0 * row_bytes, src,
-                                            size_t(row_bytes), size_t(r.step * frame_stride), size_t(r.len), true));
-        }
-        if (swap) {
-            const int64_t words = n * count * 3;
-            const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(words, 256 * 8), 1 << 20);
-            hipLaunchKernelGGL(traj_bswap_kernel, dim3(grid), dim3(256), 0, stream, reinterpret_cast<uint32_t *>(d_out),
-                               words);
-            MDX_HIP(hipGetLastError());
-        }
-        return MDX_OK;
-    }
-    // whole frames through the pinned ring, the particles picked by the unpack kernel
-    const int *d_index = nullptr;
-    if (first != 0) {                        // (d_index == nullptr: the first `count` particles)
-        MDX_TRY(d_cols.ensure(size_t(4) * count));
-        hipLaunchKernelGGL(traj_iota_kernel, dim3((unsigned)ceil_div(count, 256)), dim3(256), 0, stream,
-                           d_cols.as<int>(), int(first), count);
-        MDX_HIP(hipGetLastError());
-        d_index = d_cols.as<int>();
-    }
-    TrajSelection s{d_index, count, d_out};
-    return stage_async(device, stream, frames, n, &s, 1);
-}
-
 }  // namespace mdx
 
 // ---------------------------------------------------------------------------------- C-ABI
@@ -999,32 +903,9 @@ int mdx_traj_load_device(mdx_traj_t h, int dev, const int64_t *frames, int64_t n
     MDX_TRY(set_device(dev));
     if (!h->stream)
         MDX_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    if (!d_index && n > 0) {
-        // the first n_sel (or all) particles: rows of the frames, read where the page cache holds them (NetCDF)
-        const int rc = h->t.load_columns(dev, h->stream, frames, n, 0, n_sel > 0 ? n_sel : h->t.n_atoms, d_out);
-        const hipError_t e = hipStreamSynchronize(h->stream);
-        MDX_TRY(rc);
-        MDX_HIP(e);
-        return MDX_OK;
-    }
     TrajSelection s{d_index, d_index ? n_sel : (n_sel > 0 ? n_sel : h->t.n_atoms), d_out};
     MDX_TRY(h->t.stage_async(dev, h->stream, frames, n, &s, 1));
     MDX_HIP(hipStreamSynchronize(h->stream));
-    return MDX_OK;
-}
-
-int mdx_traj_load_columns_device(mdx_traj_t h, int dev, const int64_t *frames, int64_t n, int64_t first,
-                                 int64_t count, float *d_out)
-{
-    MDX_REQUIRE(h, "NULL handle");
-    MDX_REQUIRE(n == 0 || d_out, "NULL output");
-    MDX_TRY(set_device(dev));
-    if (!h->stream)
-        MDX_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    const int rc = h->t.load_columns(dev, h->stream, frames, n, first, count, d_out);
-    const hipError_t e = hipStreamSynchronize(h->stream);     // also on an error: nothing outlives the call
-    MDX_TRY(rc);
-    MDX_HIP(e);
     return MDX_OK;
 }
 

@@ -58,10 +58,6 @@ struct Trajectory {
     // between the copy and the unpack kernel of stage_async
     int dev = -1;
     DeviceBuffer d_raw;
-    DeviceBuffer d_cols;                 // particle index of the load_columns fallback
-    const uint8_t *map = nullptr;        // read-only mapping of the whole file (load_columns), made on first use
-    size_t map_bytes = 0;
-    bool map_failed = false;
 
     int open(const char *path);
     void close();
@@ -85,16 +81,6 @@ struct Trajectory {
     //                    the ring's stream; `consumer` waits for them;
     //   unpack_async     the unpack kernel(s) on the CALLER's stream, in order with its other kernels.
     int stage_raw_async(int device, hipStream_t consumer, const int64_t *frames, int64_t n, void *d_raw_out);
-
-    // Particles [first, first + count) of the listed frames -> d_out float32[n][count][3] (native byte order), ordered
-    // on `stream`; returns when the copies have ended (kernels may still be queued on `stream`).  NetCDF files are
-    // mapped read-only and the DMA engine reads the rows where the page cache holds them (HostStager::
-    // copy_rows_pageable: no host core copies the data; runs of equally spaced frames are one 2-D copy each), the
-    // byte swap is a kernel on `stream`.  Anything that route does not take — DCD planes, rows under 4 KB, frame
-    // lists without long regular runs, MDX_TRAJ_NO_MMAP=1, a mapping that fails — goes through stage_async with an
-    // index of the particles.
-    int load_columns(int device, hipStream_t stream, const int64_t *frames, int64_t n, int64_t first, int64_t count,
-                     float *d_out);
     int unpack_async(hipStream_t stream, const void *d_raw_in, int64_t n, const TrajSelection *sel,
                      int n_sel) const;
 

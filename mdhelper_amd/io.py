@@ -82,12 +82,6 @@ class TrajectoryFile:
         f = self._frames(frames)
         check(lib().mdx_traj_load_device(self.handle, dev, _ptr(f), len(f), d_index, n_sel, d_out))
 
-    def load_columns_device(self, frames, first, count, d_out, *, dev=0):
-        """Particles ``[first, first + count)`` of the frames into HBM: ``d_out`` float32[len(frames)][count][3]
-        (raw pointer).  NetCDF: the DMA engine reads the rows out of the page cache (``mdx_traj_load_columns_device``)."""
-        f = self._frames(frames)
-        check(lib().mdx_traj_load_columns_device(self.handle, dev, _ptr(f), len(f), int(first), int(count), d_out))
-
 
 class FileTrajectory:
     """``universe.trajectory`` over a :class:`TrajectoryFile`."""

@@ -1,7 +1,9 @@
+import os
 import pathlib
 import sys
 
 import pytest
+
 
 ROOT = pathlib.Path(__file__).resolve().parents[1]
 if str(ROOT) not in sys.path:
@@ -12,6 +14,19 @@ GOLDEN = ROOT / "tests" / "golden"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Before libmdx.so is loaded: a SIGABRT inside a runtime library writes the native call stack — and the last
+    # lines the runtime wrote to the CAPTURED stderr, which die with the process otherwise — to the stderr pytest
+    # itself was started with (csrc/mdx_runtime.hip, MDX_ABORT_TRACE).
+    fd = 2
+    try:
+        cap = config.pluginmanager.getplugin("capturemanager")._global_capturing
+        saved = getattr(cap.err, "targetfd_save", None)
+        if isinstance(saved, int) and saved > 2:
+            fd = saved
+            os.set_inheritable(fd, False)
+    except Exception:
+        pass
+    os.environ.setdefault("MDX_ABORT_TRACE", str(fd))
 
 
 @pytest.fixture(scope="session")

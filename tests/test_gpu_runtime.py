@@ -37,6 +37,29 @@ def test_upload_and_strided_rows_round_trip(pinned):
             check(lib().mdx_host_unregister(0, h.ctypes.data))
 
 
+def test_strided_rows_out_of_a_file_mapping_take_the_ring(tmp_path):
+    """Rows of a numpy.memmap (file-backed pages): never handed to the runtime's pageable 2-D copy — the runtime keeps
+    copied ranges registered with the driver, and a file that is truncated afterwards then hangs every later GPU
+    operation of the process (scripts/diag/mmap_truncate_probe.py).  They go through the copy threads and the pinned
+    ring; the file may lose its tail afterwards and the device stays usable."""
+    import os
+    T, N = 300, 4099
+    rng = np.random.default_rng(5)
+    path = tmp_path / "frames.bin"
+    ref = rng.normal(size=(T, N, 3)).astype(np.float32)
+    ref.tofile(path)
+    h = np.memmap(path, dtype=np.float32, mode="r", shape=(T, N, 3))
+    buf = _core.DeviceArray((T, 1000, 3), np.float32)
+    buf.upload_columns(h, 17, 1000)                    # 12 KB rows: the runtime's route if the memory were anonymous
+    assert np.array_equal(buf.to_host(), ref[:, 17:1017])
+    del h
+    os.truncate(path, os.path.getsize(path) // 2)
+    again = _core.DeviceArray.from_host(np.arange(1000.0))
+    assert np.array_equal(again.to_host(), np.arange(1000.0))
+    buf.free()
+    again.free()
+
+
 def test_a_range_registered_too_short_goes_through_the_ring():
     """memory whose START is page-locked but whose end is not must not be handed to the DMA engine.
     (A page-aligned buffer, whole pages registered; the registration ends before the buffer does.)"""

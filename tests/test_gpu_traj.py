@@ -50,66 +50,6 @@ def test_load_device_equals_host_reader(tmp_path, kind):
 
 
 @pytest.mark.parametrize("kind", ["netcdf", "dcd"])
-def test_load_columns_device_equals_host_reader(tmp_path, kind, monkeypatch):
-    """mdx_traj_load_columns_device: particles [first, first + count) of listed frames.  NetCDF: rows of >= 4 KB of
-    equally spaced frames are 2-D copies out of the mapped file (the DMA engine reads the page cache) + a byte
-    swap on the device; short rows, irregular lists, DCD planes and MDX_TRAJ_NO_MMAP=1 go through the pinned
-    ring.  Every route: the host reader's bytes."""
-    F, N, L = 300, 5003, 60.0
-    pos = _frames(F, N, L, 17)
-    path = tmp_path / ("c.nc" if kind == "netcdf" else "c.dcd")
-    if kind == "netcdf":
-        write_amber_netcdf(path, pos, (L, L, L))
-    else:
-        write_dcd(path, pos, [[L, L, L, 90, 90, 90]])
-    t = TrajectoryFile(path)
-    cases = [(np.arange(F), 0, N), (np.arange(F), 1234, 2000), (np.arange(5, F, 3), 4000, 1003),
-             (np.arange(F), 17, 100),                                       # rows of 1.2 KB: the ring
-             (np.concatenate([np.arange(0, 128), np.arange(200, 290, 2)]), 100, 900),   # two regular runs
-             (np.random.default_rng(5).permutation(F)[:40], 0, 3000),      # no regular runs: the ring
-             (np.array([7]), 2, 5000)]
-    for frames, first, count in cases:
-        out = _core.DeviceArray((len(frames), count, 3), np.float32)
-        t.load_columns_device(frames, first, count, out.ptr)
-        assert np.array_equal(out.to_host(), pos[frames][:, first:first + count]), (len(frames), first, count)
-        out.free()
-    # whole frames through mdx_traj_load_device (no index): the same route
-    out = _core.DeviceArray((F, N, 3), np.float32)
-    t.load_device(np.arange(F), out.ptr)
-    assert np.array_equal(out.to_host(), pos)
-    with pytest.raises(ValueError):
-        t.load_columns_device(np.arange(3), N - 5, 10, out.ptr)
-    t.close()
-    # the mapping switched off: the ring serves every case
-    monkeypatch.setenv("MDX_TRAJ_NO_MMAP", "1")
-    t = TrajectoryFile(path)
-    t.load_columns_device(np.arange(F), 1234, 2000, out.ptr)
-    assert np.array_equal(_core.DeviceArray.view(out, (F, 2000, 3)).to_host(), pos[:, 1234:3234])
-    out.free()
-    t.close()
-
-
-def test_load_columns_of_a_file_that_lost_its_tail_is_an_io_error(tmp_path):
-    """The mapped route checks the file's size as it is NOW before the DMA engine is pointed at it (a mapping read
-    past the end of a truncated file is a bus error, not an errno); the frames that are still there load."""
-    import os
-    F, N, L = 64, 6000, 38.0
-    pos = _frames(F, N, L, 23)
-    path = tmp_path / "cut.nc"
-    write_amber_netcdf(path, pos, (L, L, L))
-    t = TrajectoryFile(path)
-    out = _core.DeviceArray((F, 3000, 3), np.float32)
-    t.load_columns_device(np.arange(F), 1000, 3000, out.ptr)          # maps the file
-    os.truncate(path, os.path.getsize(path) - 20 * 12 * N)
-    with pytest.raises(OSError):
-        t.load_columns_device(np.arange(F), 1000, 3000, out.ptr)
-    t.load_columns_device(np.arange(32), 1000, 3000, out.ptr)
-    assert np.array_equal(_core.DeviceArray.view(out, (32, 3000, 3)).to_host(), pos[:32, 1000:4000])
-    out.free()
-    t.close()
-
-
-@pytest.mark.parametrize("kind", ["netcdf", "dcd"])
 def test_rdf_from_file_universe_bit_exact(tmp_path, kind):
     F, N, L = 24, 3000, 31.0
     pos = _frames(F, N, L, 12)
