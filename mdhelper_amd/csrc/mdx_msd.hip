@@ -267,55 +267,95 @@ __global__ void msd_real_to_complex_kernel(const double *__restrict__ P, int64_t
 
 // MSD_m = S_m - 2 A_m of one (group, block) row on the device (correlation.py:621-648, summed over the particles):
 //   S_m (T_b - m) = 2 sum_k D_k - sum_{k=1..m} (D_{k-1} + D_{T_b-k}),   A_m = acf[m] / n_fft,
-// out[m] = (2 total - run_m) / (T_b - m) - 2 A_m / (T_b - m).  One block per row: a block-wide sum for `total`, then
-// thread t owns the lags [t L, (t + 1) L) — segment sums, an exclusive scan of the 1 024 segment sums in LDS, and a
-// second walk that writes the row.  (The host used to do this after a pageable copy of acf and D: ~1 ms per analysis
-// at C4 size, against ~0.1 ms here plus the copy of the finished row.)
+// out[m] = (2 total - run_m) / (T_b - m) - acf_factor A_m / (T_b - m)   (acf_factor 2; 1 for the cross displacements of
+// mdx_msd_cross, whose spectrum product carries the 2).  One block per row.  `total` is a block-wide sum; the running
+// sum is a scan over tiles of 4 096 lags: the tile's terms and its acf values are loaded with consecutive threads on
+// consecutive addresses and parked in LDS, thread t then owns the four lags 4 t .. 4 t + 3 of the tile — its partial
+// sum goes through a block-wide exclusive scan (wave shuffles, then the sixteen wave totals) —, the finished values go
+// back through LDS and are stored the way they were loaded.  (The first form of this kernel gave every thread one
+// long segment of the row: every load of a wave touched 64 different lines, and at C4 size — 2 rows of 100 000 lags —
+// it took longer than the host loop it had replaced: result() 0.77 -> 1.1 - 1.4 ms.)
 constexpr int FINISH_THREADS = 1024;
+constexpr int FINISH_PER = 4;                                   // lags per thread and tile
+constexpr int FINISH_TILE = FINISH_THREADS * FINISH_PER;
 __global__ __launch_bounds__(FINISH_THREADS) void msd_finish_kernel(const double *__restrict__ acf, int64_t acf_stride,
                                                                    const double *__restrict__ D, int64_t t_block,
                                                                    double inv_n, double *__restrict__ out,
                                                                    double acf_factor = 2.0)
 {
-    __shared__ double red[FINISH_THREADS];
-    const int tid = threadIdx.x;
+    __shared__ double sv[FINISH_TILE];        // terms D_{m-1} + D_{T-m}, then the finished values
+    __shared__ double sa[FINISH_TILE];        // acf[m]
+    __shared__ double wsum[FINISH_THREADS / 64];
+    __shared__ double s_total, s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t row = blockIdx.x;
     const double *d = D + row * t_block;
     const double *a = acf + row * acf_stride;
     double *o = out + row * t_block;
-    const int64_t L = (t_block + FINISH_THREADS - 1) / FINISH_THREADS;
-    const int64_t lo = min<int64_t>(int64_t(tid) * L, t_block), hi = min<int64_t>(lo + L, t_block);
-    double part = 0.0, seg = 0.0;
-    for (int64_t m = lo; m < hi; ++m) {
+    // total of D
+    double part = 0.0;
+    for (int64_t m = tid; m < t_block; m += FINISH_THREADS)
         part += d[m];
-        if (m > 0)
-            seg += d[m - 1] + d[t_block - m];
-    }
-    // total of D: tree over the threads
-    red[tid] = part;
+    for (int off = 32; off > 0; off >>= 1)
+        part += __shfl_down(part, off, 64);
+    if (lane == 0)
+        wsum[wave] = part;
     __syncthreads();
-    for (int w = FINISH_THREADS / 2; w > 0; w >>= 1) {
-        if (tid < w)
-            red[tid] += red[tid + w];
-        __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < FINISH_THREADS / 64; ++w)
+            t += wsum[w];
+        s_total = t;
+        s_carry = 0.0;
     }
-    const double total = red[0];
     __syncthreads();
-    // exclusive scan of the segment sums (Hillis-Steele on 1 024 values)
-    red[tid] = seg;
-    __syncthreads();
-    for (int w = 1; w < FINISH_THREADS; w <<= 1) {
-        const double v = tid >= w ? red[tid - w] : 0.0;
+    const double total = s_total;
+    for (int64_t m0 = 0; m0 < t_block; m0 += FINISH_TILE) {
+#pragma unroll
+        for (int j = 0; j < FINISH_PER; ++j) {
+            const int64_t m = m0 + j * FINISH_THREADS + tid;
+            const bool in = m < t_block;
+            sv[j * FINISH_THREADS + tid] = (in && m > 0) ? d[m - 1] + d[t_block - m] : 0.0;
+            sa[j * FINISH_THREADS + tid] = in ? a[m] : 0.0;
+        }
         __syncthreads();
-        red[tid] += v;
+        double v[FINISH_PER], mine = 0.0;
+#pragma unroll
+        for (int i = 0; i < FINISH_PER; ++i) {
+            mine += sv[FINISH_PER * tid + i];
+            v[i] = mine;                                  // inclusive within the thread
+        }
+        // exclusive scan of `mine` over the block
+        double incl = mine;
+        for (int off = 1; off < 64; off <<= 1) {
+            const double up = __shfl_up(incl, off, 64);
+            if (lane >= off)
+                incl += up;
+        }
+        if (lane == 63)
+            wsum[wave] = incl;
         __syncthreads();
-    }
-    double run = red[tid] - seg;
-    for (int64_t m = lo; m < hi; ++m) {
-        if (m > 0)
-            run += d[m - 1] + d[t_block - m];
-        const double w = double(t_block - m);
-        o[m] = (2.0 * total - run) / w - acf_factor * (a[m] * inv_n) / w;
+        double before = s_carry;
+        for (int w = 0; w < wave; ++w)
+            before += wsum[w];
+        before += incl - mine;
+#pragma unroll
+        for (int i = 0; i < FINISH_PER; ++i) {
+            const int64_t m = m0 + FINISH_PER * tid + i;
+            const double w = double(t_block - m);
+            const double run = before + v[i];
+            sv[FINISH_PER * tid + i] = (2.0 * total - run) / w - acf_factor * (sa[FINISH_PER * tid + i] * inv_n) / w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < FINISH_PER; ++j) {
+            const int64_t m = m0 + j * FINISH_THREADS + tid;
+            if (m < t_block)
+                o[m] = sv[j * FINISH_THREADS + tid];
+        }
+        if (tid == FINISH_THREADS - 1)
+            s_carry = before + mine;                      // everything up to the end of this tile
+        __syncthreads();
     }
 }
 
