@@ -1239,6 +1239,8 @@ int mdx_msd_set_grouping(mdx_msd_t h, int64_t n_molecules, const int64_t *offset
 {
     MDX_REQUIRE(h, "NULL handle");
     MDX_TRY(set_device(h->dev));
+    if (n_molecules <= 0 && h->mol_offsets.empty())
+        return MDX_OK;               // no grouping before, none now: nothing the queued pushes read changes
     MDX_HIP(hipStreamSynchronize(h->stream));
     h->mol_offsets.clear();
     if (n_molecules <= 0)
