@@ -962,6 +962,102 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_rows512_power_kernel(
     *pout = accumulate ? *pout + total : total;
 }
 
+// Pass B for R2 = 1024 in the same form (round 5): 400 x 1024 = 409 600, 64 x 1024 = 2^16 and 1024 x 1024 = 2^20
+// went through the general kernel above — staging pass, three in-place LDS stages, read-back, three barriers per
+// 128 KB piece — at 3.5 - 3.7 TB/s where the 512-point kernel streams Y at 6.0.  Here a thread's SIXTEEN loads (pair
+// tid & 7, points j + 64 r, j = tid >> 3) are the inputs of first-stage butterfly j of 1024 = 16 x 8 x 8: the
+// radix-16 stage runs on the registers the loads land in, its outputs go to LDS once (one barrier), the radix-8
+// stage with NS = 16 is the wave-private in-place one (two butterflies per lane), and the last radix-8 stage
+// (NS = 128: butterfly l reads points l + 128 r, output r is X[l + 128 r]) ends in registers — lane l of wave w holds
+// X[l + 64 q + 128 r] of pair w, q < 2, and adds |X|^2 to sixteen running sums.  128 KB of LDS per block: one block
+// per CU, whose next piece (16 x 16 B per thread) is in flight during stages 2 and 3.
+template <int R1>
+__global__ __launch_bounds__(THREADS, 2) void msd_fft_rows1024_power_kernel(
+    const double2 *__restrict__ Y, int p_pad, const double2 *__restrict__ tw_r2,
+    double *__restrict__ Pfull, int accumulate, int pg_major = 0)
+{
+    constexpr int R2 = 1024, ZS = R2 + 1;
+    __shared__ double2 zb[PG][ZS];
+    __shared__ double2 s_tw[R2 / 2];
+    const int k1 = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < R2 / 2; i += THREADS)
+        s_tw[i] = tw_r2[i];
+    const int n_all = p_pad / PG, n_parts = gridDim.z, part = blockIdx.z;
+    const int n_groups = (n_all - part + n_parts - 1) / n_parts;      // groups part, part + n_parts, ...
+    double *pout = Pfull + ((int64_t(part) * gridDim.y + b) * R1 + k1) * R2 + tid;
+    if (n_groups <= 0) {   // more parts than pair groups: this part contributes nothing
+        if (!accumulate) {
+            pout[0] = 0.0;
+            pout[THREADS] = 0.0;
+        }
+        return;
+    }
+    const int64_t k1_stride = pg_major ? int64_t(R2) * PG : int64_t(n_all) * R2 * PG;
+    const int64_t pg_stride = pg_major ? int64_t(R1) * R2 * PG : int64_t(R2) * PG;
+    const int64_t g_stride = int64_t(n_parts) * pg_stride;
+    const double2 *src = Y + int64_t(b) * n_all * (int64_t(R1) * R2 * PG) + int64_t(k1) * k1_stride + int64_t(part) * pg_stride + tid;
+    const int p = tid & 7, j = tid >> 3;
+    double2 v[16];
+    double acc[2][8];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        v[r] = src[THREADS * r];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            acc[q][r] = 0.0;
+    __syncthreads();   // twiddle table
+    for (int pg = 0; pg < n_groups; ++pg) {
+        // stage 1 (radix 16, NS = 1, no twiddles) on the loaded values: butterfly j of pair p -> points 16 j + r
+        dft16(v);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            zb[p][16 * j + r] = v[r];
+        __syncthreads();
+        {   // the next group's rows are in flight during stages 2 and 3 (the last iteration reloads its own group)
+            const int64_t off = int64_t(min(pg + 1, n_groups - 1)) * g_stride;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                v[r] = src[off + THREADS * r];
+        }
+        stockham_stage<R2, 8, 16, false>(zb[wave], s_tw, lane, R2);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {   // stage 3 (radix 8, NS = 128): butterfly l = lane + 64 q
+            const int l = lane + 64 * q;
+            double2 u[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                u[r] = zb[wave][l + 128 * r];
+                if (r)
+                    u[r] = cmul(u[r], tw_at<R2>(s_tw, r * l));
+            }
+            dft8(u);
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                acc[q][r] = fma(u[r].x, u[r].x, fma(u[r].y, u[r].y, acc[q][r]));
+        }
+        __syncthreads();
+    }
+    // the eight waves' sums (one pair index each), added in wave order
+    double *red = reinterpret_cast<double *>(&zb[0][0]);      // 8 x 1024 doubles
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            red[wave * R2 + lane + 64 * q + 128 * r] = acc[q][r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        double total = 0.0;
+#pragma unroll
+        for (int w = 0; w < PG; ++w)
+            total += red[w * R2 + tid + THREADS * i];
+        pout[THREADS * i] = accumulate ? pout[THREADS * i] + total : total;
+    }
+}
+
 // Pass B for 8-, 16-, 32- and 64-point rows (n_fft = 3 200 = 400 x 8, 6 400 = 400 x 16, 12 800 = 400 x 32, 25 600 = 400 x 64:
 // blocks of 801 .. 1 600, 1 601 .. 3 200, 4 097 .. 6 400 and 8 193 .. 12 800 frames — C4 with eight blocks is the last, whose half-transformed
 // block is then as large as with one block; padded to 2^15 it was 28 % larger).
@@ -1650,6 +1746,9 @@ inline void launch_rows(dim3 gb, hipStream_t stream, const double2 *Y, int p_pad
     else if constexpr (R2 == 128 || R2 == 256)
         hipLaunchKernelGGL((msd_fft_rows_mid_power_kernel<R1, R2>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,
                            Pfull, accumulate, pg_major);
+    else if constexpr (R2 == 1024)
+        hipLaunchKernelGGL((msd_fft_rows1024_power_kernel<R1>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,
+                           Pfull, accumulate, pg_major);
     else
         hipLaunchKernelGGL((msd_fft_rows_power_kernel<R1, R2>), gb, dim3(THREADS), 0, stream, Y, p_pad, tw_r2,
                            Pfull, accumulate, pg_major);
@@ -1764,7 +1863,7 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
             hipLaunchKernelGGL((msd_fft_rows512_power_kernel<400>), gb, dim3(THREADS), 0, stream, Y, p_pad,
                                tw_r2, Pfull, accumulate, pg_major);
         else
-            hipLaunchKernelGGL((msd_fft_rows_power_kernel<400, 1024>), gb, dim3(THREADS), 0, stream, Y, p_pad,
+            hipLaunchKernelGGL((msd_fft_rows1024_power_kernel<400>), gb, dim3(THREADS), 0, stream, Y, p_pad,
                                tw_r2, Pfull, accumulate, pg_major);
     } else if (sh.r1 == 512 && sh.r2 == 512) {
         MDX_MSDFFT_LAUNCH(512, 512);

@@ -106,3 +106,20 @@ def test_one_rocm_runtime_and_a_foreign_one_is_refused():
     for path in [*(ROOT / "mdhelper_amd").rglob("*.py"), ROOT / "bench.py", ROOT / "__graft_entry__.py"]:
         text = path.read_text()
         assert not re.search(r"^\s*(import torch|from torch)", text, flags=re.M), path
+
+
+def test_the_runtime_is_told_not_to_page_lock_caller_memory():
+    """csrc/mdx_runtime.hip, mdx_process_init: GPU_PINNED_MIN_XFER_SIZE is out of reach from the moment the library is
+    loaded (a value the user has set stays) — the HIP runtime then stages pageable copies instead of locking caller
+    pages and keeping the registrations (NOTES.md round 5)."""
+    import os
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r); from mdhelper_amd import _lib; _lib.lib(); "
+            "print(os.environ.get('GPU_PINNED_MIN_XFER_SIZE'))" % str(ROOT))
+    env = {k: v for k, v in os.environ.items() if k != "GPU_PINNED_MIN_XFER_SIZE"}
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True)
+    assert out.stdout.strip() == "1048576"
+    out = subprocess.run([sys.executable, "-c", code], env={**env, "GPU_PINNED_MIN_XFER_SIZE": "7"},
+                         capture_output=True, text=True, check=True)
+    assert out.stdout.strip() == "7"
