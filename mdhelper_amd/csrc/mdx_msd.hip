@@ -1543,31 +1543,15 @@ static int msd_result(mdx_msd_t h, double *msd_self_sum, double *acf_sum, double
         h->timer.collect();
         return MDX_OK;
     }
-    std::vector<double> acf(size_t(GB) * Tb), D(size_t(GB) * Tb);
-    MDX_HIP(hipMemcpy2DAsync(acf.data(), size_t(Tb) * 8, h->d_inv_out.ptr, size_t(h->n_fft) * 8,
-                             size_t(Tb) * 8, (size_t)GB, hipMemcpyDeviceToHost, h->stream));
-    MDX_HIP(hipMemcpyAsync(D.data(), h->dsq(0), size_t(8) * GB * Tb, hipMemcpyDeviceToHost, h->stream));
-    MDX_HIP(hipStreamSynchronize(h->stream));
+    // (mdx_msd_result_acf) sum over particles and dimensions of sum_k x(k) x(k+m), not normalised: the live lags of
+    // every row are packed on the device and come back in one copy through the pinned ring, like the finished rows
+    MDX_TRY(h->d_finish.ensure(size_t(8) * GB * Tb));
+    MDX_HIP(hipMemcpy2DAsync(h->d_finish.ptr, size_t(Tb) * 8, h->d_inv_out.ptr, size_t(h->n_fft) * 8, size_t(Tb) * 8,
+                             (size_t)GB, hipMemcpyDeviceToDevice, h->stream));
+    MDX_TRY(device_stager(h->dev).download(h->dev, h->stream, acf_sum, h->d_finish.ptr, size_t(8) * GB * Tb));
     h->timer.collect();
-    // MSD_m = S_m - 2 A_m   (correlation.py:621-648, summed over the particles)
-    if (acf_sum)   // sum over particles and dimensions of sum_k x(k) x(k+m), not normalised
-        for (int64_t i = 0; i < GB * Tb; ++i)
-            acf_sum[i] = acf[size_t(i)] * inv_n;
-    for (int64_t gb = 0; msd_self_sum && gb < GB; ++gb) {
-        const double *d = D.data() + gb * Tb;
-        const double *a = acf.data() + gb * Tb;
-        double *o = msd_self_sum + gb * Tb;
-        double total = 0.0;
-        for (int64_t t = 0; t < Tb; ++t)
-            total += d[t];
-        double run = 0.0;
-        for (int64_t m = 0; m < Tb; ++m) {
-            if (m > 0)
-                run += d[m - 1] + d[Tb - m];
-            const double w = double(Tb - m);
-            o[m] = (2.0 * total - run) / w - 2.0 * (a[m] * inv_n) / w;
-        }
-    }
+    for (int64_t i = 0; i < GB * Tb; ++i)
+        acf_sum[i] *= inv_n;
     return MDX_OK;
 }
 
