@@ -3,6 +3,7 @@
 #include "mdx_common.hpp"
 
 #include <execinfo.h>
+#include <fcntl.h>
 #include <signal.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -81,7 +82,8 @@ __attribute__((constructor)) void mdx_process_init()
     const char *t = getenv("MDX_ABORT_TRACE");
     if (t && *t && *t != '0') {
         const int fd = atoi(t);
-        g_abort_fd = fd > 2 ? fd : 2;
+        // (a child process inherits the variable but not the descriptor: what is not open here is stderr)
+        g_abort_fd = fd > 2 && fcntl(fd, F_GETFD) != -1 ? fd : 2;
         struct sigaction sa;
         memset(&sa, 0, sizeof sa);
         sa.sa_handler = abort_trace;
