@@ -44,7 +44,13 @@ extern "C" {
 #define MDX_ERR_STATE (-8)         /* -> RuntimeError        */
 #define MDX_ERR_IO (-9)            /* -> OSError             */
 
-/* ------------------------------------------------------------------ runtime */
+/* ------------------------------------------------------------------ runtime
+ * Loading the library sets GPU_PINNED_MIN_XFER_SIZE=1048576 (MiB) in the process unless the variable is set already:
+ * the HIP runtime then stages pageable copies through its own buffers instead of page-locking caller memory and
+ * KEEPING the registration (a kept registration of memory that is freed and handed out again, or of a file mapping
+ * that is truncated, aborts or blocks the process: NOTES.md round 5).  Copies of >= 1 MiB through mdx_memcpy_* /
+ * mdx_upload* use the library's pinned ring or pages it locks and unlocks itself.  MDX_ABORT_TRACE=<fd>: native
+ * call stack on SIGABRT. */
 
 const char *mdx_last_error(void);
 int mdx_version(void);
@@ -58,12 +64,15 @@ int mdx_memcpy_h2d(int dev, void *dst, const void *src, size_t bytes);
 int mdx_memcpy_d2h(int dev, void *dst, const void *src, size_t bytes);
 int mdx_memset(int dev, void *dst, int value, size_t bytes);
 /* Host memory -> HBM at the rate of the host-buffer entry points: page-locked / registered memory by one DMA
- * where it lies, pageable memory through the library's pinned ring with its copy threads (mdx_memcpy_h2d is
- * the runtime's own single-threaded staging).  Returns when the data is in HBM. */
+ * where it lies, pageable memory through the library's pinned ring with its copy threads (so does mdx_memcpy_h2d
+ * from 1 MiB on; below that it is the runtime's staging).  Returns when the data is in HBM. */
 int mdx_upload(int dev, void *d_dst, const void *src, size_t bytes);
 /* ... for n_rows rows of row_bytes that lie src_stride bytes apart on the host and end up contiguous in HBM: a
  * range of particles out of every frame of float32[T][N][3] (row_bytes = 12 n_range, src_stride = 12 N) — what
- * Onsager streams per group while the group before is being transformed (transport.py:976-992). */
+ * Onsager streams per group while the group before is being transformed (transport.py:976-992).  Pageable rows of
+ * >= 4 KB that lie >= 2 pages apart in anonymous memory are read by the DMA engine where they lie: slices of ~128 MB
+ * are page-locked, copied by one 2-D DMA and unlocked again, several side by side; nothing stays registered when the
+ * call returns.  Short or nearly contiguous rows and rows of a file mapping are gathered into the pinned ring. */
 int mdx_upload_rows(int dev, void *d_dst, const void *src, size_t row_bytes, size_t src_stride, size_t n_rows);
 /* Destroyed handles and mdx_free leave their device blocks (of any size) in a per-device, per-process cache so
  * that an analysis object per call does not pay hipMalloc / hipFree each time (at C4 size: seconds inside

@@ -53,7 +53,8 @@ class DeviceArray:
 
     def upload_columns(self, host, first: int, count: int):
         """Fill this array ``[T, count, ...]`` with columns ``[first, first + count)`` of the host array
-        ``[T, N, ...]`` (``mdx_upload_rows``: pinned ring and copy threads, or one 2-D DMA out of page-locked memory)."""
+        ``[T, N, ...]`` (``mdx_upload_rows``: rows of >= 4 KB in pageable anonymous memory are page-locked, read by 2-D DMA
+        and unlocked slice by slice; page-locked memory: one 2-D DMA; short rows, file mappings: copy threads + pinned ring)."""
         host = np.asarray(host)
         if host.dtype != self.dtype or not host.flags.c_contiguous or host.shape[0] != self.shape[0] \
                 or host.shape[2:] != self.shape[2:] or self.shape[1] != count \

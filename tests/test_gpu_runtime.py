@@ -40,10 +40,10 @@ def test_upload_and_strided_rows_round_trip(pinned):
 
 
 def test_strided_rows_out_of_a_file_mapping_take_the_ring(tmp_path):
-    """Rows of a numpy.memmap (file-backed pages): never handed to the runtime's pageable 2-D copy — the runtime keeps
-    copied ranges registered with the driver, and a file that is truncated afterwards then hangs every later GPU
-    operation of the process (scripts/diag/mmap_truncate_probe.py).  They go through the copy threads and the pinned
-    ring; the file may lose its tail afterwards and the device stays usable."""
+    """Rows of a numpy.memmap (file-backed pages) are never page-locked for the DMA engine: a registration on pages
+    another program can truncate blocks every later GPU operation of the process for as long as it exists
+    (scripts/diag/mmap_truncate_probe.py).  They go through the copy threads and the pinned ring; the file may lose its
+    tail afterwards and the device stays usable."""
     import os
     T, N = 300, 4099
     rng = np.random.default_rng(5)
@@ -52,7 +52,7 @@ def test_strided_rows_out_of_a_file_mapping_take_the_ring(tmp_path):
     ref.tofile(path)
     h = np.memmap(path, dtype=np.float32, mode="r", shape=(T, N, 3))
     buf = _core.DeviceArray((T, 1000, 3), np.float32)
-    buf.upload_columns(h, 17, 1000)                    # 12 KB rows: the runtime's route if the memory were anonymous
+    buf.upload_columns(h, 17, 1000)                    # 12 KB rows: locked slices if the memory were anonymous
     assert np.array_equal(buf.to_host(), ref[:, 17:1017])
     del h
     os.truncate(path, os.path.getsize(path) // 2)
