@@ -2,7 +2,9 @@
 reader, rates (first read of the fresh file, repeats) against the pread ring, and the truncation probe of
 scripts/diag/mmap_truncate_probe.py on it — nothing may stay registered after a call, so a file that loses its tail
 AFTERWARDS must leave the device usable.  Every step prints before it starts; run under `timeout`.
-    python scripts/diag/mapped_route_probe.py [T] [N]"""
+    python scripts/diag/mapped_route_probe.py [T] [N]
+(The record of what was run: `TrajectoryFile(path, mapped=True)` belongs to the patch that was measured with this script
+and not committed — NOTES.md round 5; the script does not run against the library as it is.)"""
 import faulthandler
 import json
 import os
