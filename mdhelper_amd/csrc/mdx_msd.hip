@@ -204,39 +204,67 @@ __global__ __launch_bounds__(256) void msd_gather_kernel(const double *__restric
     }
 }
 
-// per frame row: traj[row][k] += sum_a x_{a,k};  D[row] += sum_{a,k} x^2   (192 threads, k = tid % 3)
+// per frame row: traj[row][k] += sum_a x_{a,k};  D[row] += sum_{a,k} x^2.  192 threads; a thread reads PAIRS of
+// coordinates (16 bytes per lane: 8-byte loads run at 0.54 - 0.70 of that rate), 384 coordinates per round of the
+// block, so the dimensions of a thread's two coordinates never change (384 = 0 mod 3); a row that starts 8 bytes off
+// a 16-byte boundary gives its first coordinate to thread 0 alone, and the last odd coordinate goes the same way.
 __global__ __launch_bounds__(192) void msd_sums_kernel(const double *__restrict__ pos,
                                                        int64_t n_total, int64_t first, int64_t count,
                                                        int zero_dims, double *__restrict__ traj,
                                                        double *__restrict__ D)
 {
-    __shared__ double s_sum[192], s_sq[192];
+    __shared__ double s_sum[3][192], s_sq[192];
     const int64_t row = blockIdx.x;
     const int tid = threadIdx.x;
     const double *p = pos + (row * n_total + first) * 3;
     const int64_t n_elem = count * 3;
-    const bool dead = (zero_dims >> (tid % 3)) & 1;
-    double a = 0.0, q = 0.0;
-    for (int64_t e = tid; e < n_elem; e += 192) {
-        double v = dead ? 0.0 : p[e];
-        a += v;
-        q = fma(v, v, q);
+    const int head = int((reinterpret_cast<uintptr_t>(p) >> 3) & 1);      // coordinates before the first aligned pair
+    double a[3] = {0.0, 0.0, 0.0}, q = 0.0;
+    const int e0 = head + 2 * tid;                                        // this thread's first coordinate of a round
+    const int d0 = e0 % 3, d1 = (e0 + 1) % 3;
+    const bool dead0 = (zero_dims >> d0) & 1, dead1 = (zero_dims >> d1) & 1;
+    double a0 = 0.0, a1 = 0.0;
+    for (int64_t e = e0; e + 1 < n_elem; e += 384) {
+        const double2 v = *reinterpret_cast<const double2 *>(p + e);
+        const double x = dead0 ? 0.0 : v.x, y = dead1 ? 0.0 : v.y;
+        a0 += x;
+        a1 += y;
+        q = fma(x, x, fma(y, y, q));
     }
-    s_sum[tid] = a;
+    a[d0] += a0;
+    a[d1] += a1;
+    if (tid == 0) {
+        // the coordinates no pair covers: the one before the first aligned pair, the one behind the last whole pair
+        if (head && n_elem > 0 && !((zero_dims >> 0) & 1)) {
+            a[0] += p[0];
+            q = fma(p[0], p[0], q);
+        }
+        const int64_t covered = head + ((n_elem - head) / 2) * 2;
+        if (covered < n_elem && covered >= head) {
+            const int dk = int(covered % 3);
+            if (!((zero_dims >> dk) & 1)) {
+                a[dk] += p[covered];
+                q = fma(p[covered], p[covered], q);
+            }
+        }
+    }
+    s_sum[0][tid] = a[0];
+    s_sum[1][tid] = a[1];
+    s_sum[2][tid] = a[2];
     s_sq[tid] = q;
     __syncthreads();
     if (tid < 3) {
-        double sa = 0.0, sq = 0.0;
-        for (int i = tid; i < 192; i += 3) {
-            sa += s_sum[i];
-            sq += s_sq[i];
-        }
+        double sa = 0.0;
+        for (int i = 0; i < 192; ++i)
+            sa += s_sum[tid][i];
         traj[row * 3 + tid] += sa;
-        s_sq[tid] = sq;
     }
-    __syncthreads();
-    if (tid == 0)
-        D[row] += (s_sq[0] + s_sq[1]) + s_sq[2];
+    if (tid == 64) {
+        double sq = 0.0;
+        for (int i = 0; i < 192; ++i)
+            sq += s_sq[i];
+        D[row] += sq;
+    }
 }
 
 // P[b][f] += sum over the chunk's series of |F[b][series][f]|^2
