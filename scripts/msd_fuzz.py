@@ -28,7 +28,12 @@ while time.time() < t_end:
         n_atoms = int(rng.integers(1, 400))
         if n_blocks * t_block * n_atoms > 6_000_000:
             n_atoms = max(1, 6_000_000 // (n_blocks * t_block))
-    if rng.random() < 0.3:
+    if rng.random() < 0.08:
+        # the long shapes (round 5: 1024-point rows through msd_fft_rows1024_power_kernel; the sums kernel of 2^18 .. 2^20):
+        # 409 600 = 400 x 1024 (131 073 .. 204 800 frames), 2^18, 2^19, 2^20 — one block, a few particles
+        t_block = int(rng.choice([102401, 131072, 131073, 150000, 204800, 204801, 262144, 262145, 300000]))
+        n_blocks, n_atoms = 1, int(rng.integers(1, 7))
+    elif rng.random() < 0.3:
         # rows of whole 128-byte lines (16 | 3 n_atoms): pushes that start inside a line enter their chunk early
         # (the `head` of msd_fft_cols400_fused_kernel, blocks of 32 769 ... 102 400 frames)
         n_atoms = int(rng.choice([16, 32]))
