@@ -71,8 +71,8 @@ int mdx_upload(int dev, void *d_dst, const void *src, size_t bytes);
  * range of particles out of every frame of float32[T][N][3] (row_bytes = 12 n_range, src_stride = 12 N) — what
  * Onsager streams per group while the group before is being transformed (transport.py:976-992).  Pageable rows of
  * >= 4 KB that lie >= 2 pages apart in anonymous memory are read by the DMA engine where they lie: slices of ~128 MB
- * are page-locked, copied by one 2-D DMA and unlocked again, several side by side; nothing stays registered when the
- * call returns.  Short or nearly contiguous rows and rows of a file mapping are gathered into the pinned ring. */
+ * are page-locked, copied by one 2-D DMA and unlocked again, several side by side; every slice is unlocked before
+ * the call returns.  Short or nearly contiguous rows and rows of a file mapping are gathered into the pinned ring. */
 int mdx_upload_rows(int dev, void *d_dst, const void *src, size_t row_bytes, size_t src_stride, size_t n_rows);
 /* Destroyed handles and mdx_free leave their device blocks (of any size) in a per-device, per-process cache so
  * that an analysis object per call does not pay hipMalloc / hipFree each time (at C4 size: seconds inside

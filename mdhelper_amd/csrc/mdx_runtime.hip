@@ -761,8 +761,11 @@ int HostStager::upload_rows(int device, hipStream_t consumer, void *d_dst, const
 // the DMA engine where they lie: the rows are cut into slices of ~128 MB, and every slice is page-locked
 // (hipHostRegister on the whole pages its rows span), copied by ONE 2-D DMA on a stream of its own and unlocked
 // again (hipHostUnregister) by one of the copy threads, several slices side by side.  Locking is cheap (0.25 ms per
-// 128 MB) and nothing stays registered when the call returns — unlike the runtime's own pageable path, whose kept
-// registrations are what mdx_process_init switches off.  Measured on the 12 GB of C4 in quarter-column chunks:
+// 128 MB) and every slice is unregistered before the call returns — unlike the runtime's own pageable path, whose kept
+// registrations are what mdx_process_init switches off.  (Anonymous memory only: whatever the driver may still hold
+// for pages the DMA engine has read is harmless there — pages that go away under a mapping that stays come back as
+// fresh pages — and is not for a file mapping, whose pages beyond a later truncation never come back: NOTES.md
+// round 5, the second mapped-file probe.)  Measured on the 12 GB of C4 in quarter-column chunks:
 // 53 - 54 GB/s with 2 .. 8 threads (the runtime's implicit route 57.5, the ring's gather 34 - 40;
 // profiles/r05_register_slices.json).
 // Callers guarantee (upload_rows checks): rows of >= 4 KB that lie >= 2 pages apart, so the page spans of two slices
