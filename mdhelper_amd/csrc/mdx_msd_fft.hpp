@@ -50,6 +50,17 @@ __device__ inline double2 cadd(double2 a, double2 b) { return make_double2(a.x +
 __device__ inline double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
 __device__ inline double2 mul_mi(double2 a) { return make_double2(a.y, -a.x); }   // * (-i)
 
+// w[r] = w1^r, r = 1 .. R - 1, by squarings and single steps (depth log2 R + 1, not R - 2): the twiddles of one butterfly
+// from ONE table entry.  The LDS pipe of a CU — one for sixteen waves — is what the transform kernels queue for, the four
+// VALUs are a third idle: R - 2 complex products (relative error <= R ulp) instead of R - 2 more 16-byte LDS reads.
+template <int R> __device__ __forceinline__ void tw_powers(double2 w1, double2 *w)
+{
+    w[1] = w1;
+#pragma unroll
+    for (int r = 2; r < R; ++r)
+        w[r] = (r & 1) ? cmul(w[r - 1], w1) : cmul(w[r / 2], w[r / 2]);
+}
+
 // forward 8-point transform, natural order in and out
 __device__ __forceinline__ void dft8(double2 *a)
 {
@@ -141,8 +152,13 @@ __device__ __forceinline__ void stockham_stage(double2 *z, const double2 *tw, in
         for (int r = 0; r < RADIX; ++r) {
             const int idx = j + r * T;
             v[p][r] = (!FIRST || idx < n_live) ? z[idx] : make_double2(0.0, 0.0);
-            if (NS > 1 && r)   // W_(RADIX NS)^(r k)
-                v[p][r] = cmul(v[p][r], tw_at<M>(tw, (r * k * (M / (RADIX * NS))) & (M - 1)));
+        }
+        if (NS > 1) {   // W_(RADIX NS)^(r k), r = 1 .. RADIX - 1, as powers of one table entry
+            double2 w[RADIX];
+            tw_powers<RADIX>(tw_at<M>(tw, (k * (M / (RADIX * NS))) & (M - 1)), w);
+#pragma unroll
+            for (int r = 1; r < RADIX; ++r)
+                v[p][r] = cmul(v[p][r], w[r]);
         }
         dft<RADIX>(v[p]);
     }
@@ -253,6 +269,9 @@ __device__ __forceinline__ void dft4(double2 *a)
 // for radix 5 where the Stockham stage above holds 40), and no fence is needed between rounds.
 // After the last stage slot p holds X[digit-reversed p] (dif_slot below).  tw[m] = exp(-2 pi i m / M).
 // FIRST: slots >= M / 2 are structurally zero (the zero padding) and are not read.
+#ifndef DIF_GENERATED_TWIDDLES
+#define DIF_GENERATED_TWIDDLES 1
+#endif
 template <int M, int MS, int RADIX, bool FIRST>
 __device__ __forceinline__ void dif_stage(double2 *z, const double2 *tw, int lane)
 {
@@ -277,11 +296,29 @@ __device__ __forceinline__ void dif_stage(double2 *z, const double2 *tw, int lan
                 dft10<FIRST>(v);
             else
                 dft8(v);
+            if (SUB > 1 && DIF_GENERATED_TWIDDLES) {
+                // W_MS^(t k), k = 1 .. RADIX - 1, as powers of the ONE table entry W_MS^t (tw_powers: pass A issued 102 LDS
+                // instructions per wave and iteration, 18 of them these twiddle reads)
+                // (one running power, not tw_powers' tree: ten of them live at once cost the 400-point pass A its last
+                // registers — 128 and three spills against 108 — and a scratch reload drains the queue of row loads)
+                const double2 w1 = tw[t * (M / MS)];
+                double2 w = w1;
 #pragma unroll
-            for (int k = 0; k < RADIX; ++k) {
-                if (k && SUB > 1)
-                    v[k] = cmul(v[k], tw[t * k * (M / MS)]);
-                zz[k * SUB] = v[k];
+                for (int k = 0; k < RADIX; ++k) {
+                    if (k) {
+                        v[k] = cmul(v[k], w);
+                        if (k + 1 < RADIX)
+                            w = cmul(w, w1);
+                    }
+                    zz[k * SUB] = v[k];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < RADIX; ++k) {
+                    if (k && SUB > 1)
+                        v[k] = cmul(v[k], tw[t * k * (M / MS)]);
+                    zz[k * SUB] = v[k];
+                }
             }
         }
     }
@@ -590,15 +627,23 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols400_fused_kernel(
         dif_stage<R1, 4, 4, false>(zb[wave], s_h, lane);
         __syncthreads();
         double2 *o = out + int64_t(pg0 + q) * pg_stride + int64_t(n2) * PG;
+        {
+            // W_N^(n2 k1), k1 = kbase + 64 i: W_N^(n2 kbase) times powers of W_N^(64 n2) — two table products and six
+            // complex products instead of seven table products (fourteen 16-byte LDS reads);
+            // W_N^m = W_R1^(m / R2) * W_N^(m mod R2), m < N
+            const unsigned mb = unsigned(kbase) * unsigned(n2), ms = 64u * unsigned(n2);
+            double2 w = cmul(s_h[mb / R2], s_n[mb & (R2 - 1)]);
+            const double2 ws = cmul(s_h[ms / R2], s_n[ms & (R2 - 1)]);
 #pragma unroll
-        for (int i = 0; i < OUTS; ++i) {
-            // the last round holds lines for kbase < 16 only: the other threads repeat round 5
-            const int ii = (i < OUTS - 1 || kbase + 64 * i < R1) ? i : OUTS - 2;
-            const int k1 = kbase + 64 * ii;
-            // W_N^(n2 k1) = W_R1^(m / R2) * W_N^(m mod R2), m = n2 k1 < N
-            const unsigned m = unsigned(k1) * unsigned(n2);
-            const double2 w = cmul(s_h[m / R2], s_n[m & (R2 - 1)]);
-            o[int64_t(64 * ii) * k1_stride] = cmul(zb[p][dif_slot_400(k1)], w);
+            for (int i = 0; i < OUTS; ++i) {
+                // the last round holds lines for kbase < 16 only: the other threads repeat round 5 (with its twiddle)
+                const bool own = i < OUTS - 1 || kbase + 64 * i < R1;
+                const int ii = own ? i : OUTS - 2;
+                const int k1 = kbase + 64 * ii;
+                if (i && own)
+                    w = cmul(w, ws);
+                o[int64_t(64 * ii) * k1_stride] = cmul(zb[p][dif_slot_400(k1)], w);
+            }
         }
         __syncthreads();
         q = q_n;
@@ -937,10 +982,14 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_rows512_power_kernel(
         {   // stage 3 (NS = 64): butterfly l reads points l + 64 r, output r is X[l + 64 r]
             double2 u[8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
+            for (int r = 0; r < 8; ++r)
                 u[r] = zb[wave][lane + 64 * r];
-                if (r)
-                    u[r] = cmul(u[r], tw_at<R2>(s_tw, r * lane));
+            {   // W_512^(r lane) as powers of W_512^lane
+                double2 w[8];
+                tw_powers<8>(tw_at<R2>(s_tw, lane), w);
+#pragma unroll
+                for (int r = 1; r < 8; ++r)
+                    u[r] = cmul(u[r], w[r]);
             }
             dft8(u);
 #pragma unroll
@@ -1028,10 +1077,14 @@ __global__ __launch_bounds__(THREADS, 2) void msd_fft_rows1024_power_kernel(
             const int l = lane + 64 * q;
             double2 u[8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
+            for (int r = 0; r < 8; ++r)
                 u[r] = zb[wave][l + 128 * r];
-                if (r)
-                    u[r] = cmul(u[r], tw_at<R2>(s_tw, r * l));
+            {   // W_1024^(r l) as powers of W_1024^l
+                double2 w[8];
+                tw_powers<8>(tw_at<R2>(s_tw, l), w);
+#pragma unroll
+                for (int r = 1; r < 8; ++r)
+                    u[r] = cmul(u[r], w[r]);
             }
             dft8(u);
 #pragma unroll
