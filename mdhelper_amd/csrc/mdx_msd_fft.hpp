@@ -192,8 +192,13 @@ __device__ __forceinline__ void stockham_stage_batch(double2 *z, int zs, const d
     for (int r = 0; r < RADIX; ++r) {
         const int idx = j + r * T;
         v[r] = (!FIRST || idx < n_live) ? zc[idx] : make_double2(0.0, 0.0);
-        if (NS > 1 && r)
-            v[r] = cmul(v[r], tw_at<M>(tw, (r * k * (M / (RADIX * NS))) & (M - 1)));
+    }
+    if (NS > 1) {
+        double2 w[RADIX];
+        tw_powers<RADIX>(tw_at<M>(tw, (k * (M / (RADIX * NS))) & (M - 1)), w);
+#pragma unroll
+        for (int r = 1; r < RADIX; ++r)
+            v[r] = cmul(v[r], w[r]);
     }
     dft<RADIX>(v);
     wave_lds_fence();
@@ -332,6 +337,28 @@ __device__ __forceinline__ int dif_slot_400(int k)
     const int q1 = k / 10, ka = k - 10 * q1;
     const int kc = q1 / 10, kb = q1 - 10 * kc;
     return 40 * ka + 4 * kb + kc;
+}
+
+// The last stage (radix 4, sub-transforms of 4 consecutive slots) of a 400-point dif transform WITHOUT the write-back:
+// butterfly b = lane + 64 p (< 100) reads slots 4 b .. 4 b + 3 and adds |X|^2 of its four outputs to Pq[4 p + k] — the
+// slot 4 b + k holds X[digit-reversed] as after dif_stage<400, 4, 4>.  For kernels that only want the power spectrum
+// (the single-pass kernel): eight LDS writes, seven reads and a fence fewer per transform.
+__device__ __forceinline__ void dif_last4_power_400(const double2 *z, int lane, double *Pq)
+{
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int b = lane + 64 * p;
+        if (p == 0 || b < 100) {
+            double2 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                v[k] = z[4 * b + k];
+            dft4(v);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                Pq[4 * p + k] = fma(v[k].x, v[k].x, fma(v[k].y, v[k].y, Pq[4 * p + k]));
+        }
+    }
 }
 
 // In-place forward M-point transform of z[0..M) (LDS) by one wave.  tw: exp(-2 pi i m / M),
@@ -1468,11 +1495,11 @@ __global__ __launch_bounds__(THREADS, R2 == 4 ? 1 : 2) void msd_fft_single400_ke
     // rounds 5 registers — and a scratch reload waits for every load issued before it), its rows are loaded at the
     // top of their own iteration
     constexpr int EARLY = R2 == 4 ? 0 : LOADS;
-    double P[R2][SL];
+    double P[R2][8];        // |X|^2 sums: P[r][4 p + k] <-> slot 4 (lane + 64 p) + k of sub-transform r (dif_last4_power_400)
 #pragma unroll
     for (int r = 0; r < R2; ++r)
 #pragma unroll
-        for (int i = 0; i < SL; ++i)
+        for (int i = 0; i < 8; ++i)
             P[r][i] = 0.0;
     double sd[PASSES], sx[PASSES], sy[PASSES], sz[PASSES];
 #pragma unroll
@@ -1535,13 +1562,7 @@ __global__ __launch_bounds__(THREADS, R2 == 4 ? 1 : 2) void msd_fft_single400_ke
         if (R2 == 1) {
             dif_stage<R1, 400, 10, true>(z, s_h, lane);
             dif_stage<R1, 40, 10, false>(z, s_h, lane);
-            dif_stage<R1, 4, 4, false>(z, s_h, lane);
-#pragma unroll
-            for (int i = 0; i < SL; ++i)
-                if (i < SL - 1 || lane + 64 * i < R1) {
-                    const double2 v = z[lane + 64 * i];
-                    P[0][i] = fma(v.x, v.x, fma(v.y, v.y, P[0][i]));
-                }
+            dif_last4_power_400(z, lane, P[0]);
         } else if (R2 == 2) {
             double2 xr[SL];
 #pragma unroll
@@ -1550,24 +1571,22 @@ __global__ __launch_bounds__(THREADS, R2 == 4 ? 1 : 2) void msd_fft_single400_ke
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 if (r == 1) {
+                    // x W_800^n, n = lane + 64 i: W_800^lane (one table entry) times powers of W_800^64 = W_400^32
+                    const double2 wl = s_h[lane >> 1];
+                    double2 w = (lane & 1) ? cmul(wl, wn1) : wl;
+                    const double2 ws = s_h[32];
 #pragma unroll
-                    for (int i = 0; i < SL; ++i)
-                        if (i < SL - 1 || lane + 64 * i < R1) {
-                            const int n = lane + 64 * i;
-                            const double2 w0 = s_h[n >> 1];
-                            z[n] = cmul(xr[i], (n & 1) ? cmul(w0, wn1) : w0);
-                        }
+                    for (int i = 0; i < SL; ++i) {
+                        if (i < SL - 1 || lane + 64 * i < R1)
+                            z[lane + 64 * i] = cmul(xr[i], w);
+                        if (i + 1 < SL)
+                            w = cmul(w, ws);
+                    }
                     wave_lds_fence();
                 }
                 dif_stage<R1, 400, 10, false>(z, s_h, lane);
                 dif_stage<R1, 40, 10, false>(z, s_h, lane);
-                dif_stage<R1, 4, 4, false>(z, s_h, lane);
-#pragma unroll
-                for (int i = 0; i < SL; ++i)
-                    if (i < SL - 1 || lane + 64 * i < R1) {
-                        const double2 v = z[lane + 64 * i];
-                        P[r][i] = fma(v.x, v.x, fma(v.y, v.y, P[r][i]));
-                    }
+                dif_last4_power_400(z, lane, P[r]);
             }
         } else {
             double2 *w = zw[R2 == 4 ? wave : 0];
@@ -1601,14 +1620,9 @@ __global__ __launch_bounds__(THREADS, R2 == 4 ? 1 : 2) void msd_fft_single400_ke
                 __builtin_amdgcn_sched_barrier(0);
                 dif_stage<R1, 400, 10, false>(w, s_h, lane);
                 dif_stage<R1, 40, 10, false>(w, s_h, lane);
-                dif_stage<R1, 4, 4, false>(w, s_h, lane);
+                dif_last4_power_400(w, lane, P[r]);
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < SL; ++i)
-                    if (i < SL - 1 || lane + 64 * i < R1) {
-                        const double2 v = w[lane + 64 * i];
-                        P[r][i] = fma(v.x, v.x, fma(v.y, v.y, P[r][i]));
-                    }
+                wave_lds_fence();          // the next sub-transform's work buffer is this one
             }
         }
         __syncthreads();   // the next staging overwrites the rows
@@ -1630,9 +1644,13 @@ __global__ __launch_bounds__(THREADS, R2 == 4 ? 1 : 2) void msd_fft_single400_ke
 #pragma unroll
     for (int r = 0; r < R2; ++r)
 #pragma unroll
-        for (int i = 0; i < SL; ++i)
-            if (i < SL - 1 || lane + 64 * i < R1)
-                red[(wave * R2 + r) * R1 + lane + 64 * i] = P[r][i];
+        for (int pq = 0; pq < 2; ++pq) {
+            if (pq == 0 || lane + 64 * pq < 100) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    red[(wave * R2 + r) * R1 + 4 * (lane + 64 * pq) + k] = P[r][4 * pq + k];
+            }
+        }
     __syncthreads();
     double *pf = Pfull + (int64_t(blockIdx.x) * gridDim.y + b) * (int64_t(R1) * R2);
     for (int idx = tid; idx < R2 * R1; idx += THREADS) {
