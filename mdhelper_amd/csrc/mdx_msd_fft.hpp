@@ -437,13 +437,29 @@ __global__ __launch_bounds__(THREADS, R1 == 512 ? 4 : 2) void msd_fft_cols_kerne
         fft_wave<R1>(zb[wave], s_h, lane, R1 / 2);
         __syncthreads();
         double2 *o = out + int64_t(kbase) * k1_stride + int64_t(n2) * PG;
+        if constexpr (R1 >= 1024) {
+            // W_N^(n2 k1), k1 = kbase + 64 i: W_N^(n2 kbase) times powers of W_N^(64 n2) — two table products and
+            // OUTS - 1 complex products instead of OUTS table products; W_N^m = W_R1^(m / R2) * W_N^(m mod R2), m < N
+            // (the 1024-point columns run one block per CU and queue for its LDS pipe: 2^19 30.6 -> 29.4 ms, 2^20
+            // 31.2 -> 30.1; the 512-point columns, two blocks per CU, gained nothing from the chain of products)
+            const unsigned mb = unsigned(kbase) * unsigned(n2), ms = 64u * unsigned(n2);
+            double2 w = cmul(tw_at<R1>(s_h, int(mb / R2)), s_n[mb & (R2 - 1)]);
+            const double2 ws = cmul(tw_at<R1>(s_h, int(ms / R2)), s_n[ms & (R2 - 1)]);
 #pragma unroll
-        for (int i = 0; i < OUTS; ++i) {
-            const int k1 = kbase + 64 * i;
-            // W_N^(n2 k1) = W_R1^(m / R2) * W_N^(m mod R2), m = n2 k1 < N
-            const unsigned m = unsigned(k1) * unsigned(n2);
-            const double2 w = cmul(tw_at<R1>(s_h, int(m / R2)), s_n[m & (R2 - 1)]);
-            o[int64_t(64 * i) * k1_stride] = cmul(zb[p][k1], w);
+            for (int i = 0; i < OUTS; ++i) {
+                o[int64_t(64 * i) * k1_stride] = cmul(zb[p][kbase + 64 * i], w);
+                if (i + 1 < OUTS)
+                    w = cmul(w, ws);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < OUTS; ++i) {
+                const int k1 = kbase + 64 * i;
+                // W_N^(n2 k1) = W_R1^(m / R2) * W_N^(m mod R2), m = n2 k1 < N
+                const unsigned m = unsigned(k1) * unsigned(n2);
+                const double2 w = cmul(tw_at<R1>(s_h, int(m / R2)), s_n[m & (R2 - 1)]);
+                o[int64_t(64 * i) * k1_stride] = cmul(zb[p][k1], w);
+            }
         }
         __syncthreads();
     }
