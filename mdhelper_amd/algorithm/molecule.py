@@ -33,6 +33,10 @@ def center_of_mass(group=None, grouping: str = None, *, masses=None, positions=N
     ``n_groups`` equal molecules).  ``images`` (boundary-crossing counts) unwrap
     the positions with ``dimensions`` first.
     """
+    # (reference molecule.py:218-221: the grouping is checked before anything else)
+    if grouping not in {None, "residues", "segments"}:
+        raise ValueError(f"Invalid grouping: '{grouping}'. Valid options are None, 'residues', "
+                         "and 'segments'.")
     if group is not None:
         pos = np.array(group.positions if positions is None else positions, dtype=float)
         m = np.asarray(group.masses if masses is None else masses, dtype=float)
@@ -47,7 +51,7 @@ def center_of_mass(group=None, grouping: str = None, *, masses=None, positions=N
                                      "trajectory.")
                 dimensions = dims
             pos = pos + np.asarray(images) * np.asarray(dimensions, dtype=float)[:3]
-        if grouping in (None, "atoms") and not n_groups:
+        if grouping is None and not n_groups:
             com = (m[:, None] * pos).sum(axis=0) / m.sum()
             return (com, m, pos) if raw else com
         if n_groups:

@@ -236,6 +236,8 @@ def test_frame_prep_helpers():
     assert np.allclose(com, want)
     assert np.allclose(molecule.center_of_mass(positions=u.atoms.positions, masses=u.atoms.masses),
                        molecule.center_of_mass(u.atoms))
+    # (the three cases of the reference's tests/test_algorithm_utility.py:13-25)
+    assert np.allclose(utility.get_closest_factors(1000, 3), 10 * np.ones(3, dtype=int))
     assert utility.get_closest_factors(35904, 3).tolist() == [32, 33, 34]
     assert utility.get_closest_factors(73440, 4, reverse=True).tolist() == [18, 17, 16, 15]
 
@@ -330,3 +332,41 @@ def test_equal_wavenumber_means_follow_the_reference_loop():
     u = np.unique(w.round(11))
     x = np.arange(8.0).reshape(2, 4)
     assert np.array_equal(fast(x, w, u), loop(x, w, u))
+
+
+def test_center_of_mass_follows_the_reference_tests():
+    """The reference's own test_algorithm_molecule.py (its AdK universe comes from MDAnalysisTests, so the cases are
+    restated on a synthetic universe): the four error cases of `test_center_of_mass_errors` (:19-40) and the
+    definitional cases 2-6, 8-11 of `test_center_of_mass_mda` (:42-122) against sum(m x) / sum(m)."""
+    import mdhelper_amd as mdx
+    rng = np.random.default_rng(8)
+    N, R = 40, 10
+    pos = rng.uniform(0, 20, (2, N, 3)).astype(np.float32)
+    masses = rng.uniform(1, 16, N)
+    u = mdx.ArrayUniverse(pos, [20, 20, 20, 90, 90, 90], masses=masses, resids=np.arange(N) // 4,
+                          segids=np.zeros(N, dtype=int))
+    # errors (:19-40)
+    with pytest.raises(ValueError):
+        molecule.center_of_mass()
+    with pytest.raises(ValueError):
+        molecule.center_of_mass(u.atoms, "atoms")
+    no_box = mdx.ArrayUniverse(pos, None, masses=masses)
+    with pytest.raises(ValueError):
+        molecule.center_of_mass(no_box.atoms, images=np.zeros((N, 3)))
+    with pytest.raises(ValueError):
+        molecule.center_of_mass(masses=u.atoms.masses,
+                                positions=[u.atoms.positions[4 * i:4 * i + 4] for i in range(R)])
+    # values (:52-122)
+    x = np.asarray(u.atoms.positions, dtype=float)
+    com = (masses[:, None] * x).sum(0) / masses.sum()
+    assert np.allclose(molecule.center_of_mass(u.atoms), com)
+    c, m, p = molecule.center_of_mass(u.atoms, images=np.zeros((N, 3), dtype=int), dimensions=np.array((0, 0, 0)),
+                                      raw=True)
+    assert np.allclose(c, com) and np.allclose(m, masses) and np.allclose(p, x)
+    res = (masses.reshape(R, 4)[..., None] * x.reshape(R, 4, 3)).sum(1) / masses.reshape(R, 4).sum(1, keepdims=True)
+    assert np.allclose(molecule.center_of_mass(u.atoms, "residues"), res)
+    assert np.allclose(molecule.center_of_mass(masses=[masses[4 * i:4 * i + 4] for i in range(R)],
+                                               positions=[x[4 * i:4 * i + 4] for i in range(R)]), res)
+    assert np.allclose(molecule.center_of_mass(u.atoms, n_groups=R), res)
+    assert np.allclose(molecule.center_of_mass(masses=masses, positions=x, n_groups=R), res)
+    assert np.allclose(molecule.center_of_mass(u.atoms, "segments"), com)
