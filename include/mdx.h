@@ -312,6 +312,14 @@ int mdx_msd_push(mdx_msd_t h, int group, const double *pos, int64_t n_total, int
                  int64_t count, int zero_dims);
 int mdx_msd_push_device(mdx_msd_t h, int group, const double *d_pos, int64_t n_total,
                         int64_t first, int64_t count, int zero_dims);
+/* The same for float32 positions resident in HBM — what a trajectory reader or a GPU MD engine holds —, a plain
+ * particle range with nothing to prepare (no unwrapping, no molecule centres, no shift): pass A widens them as it
+ * stages them, so no float64 copy is made (C4: 18 GB of traffic per group less).  Only the engine's 400 x R2
+ * two-pass transforms read float32 in place (blocks of 801 .. 204 800 frames); other engines return
+ * MDX_ERR_UNSUPPORTED and the caller goes through mdx_msd_push_frames_device.  Results equal those of the widened
+ * frames bit for bit. */
+int mdx_msd_push_device_f32(mdx_msd_t h, int group, const float *d_pos, int64_t n_total, int64_t first,
+                            int64_t count, int zero_dims);
 /* msd_self[g][b][t] = sum_particles MSD_particle / N_g  (transport.py:1036-1039, before /2D)
  * sum_traj[g][b][t][3] = sum_particles r(t)            (input of :1034 and :1044-1052) */
 int mdx_msd_result(mdx_msd_t h, double *msd_self_sum, double *sum_traj);

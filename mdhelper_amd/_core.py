@@ -551,6 +551,18 @@ class MsdEngine(_Engine):
     def push_device(self, group, d_pos, n_total, first, count, zero_dims=0):
         check(lib().mdx_msd_push_device(self.handle, group, d_pos, n_total, first, count, zero_dims))
 
+    @property
+    def reads_f32(self):
+        """Whether pass A of this engine reads float32 positions where they lie (``push_device_f32``): the 400 x R2
+        two-pass transforms (blocks of 801 .. 204 800 frames)."""
+        own, r1, r2 = self.transform
+        return bool(own) and r1 == 400 and r2 >= 8
+
+    def push_device_f32(self, group, d_pos, n_total, first, count, zero_dims=0):
+        """``mdx_msd_push_device_f32``: a plain particle range of float32 frames resident in HBM, widened by pass A as
+        it stages them (``NotImplementedError`` from engines whose transforms do not: see :attr:`reads_f32`)."""
+        check(lib().mdx_msd_push_device_f32(self.handle, group, d_pos, n_total, first, count, zero_dims))
+
     def set_grouping(self, offsets, masses):
         """Rows of the following ``push_traj`` calls are particles of molecules
         ``[offsets[g], offsets[g+1])``; the engine receives their float64 centres of mass.

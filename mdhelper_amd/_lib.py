@@ -105,6 +105,7 @@ _SIGNATURES = {
     "mdx_msd_transform": (c_int, [_vp, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "mdx_msd_push": (c_int, [_vp, c_int, _vp, c_int64, c_int64, c_int64, c_int]),
     "mdx_msd_push_device": (c_int, [_vp, c_int, _vp, c_int64, c_int64, c_int64, c_int]),
+    "mdx_msd_push_device_f32": (c_int, [_vp, c_int, _vp, c_int64, c_int64, c_int64, c_int]),
     "mdx_msd_result": (c_int, [_vp, _vp, _vp]),
     "mdx_msd_allreduce": (c_int, [_vp, _vp]),
     "mdx_msd_stats": (c_int, [_vp, POINTER(c_int64), POINTER(c_double), POINTER(c_int64)]),

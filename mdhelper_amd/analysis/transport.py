@@ -394,13 +394,19 @@ class Onsager(SerialAnalysisBase):
                         return eng.system_com_device(resident, n_total, rows, masses, **kw)
 
                     def push(g, rows, **kw):
-                        if (resident.dtype == np.float64 and not eng.has_grouping and kw.get("shift") is None
-                                and kw.get("unwrap_dims") is None and len(rows)
-                                and np.array_equal(rows, np.arange(rows[0], rows[0] + len(rows)))):
+                        plain = (not eng.has_grouping and kw.get("shift") is None
+                                 and kw.get("unwrap_dims") is None and len(rows)
+                                 and np.array_equal(rows, np.arange(rows[0], rows[0] + len(rows))))
+                        if plain and resident.dtype == np.float64:
                             # float64 frames in HBM, a contiguous range of particles, nothing to prepare:
                             # the correlation kernels read them where they lie
                             eng.push_device(g, resident.ptr, n_total, int(rows[0]), len(rows),
                                             kw.get("zero_dims", 0))
+                        elif plain and resident.dtype == np.float32 and eng.reads_f32:
+                            # ... and so do float32 frames where the first pass widens them as it stages them
+                            # (mdx_msd_push_device_f32: the 400 x R2 transforms; no float64 copy of the group)
+                            eng.push_device_f32(g, resident.ptr, n_total, int(rows[0]), len(rows),
+                                                kw.get("zero_dims", 0))
                         else:
                             eng.push_frames_device(g, resident, n_total, rows, **kw)
                 elif native is not None:

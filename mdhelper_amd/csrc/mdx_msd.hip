@@ -503,9 +503,15 @@ struct mdx_msd {
     int64_t traj_len() const { return int64_t(n_groups) * n_blocks * t_block * 3; }
 };
 
+// d_pos32: the positions as float32 instead (d_pos unused): only where pass A reads them itself
+// (msdfft::cols_read_f32 — the 400-point family with two passes); other shapes answer MDX_ERR_UNSUPPORTED and the
+// caller widens the frames first (mdx_msd_push_frames_device)
 static int msd_push_device(mdx_msd *h, int group, const double *d_pos, int64_t n_total, int64_t first,
-                           int64_t count, int zero_dims)
+                           int64_t count, int zero_dims, const float *d_pos32 = nullptr)
 {
+    if (d_pos32 && !(h->own_fft && !h->single && h->fused_sums && msdfft::cols_read_f32(h->shape)))
+        return fail(MDX_ERR_UNSUPPORTED, "float32 positions are read in place by the 400 x R2 two-pass transforms only "
+                    "(this engine: n_fft = %lld)", (long long)h->n_fft);
     if (count == 0)
         return MDX_OK;
     const int B = h->n_blocks;
@@ -556,7 +562,8 @@ static int msd_push_device(mdx_msd *h, int group, const double *d_pos, int64_t n
             // in the middle of a line is entered `head` coordinates early, so that pass A's 128-byte pieces
             // are whole lines (msd_fft_cols400_fused_kernel); the head is staged as zeros
             const int head = ((h->single || (h->fused_sums && msdfft::aligns_head(h->shape))) && (n_total * 3) % 16 == 0 &&
-                              (reinterpret_cast<uintptr_t>(d_pos) & 127u) == 0)
+                              (reinterpret_cast<uintptr_t>(d_pos32 ? static_cast<const void *>(d_pos32)
+                                                                   : static_cast<const void *>(d_pos)) & 127u) == 0)
                                  ? int(((first + a0) * 3) % 16)
                                  : 0;
             const int64_t ne = c * 3 + head;
@@ -575,10 +582,10 @@ static int msd_push_device(mdx_msd *h, int group, const double *d_pos, int64_t n
             }
             msdfft::launch(h->shape, h->stream, d_pos, n_total, first + a0, ne, h->t_block, B, zero_dims, p_pad,
                            tw_r1, tw_r2, twN, h->d_spec.as<double2>(), h->d_pfull.as<double>(), 0,
-                           h->fused_sums ? h->d_part.as<double2>() : nullptr, h->traj(group), h->dsq(group), head);
+                           h->fused_sums ? h->d_part.as<double2>() : nullptr, h->traj(group), h->dsq(group), head, d_pos32);
             msdfft::launch_fold(h->shape, h->stream, h->d_pfull.as<double>(), B, h->nc, h->power(group));
             // positions read once (twice where the sums are a kernel of their own), Y written and read once
-            h->bytes_moved += c * 3 * B * ((h->fused_sums ? 1 : 2) * h->t_block * 8 + 2 * h->n_fft * 8);
+            h->bytes_moved += c * 3 * B * ((h->fused_sums ? 1 : 2) * h->t_block * (d_pos32 ? 4 : 8) + 2 * h->n_fft * 8);
             continue;
         }
         dim3 g1((unsigned)ceil_div(h->n_fft, GT), (unsigned)ceil_div(n_elem, GT), (unsigned)B);
@@ -1237,6 +1244,17 @@ int mdx_msd_push_device(mdx_msd_t h, int group, const double *d_pos, int64_t n_t
     MDX_REQUIRE(zero_dims >= 0 && zero_dims < 8, "zero_dims is a 3-bit mask");
     MDX_TRY(set_device(h->dev));
     return msd_push_device(h, group, d_pos, n_total, first, count, zero_dims);
+}
+
+int mdx_msd_push_device_f32(mdx_msd_t h, int group, const float *d_pos, int64_t n_total, int64_t first,
+                            int64_t count, int zero_dims)
+{
+    MDX_REQUIRE(h && d_pos, "NULL argument");
+    MDX_REQUIRE(group >= 0 && group < h->n_groups, "group %d out of range", group);
+    MDX_REQUIRE(first >= 0 && count >= 0 && first + count <= n_total, "particle range out of bounds");
+    MDX_REQUIRE(zero_dims >= 0 && zero_dims < 8, "zero_dims is a 3-bit mask");
+    MDX_TRY(set_device(h->dev));
+    return msd_push_device(h, group, nullptr, n_total, first, count, zero_dims, d_pos);
 }
 
 int mdx_msd_push(mdx_msd_t h, int group, const double *pos, int64_t n_total, int64_t first,

@@ -485,9 +485,13 @@ __global__ __launch_bounds__(THREADS, R1 == 512 ? 4 : 2) void msd_fft_cols_kerne
 constexpr int SG = 8;              // pair groups per super group
 constexpr int SUMS_ROWS = 200;     // live rows of the 400-point first factor
 
-template <int R2>
+// In: double — the float64 position store of the reference's Onsager (transport.py:932) — or float (round 5): float32
+// frames resident in HBM, what a trajectory reader or a GPU MD engine delivers, are widened as they are staged, so a
+// plain particle range of them needs no preparation pass (6 GB read + 12 GB written per 5 000-particle group of C4);
+// a pair is then 8 bytes per lane and a row piece 64 bytes, everything behind the staging is the same code.
+template <int R2, typename In = double>
 __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols400_fused_kernel(
-    const double *__restrict__ pos, int64_t n_total, int64_t first, int64_t n_elem, int64_t t_block,
+    const In *__restrict__ pos, int64_t n_total, int64_t first, int64_t n_elem, int64_t t_block,
     int zero_dims, int p_pad, const double2 *__restrict__ tw_r1, const double2 *__restrict__ twN,
     double2 *__restrict__ Y, double2 *__restrict__ part, int head, int pg_major)
 {
@@ -526,7 +530,7 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols400_fused_kernel(
     // lane: 8-byte-per-lane loads run at 0.54-0.70 of the 16-byte rate (MI355X_MICROARCH.md), and the pair is what
     // gets staged anyway
     const int lp = tid & 7, s = 2 * lp, row0 = tid >> 3;
-    const double *base = pos + (int64_t(b) * t_block * n_total + first) * 3 - head;
+    const In *base = pos + (int64_t(b) * t_block * n_total + first) * 3 - head;
     const int64_t row_stride = n_total * 3;
     const int64_t istr = int64_t(64) * R2 * row_stride;       // rows row0 + 64 i -> + i * istr
     // stores: pair p of line kbase + 64 i
@@ -536,8 +540,8 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols400_fused_kernel(
     double2 *out = Y + int64_t(b) * n_pg * (int64_t(R1) * R2 * PG) + int64_t(kbase) * k1_stride + p;
 
     // rows of the current iteration: coordinate e = 16 (pg0 + q) + s, column n2
-    const double *cur = base + (int64_t(row0) * R2 + n2_begin) * row_stride + int64_t(pg0) * 16 + s;
-    struct alignas(8) Pair { double x, y; };   // two consecutive coordinates; the address is 8-byte aligned
+    const In *cur = base + (int64_t(row0) * R2 + n2_begin) * row_stride + int64_t(pg0) * 16 + s;
+    struct alignas(sizeof(In)) Pair { In x, y; };   // two consecutive coordinates; the address is aligned to one of them
     Pair x[LOADS];
     // entry i of (column N2, pair group pg0 + Q) holds live values (else zeros are staged): the coordinates lie
     // in the chunk (the second of a pair may not: the chunk has 3 c coordinates) and their dimensions are kept,
@@ -565,7 +569,7 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols400_fused_kernel(
     _Pragma("unroll") for (int i = 0; i < LOADS; ++i)                                       \
     {                                                                                       \
         const bool row_ = 16 * (Q) < e_lim && MDX_FUSED_ROW(N2, i);                         \
-        const double *q_ = row_ ? (CUR) + i * istr - (16 * (Q) + 1 < e_lim ? 0 : 1) : base; \
+        const In *q_ = row_ ? (CUR) + i * istr - (16 * (Q) + 1 < e_lim ? 0 : 1) : base;     \
         x[i] = *reinterpret_cast<const Pair *>(q_);                                         \
     }
     MDX_FUSED_LOAD(n2_begin, 0, cur)
@@ -598,9 +602,9 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols400_fused_kernel(
             for (int i = 0; i < LOADS; ++i) {
                 // (rows 200..255 of the last round receive zeros: the first stage does not read rows >= 200
                 // and overwrites them; no branch here, or the compiler drains vmcnt at its join)
-                const double v0 = shifted ? x[i].y : x[i].x;
+                const double v0 = double(shifted ? x[i].y : x[i].x);
                 zb[lp][row0 + 64 * i] = make_double2(MDX_FUSED_OK0(n2, q, i) ? v0 : 0.0,
-                                                     MDX_FUSED_OK1(n2, q, i) ? x[i].y : 0.0);
+                                                     MDX_FUSED_OK1(n2, q, i) ? double(x[i].y) : 0.0);
             }
         }
         __syncthreads();
@@ -1780,6 +1784,8 @@ inline int pair_group_multiple(const Shape &sh) { return (sh.r2 == 128 || sh.r2 
 inline bool fuses_sums(const Shape &sh) { return sh.r1 == 400 || sh.r1 == 64; }
 // pass A kernels that can enter a chunk a few coordinates early to make its 128-byte pieces whole cache lines
 inline bool aligns_head(const Shape &sh) { return sh.r1 == 400; }   // (16-point factors: trajectories too short to matter)
+// pass A kernels that read float32 positions where they lie (launch(..., pos32)): the 400-point family with two passes
+inline bool cols_read_f32(const Shape &sh) { return sh.r1 == 400 && sh.r2 >= 2; }
 inline int fused_super_groups(int p_pad) { return (p_pad / PG + SG - 1) / SG; }
 // bytes of the partial-sum records of one launch: [super group][block][R2][200 rows][4 doubles]
 inline size_t fused_part_bytes(const Shape &sh, int p_pad, int n_blocks)
@@ -1847,8 +1853,9 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
                    int64_t first, int64_t n_elem, int64_t t_block, int n_blocks, int zero_dims,
                    int p_pad, const double2 *tw_r1, const double2 *tw_r2, const double2 *twN,
                    double2 *Y, double *Pfull, int accumulate, double2 *part = nullptr,
-                   double *traj = nullptr, double *dsq = nullptr, int head = 0)
+                   double *traj = nullptr, double *dsq = nullptr, int head = 0, const float *pos32 = nullptr)
 {
+    // pos32: the positions as float32 (400-point first factor with fused sums only: cols400_reads_f32); `pos` is unused then
     // >= ~1024 blocks of pass A where the batch allows it
     int split = 4;
     while (split < sh.r2 / 2 && int64_t(p_pad / PG) * split * n_blocks < 1024)
@@ -1894,9 +1901,14 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
         // 0.3 ms more than the layout saves pass A) and pass B takes the layout
         const int pg_major = sh.r2 >= 32 ? 1 : 0;
 #define MDX_MSDFFT_COLS400(R2_)                                                                                       \
-    hipLaunchKernelGGL((msd_fft_cols400_fused_kernel<R2_>), dim3((unsigned)n_sg, (unsigned)fsplit, (unsigned)n_blocks), \
-                       dim3(THREADS), 0, stream, pos, n_total, first, n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y, \
-                       part, head, pg_major)
+    if (pos32)                                                                                                       \
+        hipLaunchKernelGGL((msd_fft_cols400_fused_kernel<R2_, float>), dim3((unsigned)n_sg, (unsigned)fsplit,        \
+                           (unsigned)n_blocks), dim3(THREADS), 0, stream, pos32, n_total, first, n_elem, t_block,    \
+                           zero_dims, p_pad, tw_r1, twN, Y, part, head, pg_major);                                   \
+    else                                                                                                             \
+        hipLaunchKernelGGL((msd_fft_cols400_fused_kernel<R2_>), dim3((unsigned)n_sg, (unsigned)fsplit, (unsigned)n_blocks), \
+                           dim3(THREADS), 0, stream, pos, n_total, first, n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y, \
+                           part, head, pg_major)
         if (sh.r2 == 2) {
             MDX_MSDFFT_COLS400(2);
         } else if (sh.r2 == 4) {

@@ -1,0 +1,13 @@
+#!/bin/bash
+out=gpurun_out/r5x; mkdir -p $out
+timeout -k 10 600 python -m pytest tests -m gpu -x -q -k "msd or onsager or Onsager or c4 or float32" > $out/pytest.log 2>&1; echo "pytest rc=$?"; tail -2 $out/pytest.log | cut -c1-200
+timeout -k 10 400 python bench.py --workload msd --steps 6 --warmup 5 --no-cpu-baseline > $out/msd.json 2> $out/msd.err; echo "bench rc=$?"
+python - <<'PY'
+import json
+d = json.load(open("gpurun_out/r5x/msd.json"))
+print("ms/step %.2f kernel %.2f" % (d["ms_per_step"], d["roofline"]["kernel_ms_per_step"]))
+o = d["onsager"]
+for k in ("class_hbm_f64", "class_hbm_f32", "class_host_f32", "class_host_f32_pinned", "class_file"):
+    v = o[k]
+    print(k, "%.1f ms" % v["ms_per_analysis"], [round(x, 1) for x in v["ms_each"]], {a: round(b, 1) for a, b in v["phases_ms"].items()}, "dev", v.get("max_rel_deviation_from_hbm_f64"))
+PY

@@ -863,3 +863,35 @@ def test_rdf_persistent_blocks_flush_their_lds_bins_between_items(units, monkeyp
     eng.accumulate(a[rest], b[rest], dims)
     assert np.array_equal(all_counts - eng.counts(), want_cross)
     eng.close()
+
+
+@pytest.mark.parametrize("t_block,n_blocks", [(801, 3), (5000, 2), (40000, 1)])
+def test_msd_pass_a_reads_float32_frames_in_place(t_block, n_blocks):
+    """mdx_msd_push_device_f32: float32 frames resident in HBM, a plain particle range — pass A of the 400 x R2 transforms
+    widens them as it stages them.  Bit for bit what the widened float64 frames give through mdx_msd_push_device
+    (zeroed dimension, a range that starts inside a 128-byte line, two groups); engines whose transforms do not read
+    float32 say so."""
+    rng = np.random.default_rng(t_block)
+    n, T = 37, t_block * n_blocks
+    pos32 = (rng.uniform(0, 30, (1, n, 3)) + np.cumsum(rng.normal(0, 0.2, (T, n, 3)), axis=0)).astype(np.float32)
+    d32 = _core.DeviceArray.from_host(pos32)
+    d64 = _core.DeviceArray.from_host(pos32.astype(np.float64))
+    out = []
+    for f32 in (False, True):
+        eng = _core.MsdEngine(t_block, n_blocks, 2)
+        assert eng.reads_f32
+        for g, (first, count, zero) in enumerate(((0, 21, 0), (21, 16, 2))):
+            if f32:
+                eng.push_device_f32(g, d32.ptr, n, first, count, zero)
+            else:
+                eng.push_device(g, d64.ptr, n, first, count, zero)
+        out.append(eng.result())
+        eng.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    small = _core.MsdEngine(300, 2, 1)               # a single-pass length: no float32 route
+    assert not small.reads_f32
+    with pytest.raises(NotImplementedError):
+        small.push_device_f32(0, d32.ptr, n, 0, n)
+    small.close()
+    d32.free()
+    d64.free()
