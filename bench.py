@@ -1425,7 +1425,7 @@ def configs_summary(extra):
     msd = extra.get("msd") or {}
     ons = (msd.get("onsager") or {}) if isinstance(msd, dict) else {}
     more = {}
-    for key in ("class_hbm_f64", "class_host_f32", "class_host_f32_pinned", "class_file"):
+    for key in ("class_hbm_f64", "class_hbm_f32", "class_host_f32", "class_host_f32_pinned", "class_file"):
         leg = ons.get(key)
         if isinstance(leg, dict) and "ms_per_analysis" in leg:
             more[key + "_ms"] = round(leg["ms_per_analysis"], 1)
