@@ -509,8 +509,8 @@ struct mdx_msd {
 static int msd_push_device(mdx_msd *h, int group, const double *d_pos, int64_t n_total, int64_t first,
                            int64_t count, int zero_dims, const float *d_pos32 = nullptr)
 {
-    if (d_pos32 && !(h->own_fft && !h->single && h->fused_sums && msdfft::cols_read_f32(h->shape)))
-        return fail(MDX_ERR_UNSUPPORTED, "float32 positions are read in place by the 400 x R2 two-pass transforms only "
+    if (d_pos32 && !(h->own_fft && (h->single || h->fused_sums) && msdfft::cols_read_f32(h->shape)))
+        return fail(MDX_ERR_UNSUPPORTED, "float32 positions are read in place by the transforms with a 400-point first factor only "
                     "(this engine: n_fft = %lld)", (long long)h->n_fft);
     if (count == 0)
         return MDX_OK;
@@ -573,11 +573,12 @@ static int msd_push_device(mdx_msd *h, int group, const double *d_pos, int64_t n
                 // one pass: positions -> |F|^2 sums and per-frame sums, nothing written in between
                 const int parts = msdfft::launch_single(h->shape, h->stream, d_pos, n_total, first + a0, ne, h->t_block, B,
                                                         zero_dims, p_pad, tw_r1, twN, h->d_pfull.as<double>(),
-                                                        h->d_part.as<double2>(), h->traj(group), h->dsq(group), head);
+                                                        h->d_part.as<double2>(), h->traj(group), h->dsq(group), head,
+                                                        d_pos32);
                 hipLaunchKernelGGL(msdfft::msd_power_fold_kernel, dim3((unsigned)ceil_div(h->nc, 256), (unsigned)B),
                                    dim3(256), 0, h->stream, h->d_pfull.as<double>(), h->shape.r1, h->shape.r2, parts,
                                    h->nc, h->power(group));
-                h->bytes_moved += c * 3 * B * h->t_block * 8;      // the positions, once
+                h->bytes_moved += c * 3 * B * h->t_block * (d_pos32 ? 4 : 8);      // the positions, once
                 continue;
             }
             msdfft::launch(h->shape, h->stream, d_pos, n_total, first + a0, ne, h->t_block, B, zero_dims, p_pad,

@@ -1467,9 +1467,9 @@ __global__ __launch_bounds__(256) void msd_power_fold_kernel(const double *__res
 // Pfull[split][b][k1][k2] (k = k1 + 400 k2) as the row kernels leave it: msd_power_fold_kernel folds the splits.
 constexpr int single_live(int r2) { return 200 * r2; }
 
-template <int R2>
+template <int R2, typename In = double>       // In: double, or float (widened at the staging: see msd_fft_cols400_fused_kernel)
 __global__ __launch_bounds__(THREADS, R2 == 4 ? 1 : 2) void msd_fft_single400_kernel(
-    const double *__restrict__ pos, int64_t n_total, int64_t first, int64_t n_elem, int64_t t_block,
+    const In *__restrict__ pos, int64_t n_total, int64_t first, int64_t n_elem, int64_t t_block,
     int zero_dims, int p_pad, const double2 *__restrict__ tw_r1, const double2 *__restrict__ twN,
     double *__restrict__ Pfull, double2 *__restrict__ part, int head)
 {
@@ -1488,10 +1488,10 @@ __global__ __launch_bounds__(THREADS, R2 == 4 ? 1 : 2) void msd_fft_single400_ke
         s_h[i] = tw_r1[i];
     const int dshift = (3 - head % 3) % 3;           // dimension of chunk coordinate e: (e + dshift) % 3
     const int lp = tid & 7, s = 2 * lp, row0 = tid >> 3;
-    const double *base = pos + (int64_t(b) * t_block * n_total + first) * 3 - head;
+    const In *base = pos + (int64_t(b) * t_block * n_total + first) * 3 - head;
     const int64_t row_stride = n_total * 3;
     const int t_lim = int(min<int64_t>(t_block, LIVE));
-    struct alignas(8) Pair { double x, y; };
+    struct alignas(sizeof(In)) Pair { In x, y; };
     Pair x[LOADS];
     // dead rows re-read the block's last live row and coordinates past the chunk the chunk's first pair (valid
     // memory; zeros are staged for them); a pair whose second coordinate lies past the chunk is read one coordinate
@@ -1500,7 +1500,7 @@ __global__ __launch_bounds__(THREADS, R2 == 4 ? 1 : 2) void msd_fft_single400_ke
 #define MDX_SINGLE_LOAD(PG_, I0, I1)                                                                 \
     {                                                                                                \
         const int64_t e0_ = int64_t(16) * (PG_) + s;                                                 \
-        const double *c_ = e0_ < n_elem ? base + e0_ - (e0_ + 1 < n_elem ? 0 : 1) : base;            \
+        const In *c_ = e0_ < n_elem ? base + e0_ - (e0_ + 1 < n_elem ? 0 : 1) : base;                \
         int r0_ = row0;                                                                              \
         asm volatile("" : "+v"(r0_));                                                                \
         _Pragma("unroll") for (int i = (I0); i < (I1); ++i)                                          \
@@ -1545,8 +1545,8 @@ __global__ __launch_bounds__(THREADS, R2 == 4 ? 1 : 2) void msd_fft_single400_ke
                 const int row = row0 + 64 * i;
                 if (LIVE % 64 == 0 || row < LIVE) {
                     const bool live = row < t_lim;
-                    const double v0 = shifted ? x[i].y : x[i].x;
-                    zb[lp][row] = make_double2(ok0 && live ? v0 : 0.0, ok1 && live ? x[i].y : 0.0);
+                    const double v0 = double(shifted ? x[i].y : x[i].x);
+                    zb[lp][row] = make_double2(ok0 && live ? v0 : 0.0, ok1 && live ? double(x[i].y) : 0.0);
                 }
             }
         }
@@ -1785,7 +1785,8 @@ inline bool fuses_sums(const Shape &sh) { return sh.r1 == 400 || sh.r1 == 64; }
 // pass A kernels that can enter a chunk a few coordinates early to make its 128-byte pieces whole cache lines
 inline bool aligns_head(const Shape &sh) { return sh.r1 == 400; }   // (16-point factors: trajectories too short to matter)
 // pass A kernels that read float32 positions where they lie (launch(..., pos32)): the 400-point family with two passes
-inline bool cols_read_f32(const Shape &sh) { return sh.r1 == 400 && sh.r2 >= 2; }
+// (and the single-pass kernel of the same first factor)
+inline bool cols_read_f32(const Shape &sh) { return sh.r1 == 400; }
 inline int fused_super_groups(int p_pad) { return (p_pad / PG + SG - 1) / SG; }
 // bytes of the partial-sum records of one launch: [super group][block][R2][200 rows][4 doubles]
 inline size_t fused_part_bytes(const Shape &sh, int p_pad, int n_blocks)
@@ -1807,13 +1808,17 @@ inline size_t single_part_bytes(const Shape &sh, int n_blocks)
 inline int launch_single(const Shape &sh, hipStream_t stream, const double *pos, int64_t n_total, int64_t first,
                          int64_t n_elem, int64_t t_block, int n_blocks, int zero_dims, int p_pad,
                          const double2 *tw_r1, const double2 *twN, double *Pfull, double2 *part, double *traj,
-                         double *dsq, int head)
+                         double *dsq, int head, const float *pos32 = nullptr)
 {
     const int splits = std::min(single_splits(n_blocks), p_pad / PG);
     const dim3 grid((unsigned)splits, (unsigned)n_blocks);
 #define MDX_MSDFFT_SINGLE(R2_)                                                                                   \
-    hipLaunchKernelGGL((msd_fft_single400_kernel<R2_>), grid, dim3(THREADS), 0, stream, pos, n_total, first, n_elem, \
-                       t_block, zero_dims, p_pad, tw_r1, twN, Pfull, part, head)
+    if (pos32)                                                                                                   \
+        hipLaunchKernelGGL((msd_fft_single400_kernel<R2_, float>), grid, dim3(THREADS), 0, stream, pos32, n_total, first, \
+                           n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Pfull, part, head);                    \
+    else                                                                                                         \
+        hipLaunchKernelGGL((msd_fft_single400_kernel<R2_>), grid, dim3(THREADS), 0, stream, pos, n_total, first, n_elem, \
+                           t_block, zero_dims, p_pad, tw_r1, twN, Pfull, part, head)
     if (sh.r2 == 1) {
         MDX_MSDFFT_SINGLE(1);
     } else if (sh.r2 == 2) {
