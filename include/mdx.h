@@ -315,8 +315,9 @@ int mdx_msd_push_device(mdx_msd_t h, int group, const double *d_pos, int64_t n_t
 /* The same for float32 positions resident in HBM — what a trajectory reader or a GPU MD engine holds —, a plain
  * particle range with nothing to prepare (no unwrapping, no molecule centres, no shift): pass A widens them as it
  * stages them, so no float64 copy is made (C4: 18 GB of traffic per group less).  Only the engine's transforms
- * with a 400-point first factor read float32 in place (mdx_msd_transform: r1 == 400 — the single-pass kernel and the
- * 400 x R2 family, which serve most block lengths up to 204 800 frames); other engines return MDX_ERR_UNSUPPORTED
+ * with a 400- or 64-point first factor read float32 in place (mdx_msd_transform: r1 == 400 or 64 — the single-pass
+ * kernel, the 400 x R2 family and 2^13 .. 2^16: every block length up to 204 800 frames); other engines (2^18 .. 2^20,
+ * rocFFT) return MDX_ERR_UNSUPPORTED
  * and the caller goes through mdx_msd_push_frames_device.  Results equal those of the widened
  * frames bit for bit. */
 int mdx_msd_push_device_f32(mdx_msd_t h, int group, const float *d_pos, int64_t n_total, int64_t first,

@@ -554,9 +554,10 @@ class MsdEngine(_Engine):
     @property
     def reads_f32(self):
         """Whether the first pass of this engine reads float32 positions where they lie (``push_device_f32``): the
-        transforms with a 400-point first factor (the single-pass kernel, the 400 x R2 family)."""
+        transforms with a 400- or 64-point first factor (the single-pass kernel, the 400 x R2 family, 2^13 .. 2^16:
+        every block length up to 204 800 frames)."""
         own, r1, _r2 = self.transform
-        return bool(own) and r1 == 400
+        return bool(own) and r1 in (400, 64)
 
     def push_device_f32(self, group, d_pos, n_total, first, count, zero_dims=0):
         """``mdx_msd_push_device_f32``: a plain particle range of float32 frames resident in HBM, widened by pass A as

@@ -510,7 +510,7 @@ static int msd_push_device(mdx_msd *h, int group, const double *d_pos, int64_t n
                            int64_t count, int zero_dims, const float *d_pos32 = nullptr)
 {
     if (d_pos32 && !(h->own_fft && (h->single || h->fused_sums) && msdfft::cols_read_f32(h->shape)))
-        return fail(MDX_ERR_UNSUPPORTED, "float32 positions are read in place by the transforms with a 400-point first factor only "
+        return fail(MDX_ERR_UNSUPPORTED, "float32 positions are read in place by the transforms with a 400- or 64-point first factor only "
                     "(this engine: n_fft = %lld)", (long long)h->n_fft);
     if (count == 0)
         return MDX_OK;

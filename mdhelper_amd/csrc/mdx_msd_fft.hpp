@@ -747,9 +747,9 @@ __global__ __launch_bounds__(256) void msd_partials_reduce_kernel(const double2 
 // entries read a valid dummy address and are zeroed when staged), placeholder stores give the loop
 // entry the back edge's queue of memory operations, and W_N^m comes from two short tables
 // (m = 32 a + b) so that the block's LDS stays below half a CU's with the 8 KB of running sums.
-template <int R1, int R2>
+template <int R1, int R2, typename In = double>     // In: double, or float (widened at the staging, as in the 400-point kernel)
 __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols_small_fused_kernel(
-    const double *__restrict__ pos, int64_t n_total, int64_t first, int64_t n_elem, int64_t t_block,
+    const In *__restrict__ pos, int64_t n_total, int64_t first, int64_t n_elem, int64_t t_block,
     int zero_dims, int p_pad, const double2 *__restrict__ tw_r1, const double2 *__restrict__ twN,
     double2 *__restrict__ Y, double2 *__restrict__ part, int pg_major)
 {
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols_small_fused_kernel(
 
     // loads: coordinate s of the pair group, live row n1, PER consecutive columns from c_in
     const int s = tid & 15, n1 = (tid >> 4) % LIVE, c_in = (tid >> 4) / LIVE * PER;
-    const double *base = pos + (int64_t(b) * t_block * n_total + first) * 3;
+    const In *base = pos + (int64_t(b) * t_block * n_total + first) * 3;
     const int64_t row_stride = n_total * 3;
     double *dst = reinterpret_cast<double *>(&zb[s >> 1][c_in][0]) + (s & 1);
     // stores: pair p, line k1, PER consecutive columns from c_out
@@ -795,12 +795,12 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols_small_fused_kernel(
     const int t_lim = int(min<int64_t>(t_block - int64_t(n1) * R2 - c_in, int64_t(1) << 30));        // N2 + i < t_lim
 #define MDX_SF_OK(N2, Q, I) \
     (16 * (Q) < e_lim && !((zero_dims >> ((pg0 + (Q) + s) % 3)) & 1) && (N2) + (I) < t_lim)
-    const double *cur = base + (int64_t(n1) * R2 + g_begin * NC + c_in) * row_stride + int64_t(pg0) * 16 + s;
-    double x[PER];
+    const In *cur = base + (int64_t(n1) * R2 + g_begin * NC + c_in) * row_stride + int64_t(pg0) * 16 + s;
+    In x[PER];
 #define MDX_SF_LOAD(N2, Q, CUR)                                                              \
     _Pragma("unroll") for (int i = 0; i < PER; ++i)                                          \
     {                                                                                        \
-        const double *q_ = MDX_SF_OK(N2, Q, i) ? (CUR) + i * row_stride : base;              \
+        const In *q_ = MDX_SF_OK(N2, Q, i) ? (CUR) + i * row_stride : base;                  \
         x[i] = *q_;                                                                          \
     }
     MDX_SF_LOAD(g_begin * NC, 0, cur)
@@ -817,7 +817,7 @@ __global__ __launch_bounds__(THREADS, 4) void msd_fft_cols_small_fused_kernel(
     for (int it = 0; it < n_iter; ++it) {
 #pragma unroll
         for (int i = 0; i < PER; ++i)
-            dst[2 * (i * ZS + n1)] = MDX_SF_OK(n2, q, i) ? x[i] : 0.0;
+            dst[2 * (i * ZS + n1)] = MDX_SF_OK(n2, q, i) ? double(x[i]) : 0.0;
         __syncthreads();
         const bool wrap = q + 1 == n_q;
         {   // per-frame sums of this pair group: lane pair (2 f, 2 f + 1) owns frame f = 32 wave + lane / 2
@@ -1785,8 +1785,8 @@ inline bool fuses_sums(const Shape &sh) { return sh.r1 == 400 || sh.r1 == 64; }
 // pass A kernels that can enter a chunk a few coordinates early to make its 128-byte pieces whole cache lines
 inline bool aligns_head(const Shape &sh) { return sh.r1 == 400; }   // (16-point factors: trajectories too short to matter)
 // pass A kernels that read float32 positions where they lie (launch(..., pos32)): the 400-point family with two passes
-// (and the single-pass kernel of the same first factor)
-inline bool cols_read_f32(const Shape &sh) { return sh.r1 == 400; }
+// (the single-pass kernel of the 400-point first factor included), the 64-point family: every shape with fused sums
+inline bool cols_read_f32(const Shape &sh) { return sh.r1 == 400 || sh.r1 == 64; }
 inline int fused_super_groups(int p_pad) { return (p_pad / PG + SG - 1) / SG; }
 // bytes of the partial-sum records of one launch: [super group][block][R2][200 rows][4 doubles]
 inline size_t fused_part_bytes(const Shape &sh, int p_pad, int n_blocks)
@@ -1878,8 +1878,12 @@ inline void launch(const Shape &sh, hipStream_t stream, const double *pos, int64
         const int fsplit = std::min(ng, slots_split(int64_t(n_sg) * n_blocks, 1, 64));
         const dim3 gf((unsigned)n_sg, (unsigned)fsplit, (unsigned)n_blocks);
 #define MDX_MSDFFT_SMALL_FUSED(A, B)                                                                              \
-    hipLaunchKernelGGL((msd_fft_cols_small_fused_kernel<A, B>), gf, dim3(THREADS), 0, stream, pos, n_total, first, \
-                       n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y, part, pgm);                             \
+    if (pos32)                                                                                                    \
+        hipLaunchKernelGGL((msd_fft_cols_small_fused_kernel<A, B, float>), gf, dim3(THREADS), 0, stream, pos32, n_total, \
+                           first, n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y, part, pgm);                   \
+    else                                                                                                          \
+        hipLaunchKernelGGL((msd_fft_cols_small_fused_kernel<A, B>), gf, dim3(THREADS), 0, stream, pos, n_total, first, \
+                           n_elem, t_block, zero_dims, p_pad, tw_r1, twN, Y, part, pgm);                         \
     hipLaunchKernelGGL(msd_partials_reduce_kernel, dim3((unsigned)((int64_t(B) * (A / 2) + 255) / 256),          \
                        (unsigned)n_blocks), dim3(256), 0, stream, part, n_sg, B, 512 / A, A / 2, t_block, traj, dsq); \
     launch_rows<A, B>(gb, stream, Y, p_pad, tw_r2, Pfull, accumulate, pgm)

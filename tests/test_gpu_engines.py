@@ -865,7 +865,8 @@ def test_rdf_persistent_blocks_flush_their_lds_bins_between_items(units, monkeyp
     eng.close()
 
 
-@pytest.mark.parametrize("t_block,n_blocks", [(150, 9), (400, 5), (777, 4), (801, 3), (5000, 2), (40000, 1)])
+@pytest.mark.parametrize("t_block,n_blocks", [(150, 9), (400, 5), (777, 4), (801, 3), (4000, 3), (5000, 2), (8000, 2),
+                                              (16384, 1), (30000, 1), (40000, 1)])
 def test_msd_pass_a_reads_float32_frames_in_place(t_block, n_blocks):
     """mdx_msd_push_device_f32: float32 frames resident in HBM, a plain particle range — pass A of the 400 x R2 transforms
     widens them as it stages them.  Bit for bit what the widened float64 frames give through mdx_msd_push_device
@@ -888,7 +889,7 @@ def test_msd_pass_a_reads_float32_frames_in_place(t_block, n_blocks):
         out.append(eng.result())
         eng.close()
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
-    other = _core.MsdEngine(4000, 1, 1)              # 2^13 = 64 x 128: no float32 route
+    other = _core.MsdEngine(110000, 1, 1)            # 2^18 = 512 x 512: no float32 route
     assert not other.reads_f32
     with pytest.raises(NotImplementedError):
         other.push_device_f32(0, d32.ptr, n, 0, n)
