@@ -586,7 +586,11 @@ class Onsager(SerialAnalysisBase):
                     if self._unwrap:
                         eng.set_initial_images(None if self._images0 is None else
                                                np.sign(self._images0[first + a:first + a + c]))
-                    eng.push_frames_device(g, buf, c, None, unwrap_dims=unwrap_dims, zero_dims=zero_mask)
+                    if unwrap_dims is None and eng.reads_f32:
+                        # nothing to prepare: the first pass reads the chunk's float32 rows where they lie
+                        eng.push_device_f32(g, buf.ptr, c, 0, c, zero_mask)
+                    else:
+                        eng.push_frames_device(g, buf, c, None, unwrap_dims=unwrap_dims, zero_dims=zero_mask)
                     k += 1
             eng.synchronize()
         finally:
